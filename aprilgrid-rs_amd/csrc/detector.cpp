@@ -1,0 +1,737 @@
+// detector.cpp -- implementation of the C ABI in include/aprilgrid_amd.h: the detector handle
+// (mirror of aprilgrid::detector::TagDetector), device workspace, chain enqueue / fetch,
+// profiling events and the parity-test hooks.  Compiled by hipcc; links only libamdhip64.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/aprilgrid_amd.h"
+#include "chain_kernels.h"
+#include "host_tail.hpp"
+
+using namespace agx;
+
+namespace {
+
+const char *kKernelNames[K_COUNT] = {"k_blur_hessian", "k_threshold", "k_union",
+                                     "k_centroid",     "k_refine",    "k_filter_sort"};
+
+struct EventPair {
+    hipEvent_t a, b;
+    int kernel;
+};
+
+}  // namespace
+
+struct agx_detector {
+    int family = AGX_T36H11;
+    FamilyInfo fam{};
+    agx_params params{};
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    RefineConsts rc{};
+    float blur_w[7]{};
+    uint32_t lim_cand = 0, lim_roots = 0, lim_out = 0;
+
+    // workspace (device)
+    ChainArgs args{};
+    size_t cap_frames = 0;        // frames the dense planes hold
+    long long cap_plane = 0;      // pixels per frame the dense planes hold
+    uint32_t alloc_cand = 0, alloc_roots = 0, alloc_out = 0;
+    std::vector<void *> device_allocs;
+    // staging for the single-frame host API
+    uint8_t *d_stage = nullptr;
+    size_t stage_bytes = 0;
+    // pinned host mirrors
+    FrameCounters *h_ctr = nullptr;
+    size_t h_ctr_frames = 0;
+    uint32_t *h_total = nullptr;
+    float *h_out = nullptr;
+    size_t h_out_records = 0;
+    float *d_out_internal = nullptr;  // workspace copy of args.out
+    bool external_out = false;       // last batch wrote into caller-owned device memory
+
+    bool enqueued = false;
+    bool profiling = false;
+    std::vector<EventPair> pending_events;
+    std::vector<hipEvent_t> free_events;
+    double prof_ms[K_COUNT]{};
+    uint64_t prof_launches[K_COUNT]{};
+
+    std::string last_error;
+};
+
+namespace {
+
+std::string g_create_error;  // reason of the last failed agx_detector_create (det == NULL)
+
+int fail(agx_detector *d, int status, const std::string &msg)
+{
+    if (d) d->last_error = msg;
+    return status;
+}
+
+#define HIP_TRY(det, expr)                                                                     \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail((det), AGX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+// Blur taps, reference src/image_util.rs:111-124 (sigma = 1.5 at the call site detector.rs:410)
+void make_blur_weights(float sigma, float w[7])
+{
+    const int radius = (int)std::ceil(sigma * 2.0f);  // == 3
+    const float two_sigma_sq = 2.0f * sigma * sigma;
+    float sum = 0.0f;
+    for (int i = 0; i < 2 * radius + 1; ++i) {
+        const float x = (float)(i - radius);
+        const float v = std::exp(-(x * x) / two_sigma_sq);
+        w[i] = v;
+        sum += v;
+    }
+    for (int i = 0; i < 2 * radius + 1; ++i) w[i] /= sum;
+}
+
+// Constants of rochade_refine for half_size_patch = 2 (the only value the reference passes,
+// detector.rs:430): cone kernel (:240-254) and the 25x6 pseudo-inverse of the quadratic
+// design matrix (:208-237).  The design's normal matrix is block diagonal on the symmetric
+// 5x5 grid (odd moments vanish): {xy}, {x}, {y} decouple and {x^2, y^2, 1} is a 3x3 block,
+// inverted here by its adjugate in binary64; one rounding to binary32.
+void make_refine_consts(RefineConsts &rc)
+{
+    const int half = 2, ks = 5;
+    double sx2 = 0, sx4 = 0;
+    for (int c = 0; c < ks; ++c) {
+        const double x = c - half;
+        sx2 += x * x;
+        sx4 += x * x * x * x;
+    }
+    const double n1 = ks;
+    // moments over the grid
+    const double m_x4 = n1 * sx4, m_x2y2 = sx2 * sx2, m_x2 = n1 * sx2, m_1 = n1 * n1;
+    // block {x^2, y^2, 1}
+    const double B[3][3] = {{m_x4, m_x2y2, m_x2}, {m_x2y2, m_x4, m_x2}, {m_x2, m_x2, m_1}};
+    double adj[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            const int r0 = (j + 1) % 3, r1 = (j + 2) % 3, c0 = (i + 1) % 3, c1 = (i + 2) % 3;
+            adj[i][j] = B[r0][c0] * B[r1][c1] - B[r0][c1] * B[r1][c0];
+        }
+    const double det = B[0][0] * adj[0][0] + B[0][1] * adj[1][0] + B[0][2] * adj[2][0];
+    int i = 0;
+    for (int r = 0; r < ks; ++r)
+        for (int c = 0; c < ks; ++c, ++i) {
+            const double x = c - half, y = r - half;
+            const double q[3] = {x * x, y * y, 1.0};
+            double blk[3];
+            for (int a = 0; a < 3; ++a) blk[a] = (adj[a][0] * q[0] + adj[a][1] * q[1] + adj[a][2] * q[2]) / det;
+            rc.pmat[i * 6 + 0] = (float)blk[0];          // x^2
+            rc.pmat[i * 6 + 1] = (float)(x * y / m_x2y2 + 0.0); // xy (+0.0: no negative zeros)
+            rc.pmat[i * 6 + 2] = (float)blk[1];          // y^2
+            rc.pmat[i * 6 + 3] = (float)(x / m_x2 + 0.0);      // x
+            rc.pmat[i * 6 + 4] = (float)(y / m_x2 + 0.0);      // y
+            rc.pmat[i * 6 + 5] = (float)blk[2];          // 1
+        }
+    const float gamma = (float)half;
+    float s = 0.0f;
+    for (int a = 0; a < ks; ++a)
+        for (int b = 0; b < ks; ++b) {
+            const float da = gamma - (float)a, db = gamma - (float)b;
+            rc.cone[a * ks + b] = std::max(0.0f, gamma + 1.0f - std::sqrt(da * da + db * db));
+        }
+    for (int a = 0; a < ks * ks; ++a) s += rc.cone[a];
+    for (int a = 0; a < ks * ks; ++a) rc.cone[a] = rc.cone[a] / s;
+}
+
+template <typename T>
+int dev_alloc(agx_detector *d, T *&ptr, size_t count)
+{
+    void *p = nullptr;
+    HIP_TRY(d, hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)));
+    d->device_allocs.push_back(p);
+    ptr = (T *)p;
+    return AGX_OK;
+}
+
+void free_workspace(agx_detector *d)
+{
+    for (void *p : d->device_allocs) (void)hipFree(p);
+    d->device_allocs.clear();
+    d->cap_frames = 0;
+    d->cap_plane = 0;
+    if (d->h_ctr) (void)hipHostFree(d->h_ctr);
+    if (d->h_out) (void)hipHostFree(d->h_out);
+    d->h_ctr = nullptr;
+    d->h_out = nullptr;
+    d->h_ctr_frames = 0;
+    d->h_out_records = 0;
+}
+
+uint32_t clamp_u32(unsigned long long v, uint32_t lo, uint32_t hi)
+{
+    return (uint32_t)std::min<unsigned long long>(std::max<unsigned long long>(v, lo), hi);
+}
+
+// (Re)allocate the workspace for n_frames frames of W x H.  Never called inside a timed
+// region once a configuration has been seen.
+int ensure_workspace(agx_detector *d, int n_frames, int W, int H)
+{
+    const long long plane = (long long)W * H;
+    const uint32_t cap_cand = d->lim_cand ? d->lim_cand : clamp_u32((unsigned long long)plane / 2, 4096, 1u << 28);
+    const uint32_t cap_roots = d->lim_roots ? d->lim_roots : clamp_u32((unsigned long long)plane / 16, 1024, 1u << 26);
+    const uint32_t cap_out = d->lim_out ? d->lim_out : clamp_u32((unsigned long long)plane / 64, 256, 8192);
+    ChainArgs &a = d->args;
+    if ((size_t)n_frames <= d->cap_frames && plane <= d->cap_plane && cap_cand <= d->alloc_cand &&
+        cap_roots <= d->alloc_roots && cap_out <= d->alloc_out) {
+        a.cap_cand = cap_cand;
+        a.cap_roots = cap_roots;
+        a.cap_out = cap_out;
+        return AGX_OK;
+    }
+    HIP_TRY(d, hipStreamSynchronize(d->stream));
+    free_workspace(d);
+    const size_t F = (size_t)n_frames;
+    int rc;
+    if ((rc = dev_alloc(d, a.blur, F * plane))) return rc;
+    if ((rc = dev_alloc(d, a.resp, F * plane))) return rc;
+    if ((rc = dev_alloc(d, a.slot_plane, F * plane))) return rc;
+    if ((rc = dev_alloc(d, a.ctr, F))) return rc;
+    if ((rc = dev_alloc(d, a.total_out, 1))) return rc;
+    if ((rc = dev_alloc(d, a.cand, F * cap_cand))) return rc;
+    if ((rc = dev_alloc(d, a.parent, F * cap_cand))) return rc;
+    if ((rc = dev_alloc(d, a.sumx, F * cap_cand))) return rc;
+    if ((rc = dev_alloc(d, a.sumy, F * cap_cand))) return rc;
+    if ((rc = dev_alloc(d, a.cnt, F * cap_cand))) return rc;
+    if ((rc = dev_alloc(d, a.minidx, F * cap_cand))) return rc;
+    if ((rc = dev_alloc(d, a.roots, F * cap_roots))) return rc;
+    if ((rc = dev_alloc(d, a.refined, F * cap_roots))) return rc;
+    if ((rc = dev_alloc(d, d->d_out_internal, F * cap_out * 5))) return rc;
+    HIP_TRY(d, hipHostMalloc((void **)&d->h_ctr, (F + 1) * sizeof(FrameCounters), hipHostMallocDefault));
+    d->h_total = (uint32_t *)(d->h_ctr + F);
+    d->h_ctr_frames = F;
+    HIP_TRY(d, hipHostMalloc((void **)&d->h_out, F * cap_out * 5 * sizeof(float), hipHostMallocDefault));
+    d->h_out_records = F * cap_out;
+    d->cap_frames = F;
+    d->cap_plane = plane;
+    d->alloc_cand = a.cap_cand = cap_cand;
+    d->alloc_roots = a.cap_roots = cap_roots;
+    d->alloc_out = a.cap_out = cap_out;
+    return AGX_OK;
+}
+
+hipEvent_t get_event(agx_detector *d)
+{
+    if (!d->free_events.empty()) {
+        hipEvent_t e = d->free_events.back();
+        d->free_events.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+// Fold finished event pairs into the per-kernel totals (caller has synchronised the stream).
+void harvest_events(agx_detector *d)
+{
+    for (EventPair &p : d->pending_events) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            d->prof_ms[p.kernel] += ms;
+            d->prof_launches[p.kernel] += 1;
+        }
+        d->free_events.push_back(p.a);
+        d->free_events.push_back(p.b);
+    }
+    d->pending_events.clear();
+}
+
+int enqueue_chain(agx_detector *d)
+{
+    ChainArgs &a = d->args;
+    HIP_TRY(d, hipMemsetAsync(a.ctr, 0, (size_t)a.n_frames * sizeof(FrameCounters), d->stream));
+    HIP_TRY(d, hipMemsetAsync(a.total_out, 0, sizeof(uint32_t), d->stream));
+    for (int k = 0; k < K_COUNT; ++k) {
+        EventPair ev{nullptr, nullptr, k};
+        if (d->profiling) {
+            ev.a = get_event(d);
+            ev.b = get_event(d);
+            HIP_TRY(d, hipEventRecord(ev.a, d->stream));
+        }
+        hipError_t e = (hipError_t)launch_kernel(k, a, d->rc, d->stream);
+        if (e != hipSuccess)
+            return fail(d, AGX_ERR_HIP, std::string("launch ") + kKernelNames[k] + ": " + hipGetErrorString(e));
+        if (d->profiling) {
+            HIP_TRY(d, hipEventRecord(ev.b, d->stream));
+            d->pending_events.push_back(ev);
+        }
+    }
+    d->enqueued = true;
+    return AGX_OK;
+}
+
+int frame_status_of(const FrameCounters &c, uint32_t cap_per_frame)
+{
+    if (c.flags & (FLAG_CAND_OVERFLOW | FLAG_ROOT_OVERFLOW | FLAG_OUT_OVERFLOW)) return AGX_ERR_CAPACITY;
+    if (c.n_out > cap_per_frame) return AGX_ERR_CAPACITY;
+    return AGX_OK;
+}
+
+bool valid_format(int f) { return f == AGX_L8 || f == AGX_L16 || f == AGX_RGB8; }
+int bytes_per_px(int f) { return f == AGX_L8 ? 1 : (f == AGX_L16 ? 2 : 3); }
+
+}  // namespace
+
+extern "C" {
+
+int agx_abi_version(void) { return AGX_ABI_VERSION; }
+
+const char *agx_status_string(int status)
+{
+    switch (status) {
+    case AGX_OK: return "ok";
+    case AGX_ERR_ARG: return "invalid argument";
+    case AGX_ERR_FORMAT: return "unsupported pixel format";
+    case AGX_ERR_CAPACITY: return "capacity exceeded";
+    case AGX_ERR_HIP: return "HIP runtime error";
+    case AGX_ERR_NO_DEVICE: return "no usable gfx950 device";
+    case AGX_ERR_FAMILY: return "unknown tag family";
+    case AGX_ERR_STATE: return "invalid call sequence";
+    default: return "unknown status";
+    }
+}
+
+const char *agx_last_error(const agx_detector *det) { return det ? det->last_error.c_str() : g_create_error.c_str(); }
+
+int agx_family_from_str(const char *name, int *family_out)
+{
+    if (!name || !family_out) return AGX_ERR_ARG;
+    static const struct { const char *lo, *up; int fam; } kNames[] = {
+        {"t16h5", "T16H5", AGX_T16H5},     {"t25h7", "T25H7", AGX_T25H7},
+        {"t25h9", "T25H9", AGX_T25H9},     {"t36h11", "T36H11", AGX_T36H11},
+        {"t36h11b1", "T36H11B1", AGX_T36H11B1}};
+    for (const auto &n : kNames)
+        if (!std::strcmp(name, n.lo) || !std::strcmp(name, n.up)) {
+            *family_out = n.fam;
+            return AGX_OK;
+        }
+    return AGX_ERR_FAMILY;
+}
+
+void agx_default_params(agx_params *out)
+{
+    if (!out) return;
+    out->tag_spacing_ratio = 0.3f;
+    out->min_saddle_angle = 30.0f;
+    out->max_saddle_angle = 60.0f;
+    out->max_num_of_boards = 2;
+}
+
+int agx_detector_create(int family, const agx_params *params, int device, agx_detector **out)
+{
+    if (!out) return AGX_ERR_ARG;
+    *out = nullptr;
+    g_create_error.clear();
+    FamilyInfo fam;
+    if (!family_info(family, fam)) return AGX_ERR_FAMILY;
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev <= 0 || device < 0 || device >= n_dev) {
+        g_create_error = std::string("hipGetDeviceCount: ") + hipGetErrorString(e) + ", devices=" +
+                         std::to_string(n_dev) + ", requested " + std::to_string(device);
+        return AGX_ERR_NO_DEVICE;
+    }
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) {
+        g_create_error = std::string("hipGetDeviceProperties: ") + hipGetErrorString(e);
+        return AGX_ERR_NO_DEVICE;
+    }
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {  // the code object is gfx950 only
+        g_create_error = std::string("device arch is '") + prop.gcnArchName + "', need gfx950";
+        return AGX_ERR_NO_DEVICE;
+    }
+    e = hipSetDevice(device);
+    if (e != hipSuccess) {
+        g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e);
+        return AGX_ERR_NO_DEVICE;
+    }
+    std::unique_ptr<agx_detector> d(new agx_detector());
+    d->family = family;
+    d->fam = fam;
+    if (params) d->params = *params;
+    else agx_default_params(&d->params);
+    d->device = device;
+    e = hipStreamCreateWithFlags(&d->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        g_create_error = std::string("hipStreamCreateWithFlags: ") + hipGetErrorString(e);
+        return AGX_ERR_HIP;
+    }
+    d->stream = d->own_stream;
+    make_blur_weights(1.5f, d->blur_w);
+    make_refine_consts(d->rc);
+    *out = d.release();
+    return AGX_OK;
+}
+
+void agx_detector_destroy(agx_detector *det)
+{
+    if (!det) return;
+    (void)hipSetDevice(det->device);
+    (void)hipStreamSynchronize(det->stream);
+    harvest_events(det);
+    for (hipEvent_t e : det->free_events) (void)hipEventDestroy(e);
+    free_workspace(det);
+    if (det->d_stage) (void)hipFree(det->d_stage);
+    if (det->own_stream) (void)hipStreamDestroy(det->own_stream);
+    delete det;
+}
+
+int agx_detector_family_info(const agx_detector *det, int *edge_bits, int *border_bits, int *hamming_distance,
+                             const uint64_t **codes, int *n_codes)
+{
+    if (!det) return AGX_ERR_ARG;
+    if (edge_bits) *edge_bits = det->fam.edge;
+    if (border_bits) *border_bits = det->fam.border;
+    if (hamming_distance) *hamming_distance = det->fam.hamming;
+    if (codes) *codes = det->fam.codes;
+    if (n_codes) *n_codes = det->fam.n_codes;
+    return AGX_OK;
+}
+
+int agx_detector_set_limits(agx_detector *det, uint32_t max_candidates, uint32_t max_clusters, uint32_t max_saddles)
+{
+    if (!det) return AGX_ERR_ARG;
+    if (max_candidates >= (1u << 30) || max_saddles > 16384) return AGX_ERR_ARG;
+    det->lim_cand = max_candidates;
+    det->lim_roots = max_clusters;
+    det->lim_out = max_saddles;
+    return AGX_OK;
+}
+
+int agx_detector_set_stream(agx_detector *det, void *hip_stream)
+{
+    if (!det) return AGX_ERR_ARG;
+    (void)hipSetDevice(det->device);
+    (void)hipStreamSynchronize(det->stream);
+    det->stream = hip_stream ? (hipStream_t)hip_stream : det->own_stream;
+    return AGX_OK;
+}
+
+int agx_detector_sync(agx_detector *det)
+{
+    if (!det) return AGX_ERR_ARG;
+    HIP_TRY(det, hipSetDevice(det->device));
+    HIP_TRY(det, hipStreamSynchronize(det->stream));
+    return AGX_OK;
+}
+
+static int batch_enqueue_impl(agx_detector *det, const void *d_frames, int n_frames, int width, int height,
+                              size_t row_stride_bytes, size_t frame_stride_bytes, int format, void *d_saddles,
+                              uint32_t saddle_capacity, void *d_frame_table)
+{
+    if (!det || !d_frames || n_frames <= 0) return fail(det, AGX_ERR_ARG, "null frames or n_frames <= 0");
+    if (!valid_format(format)) return fail(det, AGX_ERR_FORMAT, "format must be AGX_L8, AGX_L16 or AGX_RGB8");
+    if (width < 2 || height < 2) return fail(det, AGX_ERR_ARG, "width and height must be >= 2");
+    if ((long long)width * height >= (1ll << 30)) return fail(det, AGX_ERR_ARG, "frame too large (>= 2^30 px)");
+    if (row_stride_bytes < (size_t)width * bytes_per_px(format) || (row_stride_bytes & 3) ||
+        ((uintptr_t)d_frames & 3) || (frame_stride_bytes & 3) ||
+        (n_frames > 1 && frame_stride_bytes < row_stride_bytes * (size_t)height))
+        return fail(det, AGX_ERR_ARG, "strides must be multiples of 4 bytes and cover the frame");
+    if (n_frames > 65535) return fail(det, AGX_ERR_ARG, "at most 65535 frames per batch");
+    HIP_TRY(det, hipSetDevice(det->device));
+    int rc = ensure_workspace(det, n_frames, width, height);
+    if (rc) return rc;
+    ChainArgs &a = det->args;
+    a.frames = (const uint8_t *)d_frames;
+    a.frame_stride = (long long)frame_stride_bytes;
+    a.row_stride = (int)row_stride_bytes;
+    a.fmt = format;
+    a.W = width;
+    a.H = height;
+    a.n_frames = n_frames;
+    a.plane = (long long)width * height;
+    std::memcpy(a.w, det->blur_w, sizeof(a.w));
+    a.min_angle = det->params.min_saddle_angle;
+    a.max_angle = det->params.max_saddle_angle;
+    if (d_saddles) {
+        a.out = (float *)d_saddles;
+        a.out_total_cap = saddle_capacity;
+        a.frame_table = (uint32_t *)d_frame_table;
+        det->external_out = true;
+    } else {
+        a.out = det->d_out_internal;
+        a.out_total_cap = (uint32_t)std::min<size_t>((size_t)n_frames * a.cap_out, 0xffffffffu);
+        a.frame_table = nullptr;
+        det->external_out = false;
+    }
+    if (!plan_k1(a, 0)) return fail(det, AGX_ERR_ARG, "unsupported frame geometry");
+    return enqueue_chain(det);
+}
+
+int agx_saddles_batch_enqueue(agx_detector *det, const void *d_frames, int n_frames, int width, int height,
+                              size_t row_stride_bytes, size_t frame_stride_bytes, int format)
+{
+    return batch_enqueue_impl(det, d_frames, n_frames, width, height, row_stride_bytes, frame_stride_bytes, format,
+                              nullptr, 0, nullptr);
+}
+
+int agx_saddles_batch_enqueue_to(agx_detector *det, const void *d_frames, int n_frames, int width, int height,
+                                 size_t row_stride_bytes, size_t frame_stride_bytes, int format, void *d_saddles,
+                                 uint32_t saddle_capacity, void *d_frame_table)
+{
+    if (!d_saddles || !d_frame_table || ((uintptr_t)d_saddles & 3) || ((uintptr_t)d_frame_table & 3))
+        return fail(det, AGX_ERR_ARG, "null or misaligned output buffers");
+    return batch_enqueue_impl(det, d_frames, n_frames, width, height, row_stride_bytes, frame_stride_bytes, format,
+                              d_saddles, saddle_capacity, d_frame_table);
+}
+
+int agx_saddles_batch_fetch(agx_detector *det, agx_saddle *out, uint32_t cap_per_frame, uint32_t *counts,
+                            int *frame_status)
+{
+    if (!det || !counts || (!out && cap_per_frame)) return fail(det, AGX_ERR_ARG, "null output");
+    if (!det->enqueued) return fail(det, AGX_ERR_STATE, "no batch enqueued");
+    if (det->external_out) return fail(det, AGX_ERR_STATE, "last batch wrote to caller-owned device buffers");
+    HIP_TRY(det, hipSetDevice(det->device));
+    const ChainArgs &a = det->args;
+    const size_t F = (size_t)a.n_frames;
+    HIP_TRY(det, hipMemcpyAsync(det->h_ctr, a.ctr, F * sizeof(FrameCounters), hipMemcpyDeviceToHost, det->stream));
+    HIP_TRY(det, hipMemcpyAsync(det->h_total, a.total_out, sizeof(uint32_t), hipMemcpyDeviceToHost, det->stream));
+    HIP_TRY(det, hipStreamSynchronize(det->stream));
+    harvest_events(det);
+    const uint32_t total = *det->h_total;
+    if (total > det->h_out_records) return fail(det, AGX_ERR_HIP, "compact output counter out of range");
+    if (total) {
+        HIP_TRY(det, hipMemcpyAsync(det->h_out, a.out, (size_t)total * 5 * sizeof(float), hipMemcpyDeviceToHost,
+                                    det->stream));
+        HIP_TRY(det, hipStreamSynchronize(det->stream));
+    }
+    int first_bad = AGX_OK;
+    for (size_t f = 0; f < F; ++f) {
+        const FrameCounters &c = det->h_ctr[f];
+        const int st = frame_status_of(c, cap_per_frame);
+        counts[f] = c.n_out;
+        if (frame_status) frame_status[f] = st;
+        if (st != AGX_OK) {
+            if (first_bad == AGX_OK) {
+                first_bad = st;
+                char buf[160];
+                std::snprintf(buf, sizeof buf,
+                              "frame %zu: capacity exceeded (flags=0x%x candidates=%u clusters=%u saddles=%u)", f,
+                              c.flags, c.n_cand, c.n_roots, c.n_out);
+                det->last_error = buf;
+            }
+            continue;
+        }
+        std::memcpy(out + f * (size_t)cap_per_frame, det->h_out + (size_t)c.out_offset * 5,
+                    (size_t)c.n_out * sizeof(agx_saddle));
+    }
+    return first_bad;
+}
+
+int agx_refined_saddle_points(agx_detector *det, const void *pixels, int width, int height, size_t row_stride_bytes,
+                              int format, agx_saddle *out, uint32_t cap, uint32_t *n_out)
+{
+    if (!det || !pixels || !n_out) return fail(det, AGX_ERR_ARG, "null argument");
+    if (!valid_format(format)) return fail(det, AGX_ERR_FORMAT, "format must be AGX_L8, AGX_L16 or AGX_RGB8");
+    if (width < 2 || height < 2) return fail(det, AGX_ERR_ARG, "width and height must be >= 2");
+    const size_t row_bytes = (size_t)width * bytes_per_px(format);
+    if (row_stride_bytes < row_bytes) return fail(det, AGX_ERR_ARG, "row stride smaller than a row");
+    HIP_TRY(det, hipSetDevice(det->device));
+    const size_t pitch = (row_bytes + 3) & ~(size_t)3;
+    const size_t need = pitch * (size_t)height;
+    if (need > det->stage_bytes) {
+        HIP_TRY(det, hipStreamSynchronize(det->stream));
+        if (det->d_stage) (void)hipFree(det->d_stage);
+        det->d_stage = nullptr;
+        det->stage_bytes = 0;
+        HIP_TRY(det, hipMalloc((void **)&det->d_stage, need));
+        det->stage_bytes = need;
+    }
+    HIP_TRY(det, hipMemcpy2DAsync(det->d_stage, pitch, pixels, row_stride_bytes, row_bytes, (size_t)height,
+                                  hipMemcpyHostToDevice, det->stream));
+    int rc = agx_saddles_batch_enqueue(det, det->d_stage, 1, width, height, pitch, need, format);
+    if (rc) return rc;
+    // fetch into a private buffer first so that a too-small `cap` reports the needed size
+    uint32_t count = 0;
+    int st = AGX_OK;
+    std::vector<agx_saddle> tmp(det->args.cap_out);
+    rc = agx_saddles_batch_fetch(det, tmp.data(), det->args.cap_out, &count, &st);
+    *n_out = count;
+    if (rc) return rc;
+    if (count > cap) return fail(det, AGX_ERR_CAPACITY, "output capacity too small");
+    if (count) std::memcpy(out, tmp.data(), (size_t)count * sizeof(agx_saddle));
+    return AGX_OK;
+}
+
+int agx_luma8(const void *pixels, int width, int height, size_t row_stride_bytes, int format, uint8_t *out)
+{
+    if (!pixels || !out || width <= 0 || height <= 0) return AGX_ERR_ARG;
+    return luma8(pixels, width, height, row_stride_bytes, format, out);
+}
+
+int agx_detect_from_saddles(const agx_detector *det, const agx_saddle *saddles, uint32_t n_saddles,
+                            const uint8_t *luma, int width, int height, size_t row_stride_bytes, agx_tag *out,
+                            uint32_t cap, uint32_t *n_out)
+{
+    if (!det || !luma || !n_out || (!saddles && n_saddles) || (!out && cap)) return AGX_ERR_ARG;
+    std::vector<agx_saddle> refined(saddles, saddles + n_saddles);
+    std::vector<agx_tag> tags;
+    detect_tail(det->fam, det->params.max_num_of_boards, std::move(refined), luma, width, height, row_stride_bytes,
+                tags);
+    *n_out = (uint32_t)tags.size();
+    if (tags.size() > cap) return AGX_ERR_CAPACITY;
+    if (!tags.empty()) std::memcpy(out, tags.data(), tags.size() * sizeof(agx_tag));
+    return AGX_OK;
+}
+
+int agx_detect(agx_detector *det, const void *pixels, int width, int height, size_t row_stride_bytes, int format,
+               agx_tag *out, uint32_t cap, uint32_t *n_out)
+{
+    if (!det || !pixels || !n_out) return fail(det, AGX_ERR_ARG, "null argument");
+    if (!valid_format(format)) return fail(det, AGX_ERR_FORMAT, "format must be AGX_L8, AGX_L16 or AGX_RGB8");
+    if (width < 2 || height < 2) return fail(det, AGX_ERR_ARG, "width and height must be >= 2");
+    // detector.rs:507-508: u8 luma for the decode, saddle chain on the device
+    std::vector<uint8_t> grey((size_t)width * height);
+    int rc = luma8(pixels, width, height, row_stride_bytes, format, grey.data());
+    if (rc) return rc;
+    std::vector<agx_saddle> saddles(16384);
+    uint32_t ns = 0;
+    rc = agx_refined_saddle_points(det, pixels, width, height, row_stride_bytes, format, saddles.data(),
+                                   (uint32_t)saddles.size(), &ns);
+    if (rc) return rc;
+    return agx_detect_from_saddles(det, saddles.data(), ns, grey.data(), width, height, (size_t)width, out, cap,
+                                   n_out);
+}
+
+int agx_profile_enable(agx_detector *det, int on)
+{
+    if (!det) return AGX_ERR_ARG;
+    det->profiling = on != 0;
+    return AGX_OK;
+}
+
+int agx_profile_reset(agx_detector *det)
+{
+    if (!det) return AGX_ERR_ARG;
+    HIP_TRY(det, hipSetDevice(det->device));
+    HIP_TRY(det, hipStreamSynchronize(det->stream));
+    harvest_events(det);
+    for (int k = 0; k < K_COUNT; ++k) {
+        det->prof_ms[k] = 0.0;
+        det->prof_launches[k] = 0;
+    }
+    return AGX_OK;
+}
+
+int agx_profile_read(agx_detector *det, const char **names, double *ms_total, uint64_t *launches)
+{
+    if (!det) return AGX_ERR_ARG;
+    HIP_TRY(det, hipSetDevice(det->device));
+    HIP_TRY(det, hipStreamSynchronize(det->stream));
+    harvest_events(det);
+    for (int k = 0; k < K_COUNT; ++k) {
+        if (names) names[k] = kKernelNames[k];
+        if (ms_total) ms_total[k] = det->prof_ms[k];
+        if (launches) launches[k] = det->prof_launches[k];
+    }
+    return AGX_OK;
+}
+
+int agx_detector_constants(const agx_detector *det, float *blur_w7, float *cone25, float *pmat150)
+{
+    // det == NULL: compute them afresh (they do not depend on the family or the device)
+    float w[7];
+    RefineConsts rc;
+    if (det) {
+        std::memcpy(w, det->blur_w, sizeof w);
+        rc = det->rc;
+    } else {
+        make_blur_weights(1.5f, w);
+        make_refine_consts(rc);
+    }
+    if (blur_w7) std::memcpy(blur_w7, w, sizeof w);
+    if (cone25) std::memcpy(cone25, rc.cone, sizeof rc.cone);
+    if (pmat150) std::memcpy(pmat150, rc.pmat, sizeof rc.pmat);
+    return AGX_OK;
+}
+
+int agx_debug_fetch(agx_detector *det, int frame, int what, void *host_out, size_t cap_bytes, size_t *n_items)
+{
+    if (!det || !host_out || !n_items) return fail(det, AGX_ERR_ARG, "null argument");
+    if (!det->enqueued) return fail(det, AGX_ERR_STATE, "no batch enqueued");
+    const ChainArgs &a = det->args;
+    if (frame < 0 || frame >= a.n_frames) return fail(det, AGX_ERR_ARG, "frame out of range");
+    HIP_TRY(det, hipSetDevice(det->device));
+    HIP_TRY(det, hipStreamSynchronize(det->stream));
+    const size_t plane = (size_t)a.plane;
+    FrameCounters c;
+    HIP_TRY(det, hipMemcpy(&c, a.ctr + frame, sizeof c, hipMemcpyDeviceToHost));
+    switch (what) {
+    case AGX_DBG_BLUR:
+    case AGX_DBG_RESP: {
+        *n_items = plane;
+        if (cap_bytes < plane * sizeof(float)) return AGX_ERR_CAPACITY;
+        const float *src = (what == AGX_DBG_BLUR ? a.blur : a.resp) + (size_t)frame * plane;
+        HIP_TRY(det, hipMemcpy(host_out, src, plane * sizeof(float), hipMemcpyDeviceToHost));
+        return AGX_OK;
+    }
+    case AGX_DBG_MIN: {
+        *n_items = 1;
+        if (cap_bytes < sizeof(float)) return AGX_ERR_CAPACITY;
+        uint32_t key = ~c.min_key_inv;
+        uint32_t u = (key & 0x80000000u) ? (key & 0x7fffffffu) : ~key;
+        std::memcpy(host_out, &u, sizeof u);
+        return AGX_OK;
+    }
+    case AGX_DBG_CENTERS: {
+        const uint32_t n = std::min(c.n_roots, a.cap_roots);
+        *n_items = n;
+        if (cap_bytes < (size_t)n * sizeof(agx_cluster_info)) return AGX_ERR_CAPACITY;
+        const uint32_t nc = std::min(c.n_cand, a.cap_cand);
+        std::vector<uint32_t> roots(n), sumx(nc), sumy(nc), cnt(nc), minidx(nc);
+        const size_t cb = (size_t)frame * a.cap_cand;
+        HIP_TRY(det, hipMemcpy(roots.data(), a.roots + (size_t)frame * a.cap_roots, n * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(det, hipMemcpy(sumx.data(), a.sumx + cb, (size_t)nc * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(det, hipMemcpy(sumy.data(), a.sumy + cb, (size_t)nc * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(det, hipMemcpy(cnt.data(), a.cnt + cb, (size_t)nc * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(det, hipMemcpy(minidx.data(), a.minidx + cb, (size_t)nc * 4, hipMemcpyDeviceToHost));
+        std::vector<agx_cluster_info> info(n);
+        for (uint32_t i = 0; i < n; ++i) {
+            const uint32_t s = roots[i];
+            info[i].first_index = minidx[s];
+            info[i].size = cnt[s];
+            std::memcpy(&info[i].cx, &sumx[s], 4);  // K4 leaves the f32 centroid here
+            std::memcpy(&info[i].cy, &sumy[s], 4);
+        }
+        std::sort(info.begin(), info.end(),
+                  [](const agx_cluster_info &p, const agx_cluster_info &q) { return p.first_index < q.first_index; });
+        std::memcpy(host_out, info.data(), (size_t)n * sizeof(agx_cluster_info));
+        return AGX_OK;
+    }
+    case AGX_DBG_REFINED: {
+        const uint32_t n = c.n_refined;
+        *n_items = n;
+        if (cap_bytes < (size_t)n * sizeof(agx_saddle)) return AGX_ERR_CAPACITY;
+        std::vector<RefinedRec> rec(n);
+        HIP_TRY(det, hipMemcpy(rec.data(), a.refined + (size_t)frame * a.cap_roots, (size_t)n * sizeof(RefinedRec),
+                               hipMemcpyDeviceToHost));
+        std::sort(rec.begin(), rec.end(), [](const RefinedRec &p, const RefinedRec &q) { return p.key < q.key; });
+        agx_saddle *o = (agx_saddle *)host_out;
+        for (uint32_t i = 0; i < n; ++i) o[i] = {rec[i].x, rec[i].y, rec[i].k, rec[i].theta, rec[i].phi};
+        return AGX_OK;
+    }
+    default: return fail(det, AGX_ERR_ARG, "unknown debug item");
+    }
+}
+
+}  // extern "C"

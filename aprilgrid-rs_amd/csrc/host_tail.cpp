@@ -1,0 +1,506 @@
+// host_tail.cpp -- board search and tag decode on the host (see host_tail.hpp).
+//
+// The reference keeps this part on the CPU as well: it is pointer-chasing over a few hundred
+// saddles per frame.  Decisions here depend on f32 comparisons, so the f32 expressions keep
+// the reference's operand order and this file is compiled with -ffp-contract=off.
+#include "host_tail.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <unordered_map>
+
+namespace agx {
+
+#include "tag_families_data.inc"
+
+bool family_info(int family, FamilyInfo &out)
+{
+    switch (family) {  // src/detector.rs:369-405
+    case AGX_T16H5: out = {4, 2, 1, kT16H5, 30}; return true;
+    case AGX_T25H7: out = {5, 2, 2, kT25H7, 242}; return true;
+    case AGX_T25H9: out = {5, 2, 2, kT25H9, 35}; return true;
+    case AGX_T36H11: out = {6, 2, 3, kT36H11, 587}; return true;
+    case AGX_T36H11B1: out = {6, 1, 3, kT36H11, 587}; return true;
+    default: return false;
+    }
+}
+
+static const float kPi = 3.14159274101257324219f;
+
+float theta_distance_degree(float t0, float t1)
+{
+    float d = t0 - t1 + 90.0f;
+    if (d < 0.0f) d += 180.0f;
+    else if (d > 180.0f) d -= 180.0f;
+    return d > 90.0f ? d - 90.0f : 90.0f - d;
+}
+
+static inline float cross2(float ax, float ay, float bx, float by) { return ax * by - ay * bx; }
+static inline float dot2(float ax, float ay, float bx, float by) { return ax * bx + ay * by; }
+
+float angle_degree(float v0x, float v0y, float v1x, float v1y)
+{
+    return std::atan2(v1y * v0x - v1x * v0y, v0x * v1x + v0y * v1y) * 180.0f / kPi;
+}
+
+bool is_valid_quad(const agx_saddle &s0, const agx_saddle &d0, const agx_saddle &s1, const agx_saddle &d1)
+{
+    if (theta_distance_degree(d0.theta, d1.theta) > 5.0f) return false;
+    const float v01x = d0.x - s0.x, v01y = d0.y - s0.y;
+    const float v03x = d1.x - s0.x, v03y = d1.y - s0.y;
+    const float v02x = s1.x - s0.x, v02y = s1.y - s0.y;
+    // the diagonal must be roughly perpendicular to s0's saddle axis ("filter white block")
+    const float th = s0.theta / 180.0f * kPi;
+    const float ang = std::fabs(angle_degree(v02x, v02y, std::cos(th), std::sin(th)));
+    if (!(ang >= 60.0f && ang <= 120.0f)) return false;
+    if (cross2(v01x, v01y, v02x, v02y) * cross2(v02x, v02y, v03x, v03y) < 0.0f) return false;
+    const float v12x = s1.x - d0.x, v12y = s1.y - d0.y;
+    const float v23x = d1.x - s1.x, v23y = d1.y - s1.y;
+    if (cross2(v01x, v01y, v12x, v12y) * cross2(v12x, v12y, v23x, v23y) < 0.0f) return false;
+    const float v30x = s0.x - d1.x, v30y = s0.y - d1.y;
+    const float a0 = angle_degree(v01x, v01y, v12x, v12y);
+    const float a1 = angle_degree(v12x, v12y, v23x, v23y);
+    const float a2 = angle_degree(v23x, v23y, v30x, v30y);
+    const float a3 = angle_degree(v30x, v30y, v01x, v01y);
+    if (std::fabs(a0 - a2) > 10.0f || std::fabs(a1 - a3) > 10.0f) return false;
+    if (dot2(v01x, v01y, v02x, v02y) < 0.0f || dot2(v03x, v03y, v02x, v02y) < 0.0f) return false;
+    return true;
+}
+
+namespace {
+
+// Nearest-neighbour queries over the saddle set (the reference uses kdtree 0.8.0's
+// nearest(): ascending squared distance; ties resolved here by ascending index).
+class SaddleIndex {
+public:
+    struct Hit {
+        float d2;
+        int idx;
+        bool operator<(const Hit &o) const { return d2 < o.d2 || (d2 == o.d2 && idx < o.idx); }
+    };
+    explicit SaddleIndex(const std::vector<agx_saddle> &pts) : pts_(pts), scratch_(pts.size()) {}
+
+    // k nearest, ascending
+    int nearest(float qx, float qy, int k, Hit *out)
+    {
+        const int n = (int)pts_.size();
+        for (int i = 0; i < n; ++i) {
+            const float dx = qx - pts_[i].x, dy = qy - pts_[i].y;
+            scratch_[i] = {(0.0f + dx * dx) + dy * dy, i};
+        }
+        const int m = std::min(k, n);
+        std::partial_sort(scratch_.begin(), scratch_.begin() + m, scratch_.end());
+        std::copy(scratch_.begin(), scratch_.begin() + m, out);
+        return m;
+    }
+
+private:
+    const std::vector<agx_saddle> &pts_;
+    std::vector<Hit> scratch_;
+};
+
+struct CellKey {
+    int x, y;
+    bool operator==(const CellKey &o) const { return x == o.x && y == o.y; }
+};
+struct CellKeyHash {
+    size_t operator()(const CellKey &k) const
+    {
+        return (size_t)((uint32_t)k.x * 73856093u) ^ (size_t)((uint32_t)k.y * 19349663u);
+    }
+};
+
+// board::Board, src/board.rs:18-235.  Cells are kept in insertion order (the reference's
+// HashMap iteration order is unspecified).
+class Board {
+public:
+    Board(const std::vector<agx_saddle> &refined, SaddleIndex &index, const Quad &seed, float spacing_ratio)
+        : refined_(refined), index_(index), active_(refined.size(), 1), spacing_ratio_(spacing_ratio)
+    {
+        for (int i = 1; i < 4; ++i) active_[seed[i]] = 0;  // board.rs:35-37
+        put({0, 0}, true, seed);
+        expand({0, 0});
+    }
+    unsigned score() const { return score_; }
+
+    void collect(std::vector<Quad> &out) const  // all_tag_indexes, board.rs:49-51
+    {
+        for (const Cell &c : cells_)
+            if (c.found) out.push_back(c.quad);
+    }
+
+    void fix_missing()  // try_fix_missing, board.rs:52-112
+    {
+        struct Fix { CellKey a, b; };
+        std::vector<Fix> fixes;
+        for (const Cell &c : cells_) {
+            if (c.found) continue;
+            const CellKey b0{c.key.x + 1, c.key.y}, b1{c.key.x - 1, c.key.y};
+            const CellKey b2{c.key.x, c.key.y + 1}, b3{c.key.x, c.key.y - 1};
+            const Cell *c0 = get(b0), *c1 = get(b1);
+            if (c0 && c1) {
+                if (c0->found && c1->found) fixes.push_back({b0, b1});
+            } else {
+                const Cell *c2 = get(b2), *c3 = get(b3);
+                if (c2 && c3 && c2->found && c3->found) fixes.push_back({b2, b3});
+            }
+        }
+        for (const Fix &f : fixes) {
+            const Quad q0 = get(f.a)->quad, q1 = get(f.b)->quad;
+            Quad mid;
+            for (int i = 0; i < 4; ++i) {
+                const float x = (refined_[q0[i]].x + refined_[q1[i]].x) / 2.0f;
+                const float y = (refined_[q0[i]].y + refined_[q1[i]].y) / 2.0f;
+                SaddleIndex::Hit h;
+                index_.nearest(x, y, 1, &h);
+                mid[i] = h.idx;
+            }
+            if (is_valid_quad(refined_[mid[0]], refined_[mid[1]], refined_[mid[2]], refined_[mid[3]]))
+                put({(f.a.x + f.b.x) / 2, (f.a.y + f.b.y) / 2}, true, mid);
+        }
+    }
+
+private:
+    struct Cell {
+        CellKey key;
+        bool found;
+        Quad quad;
+    };
+
+    const Cell *get(const CellKey &k) const
+    {
+        auto it = lookup_.find(k);
+        return it == lookup_.end() ? nullptr : &cells_[it->second];
+    }
+    void put(const CellKey &k, bool found, const Quad &q)
+    {
+        auto it = lookup_.find(k);
+        if (it == lookup_.end()) {
+            lookup_.emplace(k, cells_.size());
+            cells_.push_back({k, found, q});
+        } else {
+            cells_[it->second].found = found;
+            cells_[it->second].quad = q;
+        }
+    }
+
+    // find_closest_potential_saddle_idxs, board.rs:177-233 (one side)
+    int candidates_near(float qx, float qy, float radius_sq, float theta, int out[3])
+    {
+        SaddleIndex::Hit hits[3];
+        const int m = index_.nearest(qx, qy, 3, hits);
+        int n = 0;
+        for (int i = 0; i < m; ++i) {
+            if (hits[i].d2 <= radius_sq && active_[hits[i].idx] &&
+                theta_distance_degree(theta, refined_[hits[i].idx].theta) < 5.0f) {
+                out[n++] = hits[i].idx;
+                if (n == 3) break;
+            }
+        }
+        return n;
+    }
+    void closest_pair(const agx_saddle &s0, const agx_saddle &s1, int o0[3], int &n0, int o1[3], int &n1)
+    {
+        const float ratio0 = 1.0f + spacing_ratio_;
+        const float ex = s0.x - s1.x, ey = s0.y - s1.y;
+        const float radius_sq = 0.5f * (ex * ex + ey * ey);
+        const float v10x = s1.x - s0.x, v10y = s1.y - s0.y;
+        n0 = candidates_near(s0.x + v10x * ratio0, s0.y + v10y * ratio0, radius_sq, s0.theta, o0);
+        n1 = candidates_near(s1.x + v10x * ratio0, s1.y + v10y * ratio0, radius_sq, s1.theta, o1);
+    }
+
+    bool expand_one(const Quad &q, Quad &out)  // try_expand_one, board.rs:153-176
+    {
+        int c0[3], c1[3], c2[3], c3[3], n0, n1, n2, n3;
+        closest_pair(refined_[q[0]], refined_[q[1]], c0, n0, c1, n1);
+        closest_pair(refined_[q[3]], refined_[q[2]], c3, n3, c2, n2);
+        for (int i0 = 0; i0 < n0; ++i0)
+            for (int i1 = 0; i1 < n1; ++i1)
+                for (int i2 = 0; i2 < n2; ++i2)
+                    for (int i3 = 0; i3 < n3; ++i3)
+                        if (is_valid_quad(refined_[c0[i0]], refined_[c1[i1]], refined_[c2[i2]], refined_[c3[i3]])) {
+                            out = {c0[i0], c1[i1], c2[i2], c3[i3]};
+                            return true;
+                        }
+        return false;
+    }
+
+    void expand(const CellKey &at)  // try_expand, board.rs:114-152
+    {
+        const Cell *start = get(at);
+        if (!start || !start->found) return;
+        const Quad quad = start->quad;
+        static const int kDx[4] = {1, 0, -1, 0}, kDy[4] = {0, -1, 0, 1};
+        for (int i = 0; i < 4; ++i) {
+            Quad qs;
+            for (int j = 0; j < 4; ++j) qs[j] = quad[(j + i) & 3];
+            const CellKey next{at.x + kDx[i], at.y + kDy[i]};
+            const Cell *existing = get(next);
+            if (existing && existing->found) continue;
+            Quad nq;
+            if (expand_one(qs, nq)) {
+                Quad v;
+                for (int j = 0; j < 4; ++j) v[(j + i) & 3] = nq[j];
+                for (int j = 0; j < 4; ++j) active_[v[j]] = 0;
+                score_ += 1;
+                put(next, true, v);
+                expand(next);
+            } else {
+                put(next, false, Quad{0, 0, 0, 0});
+            }
+        }
+    }
+
+    const std::vector<agx_saddle> &refined_;
+    SaddleIndex &index_;
+    std::vector<uint8_t> active_;
+    float spacing_ratio_;
+    unsigned score_ = 1;
+    std::vector<Cell> cells_;
+    std::unordered_map<CellKey, size_t, CellKeyHash> lookup_;
+};
+
+// init_quads, src/detector.rs:543-586
+void init_quads(const std::vector<agx_saddle> &refined, SaddleIndex &index, int s0_idx, std::vector<Quad> &out)
+{
+    out.clear();
+    const agx_saddle &s0 = refined[s0_idx];
+    SaddleIndex::Hit near[50];
+    const int m = index.nearest(s0.x, s0.y, 50, near);
+    std::vector<int> same, diff;
+    for (int i = 1; i < m; ++i) {
+        const int idx = near[i].idx;
+        const float td = theta_distance_degree(s0.theta, refined[idx].theta);
+        if (td < 5.0f) same.push_back(idx);
+        else if (td > 80.0f) diff.push_back(idx);
+    }
+    for (int s1_idx : same) {
+        const agx_saddle &s1 = refined[s1_idx];
+        for (size_t a = 0; a < diff.size(); ++a)
+            for (size_t b = a + 1; b < diff.size(); ++b) {
+                const agx_saddle &d0 = refined[diff[a]], &d1 = refined[diff[b]];
+                if (!is_valid_quad(s0, d0, s1, d1)) continue;
+                const float c0 = cross2(d0.x - s0.x, d0.y - s0.y, s1.x - s0.x, s1.y - s0.y);
+                if (c0 > 0.0f) out.push_back({s0_idx, diff[a], s1_idx, diff[b]});
+                else out.push_back({s0_idx, diff[b], s1_idx, diff[a]});
+            }
+    }
+}
+
+inline uint32_t f32_as_u32(float v)  // Rust `as u32`: saturating, NaN -> 0
+{
+    if (!(v > 0.0f)) return 0u;
+    if (v >= 4294967296.0f) return 0xffffffffu;
+    return (uint32_t)v;
+}
+
+}  // namespace
+
+bool try_find_best_board(const std::vector<agx_saddle> &refined, std::vector<Quad> &quads)
+{
+    quads.clear();
+    if (refined.empty()) return false;
+    SaddleIndex index(refined);
+    // seeds: the most populated round(theta) bin (ties -> smallest angle; the reference's
+    // HashMap order makes its own tie-break arbitrary), popped from the back
+    std::unordered_map<int, int> hist;
+    for (const agx_saddle &s : refined) hist[(int)std::round(s.theta)]++;
+    int best_angle = 0, best_len = -1;
+    for (const auto &kv : hist)
+        if (kv.second > best_len || (kv.second == best_len && kv.first < best_angle)) {
+            best_len = kv.second;
+            best_angle = kv.first;
+        }
+    std::vector<int> seeds;
+    for (size_t i = 0; i < refined.size(); ++i)
+        if ((int)std::round(refined[i].theta) == best_angle) seeds.push_back((int)i);
+
+    unsigned best_score = 0;
+    std::unique_ptr<Board> best;
+    std::vector<Quad> cand;
+    int count = 0;
+    while (!seeds.empty() && count < 30) {
+        const int s0 = seeds.back();
+        seeds.pop_back();
+        init_quads(refined, index, s0, cand);
+        for (const Quad &q : cand) {
+            std::unique_ptr<Board> b(new Board(refined, index, q, 0.3f));
+            if (b->score() > best_score) {
+                best_score = b->score();
+                best = std::move(b);
+            }
+        }
+        if (best_score >= 36) break;
+        ++count;
+    }
+    if (!best) return false;
+    best->fix_missing();
+    best->collect(quads);
+    return true;
+}
+
+void tag_affine(const float quad_xy[8], int side_bits, float margin, float h[6])
+{
+    // Least-squares affine map from the tag's corner grid (-m,-m), (-m,S), (S,S), (S,-m) to
+    // the image quad.  The source points are the corners of an axis-aligned square, so the
+    // normal equations diagonalise about its centre.  Evaluated in binary64, rounded once.
+    const double S = (double)((float)side_bits - 1.0f + margin), m = (double)margin;
+    const double c = 0.5 * (S - m), a = 0.5 * (S + m);
+    const double su[4] = {-a, -a, a, a}, sv[4] = {-a, a, a, -a};
+    for (int axis = 0; axis < 2; ++axis) {
+        double gu = 0, gv = 0, mean = 0;
+        for (int p = 0; p < 4; ++p) {
+            const double t = quad_xy[2 * p + axis];
+            gu += su[p] * t;
+            gv += sv[p] * t;
+            mean += t;
+        }
+        const double hu = gu / (4.0 * a * a), hv = gv / (4.0 * a * a);
+        h[3 * axis + 0] = (float)hu;
+        h[3 * axis + 1] = (float)hv;
+        h[3 * axis + 2] = (float)(mean / 4.0 - hu * c - hv * c);
+    }
+}
+
+uint64_t rotate_bits(uint64_t bits, int edge_bits)
+{
+    uint64_t out = 0;
+    int count = 0;
+    for (int r = edge_bits - 1; r >= 0; --r)
+        for (int c = 0; c < edge_bits; ++c, ++count) out |= ((bits >> (r + c * edge_bits)) & 1ull) << count;
+    return out;
+}
+
+bool best_tag(uint64_t bits, int thres, const uint64_t *codes, int n_codes, int edge_bits, int &idx, int &rot)
+{
+    for (int rotated = 0; rotated < 4; ++rotated) {
+        int best = 0;
+        unsigned best_score = (unsigned)__builtin_popcountll(codes[0] ^ bits);
+        for (int i = 1; i < n_codes; ++i) {
+            const unsigned s = (unsigned)__builtin_popcountll(codes[i] ^ bits);
+            if (s < best_score) {
+                best_score = s;
+                best = i;
+            }
+        }
+        if (best_score < (unsigned)thres) {
+            idx = best;
+            rot = rotated;
+            return true;
+        }
+        if (rotated == 3) break;
+        bits = rotate_bits(bits, edge_bits);
+    }
+    return false;
+}
+
+namespace {
+
+// try_decode_quad, src/detector.rs:448-476 (decode_positions :42-72, bit_code :74-122)
+bool decode_quad(const FamilyInfo &fam, const uint8_t *luma8, uint32_t w, uint32_t h, size_t stride,
+                 const float quad_xy[8], int &tag_id, float corners[8])
+{
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t x = f32_as_u32(std::round(quad_xy[2 * i])), y = f32_as_u32(std::round(quad_xy[2 * i + 1]));
+        if (x >= w || y >= h) return false;
+    }
+    float aff[6];
+    tag_affine(quad_xy, fam.border * 2 + fam.edge, 0.5f, aff);
+    uint8_t samples[64];
+    int n = 0;
+    for (int gx = fam.border; gx < fam.border + fam.edge; ++gx)
+        for (int gy = fam.border; gy < fam.border + fam.edge; ++gy) {
+            const float fx = (float)gx, fy = (float)gy;
+            const float px = aff[0] * fx + aff[1] * fy + aff[2] * 1.0f;
+            const float py = aff[3] * fx + aff[4] * fy + aff[5] * 1.0f;
+            const uint32_t ix = f32_as_u32(std::round(px)), iy = f32_as_u32(std::round(py));
+            if (ix >= w || iy >= h) return false;
+            samples[n++] = luma8[(size_t)iy * stride + ix];
+        }
+    int lo = 255, hi = 0;
+    for (int i = 0; i < n; ++i) {
+        lo = std::min<int>(lo, samples[i]);
+        hi = std::max<int>(hi, samples[i]);
+    }
+    if (hi - lo < 50) return false;
+    const int mid = (int)(uint8_t)f32_as_u32(std::round(((float)lo + (float)hi) / 2.0f));
+    uint64_t bits = 0;
+    uint32_t invalid = 0;
+    for (int i = 0; i < n; ++i) {  // first sample is the most significant bit
+        const int b = samples[n - 1 - i];
+        if (std::abs(mid - b) < 10) ++invalid;
+        if (b > mid) bits |= 1ull << i;
+    }
+    if (invalid > 3) return false;
+    int idx, rot;
+    if (!best_tag(bits, fam.hamming, fam.codes, fam.n_codes, fam.edge, idx, rot)) return false;
+    // rotate_left(rot) then reverse, :468-469
+    for (int i = 0; i < 4; ++i) {
+        const int src = ((3 - i) + rot) & 3;
+        corners[2 * i] = quad_xy[2 * src];
+        corners[2 * i + 1] = quad_xy[2 * src + 1];
+    }
+    tag_id = idx;
+    return true;
+}
+
+}  // namespace
+
+void detect_tail(const FamilyInfo &fam, int max_num_of_boards, std::vector<agx_saddle> refined,
+                 const uint8_t *luma8, int width, int height, size_t row_stride, std::vector<agx_tag> &tags)
+{
+    tags.clear();
+    std::vector<Quad> quads;
+    for (int round = 0; round < max_num_of_boards; ++round) {
+        if (!try_find_best_board(refined, quads)) continue;
+        std::vector<uint8_t> used(refined.size(), 0);
+        for (const Quad &q : quads) {
+            float qxy[8];
+            for (int i = 0; i < 4; ++i) {
+                qxy[2 * i] = refined[q[i]].x;
+                qxy[2 * i + 1] = refined[q[i]].y;
+            }
+            int id;
+            float corners[8];
+            if (!decode_quad(fam, luma8, (uint32_t)width, (uint32_t)height, row_stride, qxy, id, corners)) continue;
+            auto it = std::find_if(tags.begin(), tags.end(), [&](const agx_tag &t) { return t.id == (uint32_t)id; });
+            if (it == tags.end()) {
+                tags.push_back(agx_tag{});
+                it = tags.end() - 1;
+                it->id = (uint32_t)id;
+            }
+            std::memcpy(it->xy, corners, sizeof(corners));
+            for (int i = 0; i < 4; ++i) used[q[i]] = 1;
+        }
+        size_t keep = 0;
+        for (size_t i = 0; i < refined.size(); ++i)
+            if (!used[i]) refined[keep++] = refined[i];
+        refined.resize(keep);
+    }
+}
+
+int luma8(const void *pixels, int width, int height, size_t row_stride, int format, uint8_t *out)
+{
+    for (int y = 0; y < height; ++y) {
+        const uint8_t *row = (const uint8_t *)pixels + (size_t)y * row_stride;
+        uint8_t *o = out + (size_t)y * width;
+        switch (format) {
+        case AGX_L8: std::memcpy(o, row, (size_t)width); break;
+        case AGX_L16: {
+            const uint16_t *r16 = (const uint16_t *)row;
+            for (int x = 0; x < width; ++x) o[x] = (uint8_t)(((uint32_t)r16[x] + 128u) / 257u);
+            break;
+        }
+        case AGX_RGB8:
+            for (int x = 0; x < width; ++x)
+                o[x] = (uint8_t)((2126u * row[3 * x] + 7152u * row[3 * x + 1] + 722u * row[3 * x + 2]) / 10000u);
+            break;
+        default: return AGX_ERR_FORMAT;
+        }
+    }
+    return AGX_OK;
+}
+
+}  // namespace agx

@@ -1,0 +1,47 @@
+// host_tail.hpp -- the irregular tail of TagDetector::detect that stays on the host:
+// board search (reference src/detector.rs:543-639, src/board.rs, src/saddle.rs:17-67) and tag
+// decode (src/detector.rs:42-169,448-476, src/image_util.rs:39-70).
+#pragma once
+#include <array>
+#include <cstdint>
+#include <vector>
+
+#include "../../include/aprilgrid_amd.h"
+
+namespace agx {
+
+struct FamilyInfo {
+    int edge, border, hamming;
+    const uint64_t *codes;
+    int n_codes;
+};
+
+// TagDetector::new's table, src/detector.rs:369-405.  Returns false for an unknown family.
+bool family_info(int family, FamilyInfo &out);
+
+using Quad = std::array<int, 4>;
+
+// math_util.rs:15-33
+float theta_distance_degree(float t0, float t1);
+float angle_degree(float v0x, float v0y, float v1x, float v1y);
+// saddle.rs:17-67
+bool is_valid_quad(const agx_saddle &s0, const agx_saddle &d0, const agx_saddle &s1, const agx_saddle &d1);
+
+// detector.rs:588-639: quads (saddle indices) of the best board, or false (None).
+bool try_find_best_board(const std::vector<agx_saddle> &refined, std::vector<Quad> &quads);
+
+// image_util.rs:39-70 (h = 2x3 affine, row-major)
+void tag_affine(const float quad_xy[8], int side_bits, float margin, float h[6]);
+// detector.rs:124-140, 142-169
+uint64_t rotate_bits(uint64_t bits, int edge_bits);
+bool best_tag(uint64_t bits, int thres, const uint64_t *codes, int n_codes, int edge_bits, int &idx, int &rot);
+
+// detector.rs:510-539: board search + decode over a saddle list and the u8 luma plane.
+// Tags in first-insertion order; a repeated id replaces the earlier corners.
+void detect_tail(const FamilyInfo &fam, int max_num_of_boards, std::vector<agx_saddle> refined,
+                 const uint8_t *luma8, int width, int height, size_t row_stride, std::vector<agx_tag> &tags);
+
+// image 0.25.9 to_luma8 (call site detector.rs:507)
+int luma8(const void *pixels, int width, int height, size_t row_stride, int format, uint8_t *out);
+
+}  // namespace agx

@@ -1,0 +1,284 @@
+"""Host-side mirror of aprilgrid::detector (reference src/detector.rs) over the C ABI.
+
+Same names, argument meaning and error behaviour as the reference where Python allows:
+  TagFamily / TagFamily.from_str      src/tag_families.rs:5-28
+  DetectorParams.default_params()     src/detector.rs:25-41
+  Saddle                              src/saddle.rs:3-15
+  TagDetector.new / __init__          src/detector.rs:364-406
+  TagDetector.refined_saddle_points   src/detector.rs:408-446
+  TagDetector.detect                  src/detector.rs:505-540
+  TagDetector.detect_kornia           src/detector.rs:478-503
+An image is a numpy array standing for the DynamicImage variants the reference is fed:
+HxW uint8 (ImageLuma8), HxW uint16 (ImageLuma16), HxWx3 uint8 (ImageRgb8).
+"""
+import ctypes as C
+import enum
+from collections import namedtuple
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import LIB_PATH, build_library
+
+SADDLE_DTYPE = np.dtype([("x", "f4"), ("y", "f4"), ("k", "f4"), ("theta", "f4"), ("phi", "f4")])
+_CLUSTER_DTYPE = np.dtype([("first_index", "u4"), ("size", "u4"), ("cx", "f4"), ("cy", "f4")])
+
+Saddle = namedtuple("Saddle", ["p", "k", "theta", "phi"])  # p = (x, y)
+
+
+def library_path():
+    return LIB_PATH
+
+
+class AgxError(RuntimeError):
+    def __init__(self, status, detail=""):
+        self.status = status
+        msg = _ffi.lib().agx_status_string(status).decode()
+        super().__init__("%s (%d)%s" % (msg, status, (": " + detail) if detail else ""))
+
+
+class TagFamily(enum.IntEnum):
+    T16H5 = 0
+    T25H7 = 1
+    T25H9 = 2
+    T36H11 = 3
+    T36H11B1 = 4
+
+    @staticmethod
+    def from_str(s):
+        out = C.c_int(-1)
+        st = _ffi.lib().agx_family_from_str(s.encode(), C.byref(out))
+        if st != _ffi.AGX_OK:
+            raise ValueError("unknown tag family %r" % (s,))  # reference: Err(std::fmt::Error)
+        return TagFamily(out.value)
+
+
+@dataclass
+class DetectorParams:
+    tag_spacing_ratio: float = 0.3
+    min_saddle_angle: float = 30.0
+    max_saddle_angle: float = 60.0
+    max_num_of_boards: int = 2
+
+    @staticmethod
+    def default_params():
+        p = _ffi.Params()
+        _ffi.lib().agx_default_params(C.byref(p))
+        return DetectorParams(p.tag_spacing_ratio, p.min_saddle_angle, p.max_saddle_angle, p.max_num_of_boards)
+
+    def _c(self):
+        return _ffi.Params(self.tag_spacing_ratio, self.min_saddle_angle, self.max_saddle_angle,
+                           self.max_num_of_boards)
+
+
+def _image_args(img):
+    a = np.ascontiguousarray(img)
+    if a.ndim == 3 and a.shape[2] == 1:
+        a = a[:, :, 0]
+        a = np.ascontiguousarray(a)
+    if a.ndim == 2 and a.dtype == np.uint8:
+        return a, _ffi.AGX_L8, a.shape[1]
+    if a.ndim == 2 and a.dtype == np.uint16:
+        return a, _ffi.AGX_L16, a.shape[1] * 2
+    if a.ndim == 3 and a.shape[2] == 3 and a.dtype == np.uint8:
+        return a, _ffi.AGX_RGB8, a.shape[1] * 3
+    raise AgxError(_ffi.AGX_ERR_FORMAT, "image must be HxW uint8/uint16 or HxWx3 uint8, got %s %s"
+                   % (a.shape, a.dtype))
+
+
+class TagDetector:
+    """aprilgrid::detector::TagDetector on one MI355X (one handle = one device + stream;
+    use one instance per thread)."""
+
+    def __init__(self, tag_family, optional_detector_params=None, device=0):
+        self._lib = _ffi.lib()
+        self._h = C.c_void_p()
+        fam = TagFamily.from_str(tag_family) if isinstance(tag_family, str) else TagFamily(tag_family)
+        prm = optional_detector_params._c() if optional_detector_params is not None else None
+        st = self._lib.agx_detector_create(int(fam), C.byref(prm) if prm is not None else None, int(device),
+                                           C.byref(self._h))
+        if st != _ffi.AGX_OK:
+            self._h = C.c_void_p()
+            raise AgxError(st, "agx_detector_create(device=%d): %s" % (device, self._lib.agx_last_error(None).decode()))
+        self.tag_family = fam
+        self.detector_params = optional_detector_params or DetectorParams.default_params()
+        self.device = device
+        self._batch = None
+
+    new = classmethod(lambda cls, tag_family, optional_detector_params=None, device=0:
+                      cls(tag_family, optional_detector_params, device))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.agx_detector_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st):
+        if st != _ffi.AGX_OK:
+            raise AgxError(st, self._lib.agx_last_error(self._h).decode())
+
+    # ---- reference API -------------------------------------------------------------------
+    def refined_saddle_points(self, img, as_array=False, cap=16384):
+        """-> Vec<Saddle> (list of Saddle) or, with as_array=True, a SADDLE_DTYPE array."""
+        a, fmt, stride = _image_args(img)
+        h, w = a.shape[:2]
+        out = np.zeros(cap, SADDLE_DTYPE)
+        n = C.c_uint32(0)
+        self._check(self._lib.agx_refined_saddle_points(self._h, a.ctypes.data, w, h, stride, fmt, out.ctypes.data,
+                                                        cap, C.byref(n)))
+        res = out[: n.value].copy()
+        if as_array:
+            return res
+        return [Saddle((float(s["x"]), float(s["y"])), float(s["k"]), float(s["theta"]), float(s["phi"]))
+                for s in res]
+
+    def detect(self, img, cap=4096):
+        """-> HashMap<u32, [(f32,f32);4]> as {tag_id: 4x2 float32 array}."""
+        a, fmt, stride = _image_args(img)
+        h, w = a.shape[:2]
+        out = (_ffi.TagC * cap)()
+        n = C.c_uint32(0)
+        self._check(self._lib.agx_detect(self._h, a.ctypes.data, w, h, stride, fmt, out, cap, C.byref(n)))
+        return {int(out[i].id): np.array(out[i].xy, np.float32).reshape(4, 2) for i in range(n.value)}
+
+    def detect_kornia(self, img):
+        """kornia::image::Image<u8, N>: an HxWxN uint8 array, N in {1, 3} (else the reference
+        panics 'Only support u8c1 and u8c3')."""
+        a = np.asarray(img)
+        if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] not in (1, 3):
+            raise AgxError(_ffi.AGX_ERR_FORMAT, "Only support u8c1 and u8c3")
+        return self.detect(a)
+
+    def detect_from_saddles(self, saddles, luma8, cap=4096):
+        """Host tail only (board search + decode) from a SADDLE_DTYPE array and the u8 luma."""
+        s = np.ascontiguousarray(saddles, SADDLE_DTYPE)
+        g = np.ascontiguousarray(luma8, np.uint8)
+        h, w = g.shape
+        out = (_ffi.TagC * cap)()
+        n = C.c_uint32(0)
+        self._check(self._lib.agx_detect_from_saddles(self._h, s.ctypes.data, len(s), g.ctypes.data, w, h, w, out,
+                                                      cap, C.byref(n)))
+        return {int(out[i].id): np.array(out[i].xy, np.float32).reshape(4, 2) for i in range(n.value)}
+
+    @staticmethod
+    def luma8(img):
+        a, fmt, stride = _image_args(img)
+        h, w = a.shape[:2]
+        out = np.empty((h, w), np.uint8)
+        st = _ffi.lib().agx_luma8(a.ctypes.data, w, h, stride, fmt, out.ctypes.data)
+        if st != _ffi.AGX_OK:
+            raise AgxError(st)
+        return out
+
+    # ---- batches resident in device memory ----------------------------------------------
+    def set_limits(self, max_candidates=0, max_clusters=0, max_saddles=0):
+        self._check(self._lib.agx_detector_set_limits(self._h, max_candidates, max_clusters, max_saddles))
+
+    def set_stream(self, hip_stream_ptr):
+        self._check(self._lib.agx_detector_set_stream(self._h, C.c_void_p(hip_stream_ptr or 0)))
+
+    def sync(self):
+        self._check(self._lib.agx_detector_sync(self._h))
+
+    @staticmethod
+    def _tensor_format(frames):
+        import torch
+        if not frames.is_cuda or not frames.is_contiguous():
+            raise AgxError(_ffi.AGX_ERR_ARG, "frames must be a contiguous device tensor")
+        if frames.dim() == 3 and frames.dtype == torch.uint8:
+            return _ffi.AGX_L8, 1
+        if frames.dim() == 3 and frames.dtype in (torch.int16, getattr(torch, "uint16", torch.int16)):
+            return _ffi.AGX_L16, 2
+        if frames.dim() == 4 and frames.shape[3] == 3 and frames.dtype == torch.uint8:
+            return _ffi.AGX_RGB8, 3
+        raise AgxError(_ffi.AGX_ERR_FORMAT, "unsupported frame tensor %s %s" % (tuple(frames.shape), frames.dtype))
+
+    def saddles_batch_enqueue(self, frames):
+        """frames: a torch tensor on this detector's GPU -- [N,H,W] uint8 (L8), [N,H,W] int16/uint16
+        (L16) or [N,H,W,3] uint8 (RGB8), contiguous.  Returns immediately; see saddles_batch_fetch."""
+        fmt, bpp = self._tensor_format(frames)
+        n, h, w = frames.shape[:3]
+        self._check(self._lib.agx_saddles_batch_enqueue(self._h, frames.data_ptr(), n, w, h, w * bpp, w * h * bpp,
+                                                        fmt))
+        self._batch = (n, frames)  # keep the tensor alive until fetched
+
+    def saddles_batch_enqueue_to(self, frames, out_saddles, frame_table):
+        """Device-resident results: out_saddles float32 [capacity, 5] and frame_table int32
+        [n_frames, 4] (count, offset, status, clusters) are torch tensors on the same GPU."""
+        fmt, bpp = self._tensor_format(frames)
+        n, h, w = frames.shape[:3]
+        assert out_saddles.is_cuda and out_saddles.is_contiguous() and out_saddles.shape[1] == 5
+        assert frame_table.is_cuda and frame_table.is_contiguous() and tuple(frame_table.shape) == (n, 4)
+        self._check(self._lib.agx_saddles_batch_enqueue_to(
+            self._h, frames.data_ptr(), n, w, h, w * bpp, w * h * bpp, fmt, out_saddles.data_ptr(),
+            out_saddles.shape[0], frame_table.data_ptr()))
+        self._batch = None
+
+    def saddles_batch_enqueue_ptr(self, dptr, n, w, h, row_stride, frame_stride, fmt):
+        self._check(self._lib.agx_saddles_batch_enqueue(self._h, C.c_void_p(dptr), n, w, h, row_stride, frame_stride,
+                                                        fmt))
+        self._batch = (n, None)
+
+    def saddles_batch_fetch(self, cap_per_frame=8192, raise_on_overflow=True):
+        """-> (list of SADDLE_DTYPE arrays, one per frame; per-frame status array)."""
+        if self._batch is None:
+            raise AgxError(_ffi.AGX_ERR_STATE, "no batch enqueued")
+        n = self._batch[0]
+        out = np.zeros((n, cap_per_frame), SADDLE_DTYPE)
+        counts = np.zeros(n, np.uint32)
+        status = np.zeros(n, np.int32)
+        st = self._lib.agx_saddles_batch_fetch(self._h, out.ctypes.data, cap_per_frame, counts.ctypes.data,
+                                               status.ctypes.data)
+        if st != _ffi.AGX_OK and (raise_on_overflow or st != _ffi.AGX_ERR_CAPACITY):
+            self._check(st)
+        res = [out[i, : counts[i]].copy() if status[i] == 0 else out[i, :0].copy() for i in range(n)]
+        return res, status
+
+    # ---- measurement / parity hooks ------------------------------------------------------
+    def profile_enable(self, on=True):
+        self._check(self._lib.agx_profile_enable(self._h, 1 if on else 0))
+
+    def profile_reset(self):
+        self._check(self._lib.agx_profile_reset(self._h))
+
+    def profile_read(self):
+        names = (C.c_char_p * _ffi.AGX_N_KERNELS)()
+        ms = (C.c_double * _ffi.AGX_N_KERNELS)()
+        cnt = (C.c_uint64 * _ffi.AGX_N_KERNELS)()
+        self._check(self._lib.agx_profile_read(self._h, names, ms, cnt))
+        return {names[i].decode(): (ms[i], int(cnt[i])) for i in range(_ffi.AGX_N_KERNELS)}
+
+    def constants(self):
+        w = np.zeros(7, np.float32)
+        cone = np.zeros(25, np.float32)
+        pmat = np.zeros((25, 6), np.float32)
+        self._check(self._lib.agx_detector_constants(self._h, w.ctypes.data, cone.ctypes.data, pmat.ctypes.data))
+        return w, cone, pmat
+
+    def debug_fetch(self, frame, what, shape=None):
+        """Intermediate product of the last batch: 'blur', 'resp' (HxW f32), 'min' (f32),
+        'centers' (cluster table sorted by first pixel), 'refined' (unfiltered saddles)."""
+        code = {"blur": 0, "resp": 1, "min": 2, "centers": 3, "refined": 4}[what]
+        n = C.c_size_t(0)
+        if code in (0, 1):
+            assert shape is not None
+            buf = np.empty(shape, np.float32)
+        elif code == 2:
+            buf = np.empty(1, np.float32)
+        elif code == 3:
+            buf = np.empty(1 << 20, _CLUSTER_DTYPE)
+        else:
+            buf = np.empty(1 << 20, SADDLE_DTYPE)
+        self._check(self._lib.agx_debug_fetch(self._h, frame, code, buf.ctypes.data, buf.nbytes, C.byref(n)))
+        if code == 2:
+            return buf[0]
+        if code in (3, 4):
+            return buf[: n.value].copy()
+        return buf

@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the AprilGrid saddle chain on MI355X.
+
+A "step" is one pass of the hot path (luma -> blur -> Hessian response -> min/threshold ->
+clustering -> rochade_refine -> k/phi filter, kernels K1..K5) over one batch of synthetic
+1280x800 u8 frames that is already resident in HBM.  N = 1 is BASELINE.json configs[1]
+(256 frames on one MI355X); N > 1 is configs[2]: every rank owns 256 frames (weak scaling,
+2048 frames on 8 GPUs) and the only collective is the per-step RCCL gather of the result
+slabs to rank 0.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  value = pixels of all ranks through the chain per second
+(Mpix/s), inputs resident in HBM.  roofline = K1 (the dominant kernel): algorithmic bytes per
+launch / average launch duration from hipEvents recorded on the launch stream inside the
+timed region.  cpu_baseline = the C oracle (port of the reference CPU path, 1 thread) on a
+bounded sample of the same frames, rank 0, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec)
+HBM_MEASURED_GBPS = 6290.0    # float4-copy ceiling measured on MI355X (same guide)
+IN_BYTES = {"L8": 1, "L16": 2, "RGB8": 3}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=256, help="frames per GPU per step")
+    ap.add_argument("--width", type=int, default=1280)
+    ap.add_argument("--height", type=int, default=800)
+    ap.add_argument("--format", default="L8", choices=["L8", "L16", "RGB8"])
+    ap.add_argument("--unique", type=int, default=32,
+                    help="distinct rendered frames per GPU (tiled to --frames; rendering is not timed)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--noise", action="store_true", help="pure-noise frames (sensitivity row)")
+    ap.add_argument("--pmc-traffic", type=float, default=None,
+                    help="HBM bytes per K1 launch from a separate rocprofv3 --pmc run (profiles/)")
+    return ap.parse_args()
+
+
+def cpu_baseline(frames_host, fmt, budget_s):
+    """Oracle (C port of the reference CPU path, -O3 -march=native, still no FMA contraction),
+    one thread, chain only (refined_saddle_points), on as many of the bench's own frames as fit
+    in the budget."""
+    import ctypes as C
+    import numpy as np
+    from oracle import oracle as O
+    O.build()
+    native = os.path.join(ROOT, "oracle", "liborc_native.so")
+    lib = C.CDLL(native)
+    lib.orc_refined_saddle_points.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_long, C.c_int, C.c_void_p,
+                                              C.c_void_p, C.c_int, C.c_void_p]
+    prm = O.default_params()
+    out = np.zeros(1 << 16, O.SADDLE_DTYPE)
+    n_done, t_used = 0, 0.0
+    h, w = frames_host.shape[1:3]
+    ofmt = {"L8": O.FMT_L8, "L16": O.FMT_L16, "RGB8": O.FMT_RGB8}[fmt]
+    stride = w * IN_BYTES[fmt]
+    # one untimed warm-up call
+    lib.orc_refined_saddle_points(frames_host[0].ctypes.data, w, h, stride, ofmt, C.addressof(prm),
+                                  out.ctypes.data, len(out), None)
+    while t_used < budget_s and n_done < 4 * len(frames_host):
+        f = frames_host[n_done % len(frames_host)]
+        t0 = time.perf_counter()
+        lib.orc_refined_saddle_points(f.ctypes.data, w, h, stride, ofmt, C.addressof(prm), out.ctypes.data,
+                                      len(out), None)
+        t_used += time.perf_counter() - t0
+        n_done += 1
+    mpix = n_done * w * h / t_used / 1e6
+    return {"value": round(mpix, 3), "unit": "Mpix/s", "cores": 1, "kind": "port",
+            "sample": "%d frames %dx%d %s, chain only (refined_saddle_points), oracle/agx_oracle.c -O3 "
+                      "-march=native -ffp-contract=off, %.1f s" % (n_done, w, h, fmt, t_used),
+            "ms_per_frame": round(1e3 * t_used / n_done, 3)}
+
+
+def main():
+    args = parse_args()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import aprilgrid_rs_amd as A
+    from aprilgrid_rs_amd import synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs the torch.distributed.run launcher (WORLD_SIZE=%d)" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    W, H, F = args.width, args.height, args.frames
+    # ---- synthetic workload: frames [rank*F, rank*F + F) of the seeded generator, rendered
+    # straight into HBM; `unique` distinct frames tiled (rendering is outside the timed region)
+    uniq = max(1, min(args.unique, F))
+    base, gts = synth.render_batch(rank * F, uniq, W, H, device=dev, fmt=args.format, pure_noise=args.noise)
+    reps = (F + uniq - 1) // uniq
+    frames = base.repeat((reps,) + (1,) * (base.dim() - 1))[:F].contiguous()
+    del base
+    px_per_step_rank = F * W * H
+
+    det = A.TagDetector(A.TagFamily.T36H11, None, device=local_rank)
+    stream = torch.cuda.current_stream(dev)
+    det.set_stream(stream.cuda_stream)  # kernels, events and the RCCL gather share torch's stream order
+
+    SLAB = 1024  # saddle records per frame in the result slab (20 KB / frame)
+    out_saddles = torch.zeros((F * SLAB, 5), dtype=torch.float32, device=dev)
+    table = torch.zeros((F, 4), dtype=torch.int32, device=dev)
+    if world > 1 and rank == 0:
+        g_saddles = [torch.empty_like(out_saddles) for _ in range(world)]
+        g_tables = [torch.empty_like(table) for _ in range(world)]
+
+    def step():
+        det.saddles_batch_enqueue_to(frames, out_saddles, table)
+        if world > 1:
+            # the one collective of the path: result gather to rank 0 (RCCL over xGMI)
+            dist.gather(table, g_tables if rank == 0 else None, dst=0)
+            dist.gather(out_saddles, g_saddles if rank == 0 else None, dst=0)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    tb = table.cpu().numpy()
+    assert (tb[:, 2] & 7 == 0).all(), "capacity overflow in the bench workload: %s" % tb[tb[:, 2] != 0][:4]
+    saddles_per_frame = float(tb[:, 0].mean())
+    clusters_per_frame = float(tb[:, 3].mean())
+
+    det.profile_enable(True)
+    det.profile_reset()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = det.profile_read()
+    det.profile_enable(False)
+
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    result = None
+    if rank == 0:
+        total_px = px_per_step_rank * world * args.steps
+        ms_per_step = 1e3 * dt / args.steps
+        mpix = total_px / dt / 1e6
+        in_b = IN_BYTES[args.format]
+        k1_ms, k1_n = prof["k_blur_hessian"]
+        k1_avg_ms = k1_ms / max(k1_n, 1)
+        k1_bytes = px_per_step_rank * (in_b + 8)  # read input, write blur f32 + response f32
+        k1_gbps = k1_bytes / (k1_avg_ms * 1e-3) / 1e9
+        chain_ms = sum(v[0] for v in prof.values()) / max(k1_n, 1)
+        a_mat = in_b + 12  # input + blur write + response write + response re-read
+        result = {
+            "metric": "Mpix/s through the saddle chain (blur->threshold->gradient->saddle), frames resident in HBM",
+            "value": round(mpix, 1),
+            "unit": "Mpix/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "configs[%d]: %d synthetic %dx%d %s AprilGrid frames per GPU (T36H11 6x6 board, "
+                            "seeded renderer, %d distinct frames tiled)%s" % (
+                                1 if world == 1 else 2, F, W, H, args.format, uniq,
+                                ", pure noise" if args.noise else ""),
+                "frames_per_gpu": F, "width": W, "height": H, "format": args.format,
+                "frames_per_s": round(F * world * args.steps / dt, 1),
+                "saddles_per_frame": round(saddles_per_frame, 1),
+                "clusters_per_frame": round(clusters_per_frame, 1),
+                "parallelism": "frame-sharded x%d, RCCL gather of result slabs" % world if world > 1 else "1 GPU",
+            },
+            "roofline": {
+                "kernel": "k_blur_hessian (K1)",
+                "bound": "hbm",
+                "achieved": round(k1_gbps, 1),
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": round(k1_gbps / HBM_PEAK_GBPS, 4),
+                "frac_of_measured_copy_ceiling": round(k1_gbps / HBM_MEASURED_GBPS, 4),
+                "traffic": args.pmc_traffic,
+                "algorithmic_bytes_per_px": in_b + 8,
+                "bytes_per_launch": k1_bytes,
+                "avg_launch_ms": round(k1_avg_ms, 5),
+                "launches_timed": k1_n,
+            },
+            "chain": {
+                "a_mat_bytes_per_px": a_mat,
+                "kernel_ms_per_step": {k: round(v[0] / max(v[1], 1), 5) for k, v in prof.items()},
+                "sum_kernel_ms_per_step": round(chain_ms, 5),
+                "a_mat_GBps": round(px_per_step_rank * a_mat / (chain_ms * 1e-3) / 1e9, 1),
+                "a_mat_frac_of_peak": round(px_per_step_rank * a_mat / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            sample = frames[:uniq].cpu().numpy()
+            if args.format == "L16":
+                sample = sample.view(np.uint16)
+            result["cpu_baseline"] = cpu_baseline(sample, args.format, args.cpu_seconds)
+            result["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+        print(json.dumps(result), flush=True)
+    det.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return result
+
+
+if __name__ == "__main__":
+    main()

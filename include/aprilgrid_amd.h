@@ -1,0 +1,219 @@
+/*
+ * aprilgrid_amd.h -- C ABI of the MI355X-native AprilGrid saddle/tag detection path.
+ *
+ * This is the drop-in boundary for the Rust crate `aprilgrid` 0.8.0: every entry point
+ * below names the reference item (file:line under the crate root) it replaces, and a Rust
+ * shim binds them 1:1.  Plain pointers and sizes only -- no C++, torch or
+ * HIP types cross this line (a HIP stream is passed as an opaque void*).
+ *
+ * Conventions
+ *   - every function returns AGX_OK (0) or a negative agx_status; nothing unwinds across
+ *     the boundary (the reference's panics -- detector.rs:500 "Only support u8c1 and u8c3",
+ *     the height()-1 underflow at detector.rs:174 -- become AGX_ERR_FORMAT / AGX_ERR_ARG);
+ *   - the caller owns every buffer it passes; results are copied into caller memory;
+ *   - "nothing found" is AGX_OK with a zero count (reference: empty Vec / HashMap);
+ *   - a detector handle owns one device, one stream and its scratch planes: it is NOT
+ *     re-entrant.  The reference's `&self` methods are callable from many threads; a shim
+ *     keeps that property by pooling handles (one per calling thread);
+ *   - results never come from a CPU fallback: if the HIP runtime or a gfx950 device is
+ *     missing, agx_detector_create fails with AGX_ERR_NO_DEVICE.
+ */
+#ifndef APRILGRID_AMD_H
+#define APRILGRID_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AGX_ABI_VERSION 1
+
+typedef enum agx_status {
+    AGX_OK = 0,
+    AGX_ERR_ARG = -1,       /* null pointer, zero size, w or h < 2, bad stride            */
+    AGX_ERR_FORMAT = -2,    /* pixel format / channel count the reference panics on       */
+    AGX_ERR_CAPACITY = -3,  /* an output or internal list overflowed; nothing is truncated
+                               silently -- raise the capacity (agx_detector_set_limits)    */
+    AGX_ERR_HIP = -4,       /* a HIP runtime call failed; see agx_last_error              */
+    AGX_ERR_NO_DEVICE = -5, /* no usable gfx950 device                                    */
+    AGX_ERR_FAMILY = -6,    /* unknown tag family (TagFamily::from_str Err)               */
+    AGX_ERR_STATE = -7      /* call sequence error (e.g. fetch before enqueue)            */
+} agx_status;
+
+/* tag_families::TagFamily -- src/tag_families.rs:5-13 */
+typedef enum agx_family {
+    AGX_T16H5 = 0,
+    AGX_T25H7 = 1,
+    AGX_T25H9 = 2,
+    AGX_T36H11 = 3,
+    AGX_T36H11B1 = 4 /* 1-bit border */
+} agx_family;
+
+/* The three DynamicImage variants the reference's tests, benches and detect_kornia feed the
+ * path (src/detector.rs:409,507,478-503): ImageLuma8, ImageLuma16, ImageRgb8 (HWC). */
+typedef enum agx_format {
+    AGX_L8 = 0,   /* 1 byte / pixel                                    */
+    AGX_L16 = 1,  /* 2 bytes / pixel, native endian                    */
+    AGX_RGB8 = 2  /* 3 bytes / pixel, interleaved R,G,B (kornia Image<u8,3>) */
+} agx_format;
+
+/* detector::DetectorParams -- src/detector.rs:25-41 */
+typedef struct agx_params {
+    float tag_spacing_ratio; /* kept for layout parity; unused by the reference too (:621) */
+    float min_saddle_angle;
+    float max_saddle_angle;
+    uint8_t max_num_of_boards;
+} agx_params;
+
+/* saddle::Saddle -- src/saddle.rs:3-9 ; repr(C) {p.0, p.1, k, theta, phi}, 20 bytes */
+typedef struct agx_saddle {
+    float x, y, k, theta, phi;
+} agx_saddle;
+
+/* one entry of detect()'s HashMap<u32, [(f32,f32);4]> -- src/detector.rs:505,520 */
+typedef struct agx_tag {
+    uint32_t id;
+    float xy[8]; /* 4 corners (x,y), in the order the reference returns (:467-470) */
+} agx_tag;
+
+typedef struct agx_detector agx_detector; /* opaque; mirrors detector::TagDetector */
+
+/* TagFamily::from_str -- src/tag_families.rs:15-28.  Accepts "t36h11"/"T36H11" etc. */
+int agx_family_from_str(const char *name, int *family_out);
+
+/* DetectorParams::default_params -- src/detector.rs:33-40 : (0.3, 30, 60, 2) */
+void agx_default_params(agx_params *out);
+
+/* TagDetector::new(tag_family, optional_detector_params) -- src/detector.rs:364-406.
+ * params may be NULL (== None).  device = HIP device ordinal.  The constants the
+ * reference recomputes on every call (blur weights image_util.rs:111-124, cone kernel and
+ * pseudo-inverse detector.rs:208-254) are computed once here. */
+int agx_detector_create(int family, const agx_params *params, int device, agx_detector **out);
+void agx_detector_destroy(agx_detector *det);
+
+/* Family facts of TagDetector::new's table (edge, border, hamming_distance, code_list). */
+int agx_detector_family_info(const agx_detector *det, int *edge_bits, int *border_bits,
+                             int *hamming_distance, const uint64_t **codes, int *n_codes);
+
+/* Internal list capacities per frame (0 = keep default).  Defaults scale with the frame:
+ * candidates W*H/2, clusters W*H/16, saddles min(W*H/64, 16384).  Overflow of any of them
+ * is reported as AGX_ERR_CAPACITY for that frame, never truncated. */
+int agx_detector_set_limits(agx_detector *det, uint32_t max_candidates, uint32_t max_clusters,
+                            uint32_t max_saddles);
+
+/* Use the caller's HIP stream (hipStream_t as void*) instead of the detector's own, e.g. so
+ * that events recorded by the caller bracket the kernels.  NULL restores the own stream. */
+int agx_detector_set_stream(agx_detector *det, void *hip_stream);
+
+/* ---- single frame, host memory in / host memory out ---------------------------------- */
+
+/* TagDetector::refined_saddle_points(&self, img) -> Vec<Saddle> -- src/detector.rs:408-446.
+ * pixels: host pointer, row_stride_bytes between rows.  Writes min(*n_out, cap) saddles in
+ * the reference's order (clusters by ascending first pixel, raster order); returns
+ * AGX_ERR_CAPACITY (with *n_out = required) if cap is too small. */
+int agx_refined_saddle_points(agx_detector *det, const void *pixels, int width, int height,
+                              size_t row_stride_bytes, int format, agx_saddle *out, uint32_t cap,
+                              uint32_t *n_out);
+
+/* TagDetector::detect(&self, img) -> HashMap<u32,[(f32,f32);4]> -- src/detector.rs:505-540,
+ * and detect_kornia (:478-503) through format = AGX_L8 / AGX_RGB8.  One entry per distinct
+ * id (a later quad with the same id replaces the earlier one, as HashMap::insert). */
+int agx_detect(agx_detector *det, const void *pixels, int width, int height,
+               size_t row_stride_bytes, int format, agx_tag *out, uint32_t cap, uint32_t *n_out);
+
+/* ---- batches of equally sized frames resident in device memory (HBM) ------------------ */
+
+/* Enqueue the whole saddle chain (luma -> blur -> Hessian response -> min/threshold ->
+ * clustering -> rochade_refine -> k/phi filter) for n_frames frames on the detector's
+ * stream and return without waiting.  d_frames: DEVICE pointer; frame i starts at
+ * d_frames + i*frame_stride_bytes.  row_stride_bytes must be a multiple of 4. */
+int agx_saddles_batch_enqueue(agx_detector *det, const void *d_frames, int n_frames, int width,
+                              int height, size_t row_stride_bytes, size_t frame_stride_bytes,
+                              int format);
+
+/* Wait for the enqueued batch and copy the results out.  out: n_frames * cap_per_frame
+ * saddles (frame i at out + i*cap_per_frame); counts[i] = saddles of frame i;
+ * frame_status[i] (may be NULL) = AGX_OK or AGX_ERR_CAPACITY.  Returns the first non-OK
+ * frame status, else AGX_OK. */
+int agx_saddles_batch_fetch(agx_detector *det, agx_saddle *out, uint32_t cap_per_frame,
+                            uint32_t *counts, int *frame_status);
+
+/* Same chain, results left in CALLER-OWNED DEVICE memory (nothing is copied to the host), so
+ * that they can be consumed or gathered on the device (RCCL):
+ *   d_saddles      room for saddle_capacity agx_saddle records; the frames' lists are packed
+ *                  back to back in completion order (each list itself in reference order);
+ *   d_frame_table  n_frames agx_frame_result entries: where frame i's list starts, its length
+ *                  and its status flags (0 = ok; AGX_FRAME_* bits otherwise).
+ * A frame whose list does not fit (or whose internal lists overflowed) gets a non-zero
+ * status and no records -- never a truncated list. */
+typedef struct agx_frame_result {
+    uint32_t count;   /* saddles of this frame                     */
+    uint32_t offset;  /* index of its first record in d_saddles    */
+    uint32_t status;  /* 0 or a combination of AGX_FRAME_* bits    */
+    uint32_t n_clusters;
+} agx_frame_result;
+enum {
+    AGX_FRAME_CANDIDATE_OVERFLOW = 1,
+    AGX_FRAME_CLUSTER_OVERFLOW = 2,
+    AGX_FRAME_SADDLE_OVERFLOW = 4,
+    AGX_FRAME_CENTROID_INEXACT = 8 /* informational: a cluster's coordinate sum reached 2^24 */
+};
+int agx_saddles_batch_enqueue_to(agx_detector *det, const void *d_frames, int n_frames, int width,
+                                 int height, size_t row_stride_bytes, size_t frame_stride_bytes,
+                                 int format, void *d_saddles, uint32_t saddle_capacity,
+                                 void *d_frame_table);
+
+/* Block until everything enqueued on the detector's stream has finished. */
+int agx_detector_sync(agx_detector *det);
+
+/* Host tail only: TagDetector::detect's board search + decode (src/detector.rs:510-539)
+ * from a saddle list and the u8 luma plane (to_luma8, :507), both in host memory.
+ * saddles is not modified. */
+int agx_detect_from_saddles(const agx_detector *det, const agx_saddle *saddles, uint32_t n_saddles,
+                            const uint8_t *luma8, int width, int height, size_t row_stride_bytes,
+                            agx_tag *out, uint32_t cap, uint32_t *n_out);
+
+/* to_luma8 (src/detector.rs:507) of a host image into a tightly packed host plane. */
+int agx_luma8(const void *pixels, int width, int height, size_t row_stride_bytes, int format,
+              uint8_t *out);
+
+/* ---- measurement and parity-test hooks ------------------------------------------------ */
+
+/* Per-kernel device time of the chain, from hipEvents recorded on the detector's stream
+ * around each launch while profiling is on.  names/ms/launches are arrays of
+ * AGX_N_KERNELS entries; ms accumulates since the last reset. */
+#define AGX_N_KERNELS 6
+int agx_profile_enable(agx_detector *det, int on);
+int agx_profile_reset(agx_detector *det);
+int agx_profile_read(agx_detector *det, const char **names, double *ms_total, uint64_t *launches);
+
+/* Copy an intermediate product of frame `frame` of the last batch to host memory.
+ * what: AGX_DBG_BLUR / AGX_DBG_RESP (width*height floats), AGX_DBG_MIN (1 float),
+ * AGX_DBG_CENTERS (n clusters * {u32 first_index, u32 size, f32 cx, f32 cy} sorted by
+ * first_index), AGX_DBG_REFINED (unfiltered rochade_refine output, agx_saddle each, in
+ * cluster order).  *n_items receives the element count; returns AGX_ERR_CAPACITY if
+ * cap_bytes is too small. */
+enum { AGX_DBG_BLUR = 0, AGX_DBG_RESP = 1, AGX_DBG_MIN = 2, AGX_DBG_CENTERS = 3, AGX_DBG_REFINED = 4 };
+typedef struct agx_cluster_info {
+    uint32_t first_index, size;
+    float cx, cy;
+} agx_cluster_info;
+int agx_debug_fetch(agx_detector *det, int frame, int what, void *host_out, size_t cap_bytes,
+                    size_t *n_items);
+
+/* Constants computed at create time (for parity tests): 7 blur weights, 25 cone taps,
+ * 25x6 pseudo-inverse (row i, column j at [i*6+j]). */
+int agx_detector_constants(const agx_detector *det, float *blur_w7, float *cone25, float *pmat150);
+
+const char *agx_status_string(int status);
+/* Message of the last failure on this detector (HIP error text etc.); never NULL.
+ * det == NULL: the reason of the last failed agx_detector_create. */
+const char *agx_last_error(const agx_detector *det);
+int agx_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* APRILGRID_AMD_H */

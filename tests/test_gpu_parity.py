@@ -1,0 +1,249 @@
+"""GPU parity: the HIP chain (through the C ABI) against the CPU oracle on the same inputs.
+
+Bar (DESIGN.md "Parity"): blur plane, response plane, per-frame min, cluster table
+(first pixel, size, centroid) and the saddle coordinates x, y and strength k are BIT-EXACT;
+theta and phi go through acos/atan2 (device libm vs glibc) and must agree within
+ANGLE_TOL_DEG; saddle order and count are identical; tag ids identical and tag corners
+bit-identical (they are saddle coordinates).
+"""
+import numpy as np
+import pytest
+
+from tests.util import ALL_IMAGES, REFERENCE_TAG_COUNTS, bits_equal, load_image, synth_module
+
+pytestmark = pytest.mark.gpu
+
+ANGLE_TOL_DEG = 1e-3  # |theta|, |phi| difference allowed, degrees (observed ~1e-5)
+
+
+@pytest.fixture(scope="module")
+def det():
+    import aprilgrid_rs_amd as A
+    d = A.TagDetector(A.TagFamily.T36H11, None, device=0)
+    yield d
+    d.close()
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import oracle as O
+    O.lib()
+    return O
+
+
+def check_saddles(gpu, ref, what=""):
+    assert len(gpu) == len(ref), "%s: %d saddles vs oracle %d" % (what, len(gpu), len(ref))
+    for f in ("x", "y", "k"):
+        assert bits_equal(gpu[f], ref[f]), "%s: field %s differs" % (what, f)
+    for f in ("theta", "phi"):
+        if len(ref):
+            assert np.max(np.abs(gpu[f] - ref[f])) <= ANGLE_TOL_DEG, (what, f)
+
+
+def check_frame(det, O, img, frame=0, what="", params=None):
+    """Compare every intermediate product of `frame` of the detector's last batch."""
+    h, w = img.shape[:2]
+    ref, d = O.refined_saddle_points(img, params=params, debug=True)
+    assert bits_equal(det.debug_fetch(frame, "blur", (h, w)), d["blur"]), what + ": blur plane"
+    assert bits_equal(det.debug_fetch(frame, "resp", (h, w)), d["resp"]), what + ": response plane"
+    assert bits_equal(np.float32(det.debug_fetch(frame, "min")), np.float32(d["min_resp"])), what + ": min"
+    c = det.debug_fetch(frame, "centers")
+    assert len(c) == len(d["centers"]), what + ": cluster count %d vs %d" % (len(c), len(d["centers"]))
+    assert np.array_equal(c["first_index"], d["first_index"]), what + ": cluster first pixels"
+    assert np.array_equal(c["size"], d["sizes"]), what + ": cluster sizes"
+    assert bits_equal(c["cx"], d["centers"][:, 0]) and bits_equal(c["cy"], d["centers"][:, 1]), what + ": centroids"
+    check_saddles(det.debug_fetch(frame, "refined"), d["refined"], what + " (unfiltered)")
+    return ref
+
+
+@pytest.mark.parametrize("name", ALL_IMAGES)
+def test_fixture_images_chain(det, oracle, name):
+    img = load_image(name)
+    got = det.refined_saddle_points(img, as_array=True)
+    ref = check_frame(det, oracle, img, 0, name)
+    check_saddles(got, ref, name)
+
+
+@pytest.mark.parametrize("name,expected", REFERENCE_TAG_COUNTS)
+def test_fixture_images_detect(det, oracle, name, expected):
+    """The reference's own end-to-end assertions (tests/test_detector.rs:26-32) through the
+    product path, plus id / corner parity with the oracle."""
+    img = load_image(name)
+    tags = det.detect(img)
+    assert len(tags) == expected
+    ref = oracle.detect(img)
+    assert sorted(tags) == sorted(ref)
+    for tid in ref:
+        assert bits_equal(tags[tid], ref[tid]), "corners of tag %d" % tid
+
+
+def test_detect_kornia_front_end(det, oracle):
+    """tests/test_detector.rs:35-43: Image<u8,3> -> 66 tags; u8c1 works; other N is refused."""
+    import aprilgrid_rs_amd as A
+    img = load_image("iphone.png")
+    assert len(det.detect_kornia(img)) == 66
+    g = load_image("EuRoC.png")[:, :, None]
+    assert len(det.detect_kornia(g)) == 36
+    with pytest.raises(A.AgxError):
+        det.detect_kornia(np.zeros((16, 16, 4), np.uint8))
+
+
+def test_all_pixel_values_exact(det, oracle):
+    """Every u8 and every u16 input value goes through the division-free luma conversion:
+    planes must still be bit-identical to the oracle's true division."""
+    v8 = np.repeat(np.repeat(np.arange(256, dtype=np.uint8).reshape(16, 16), 8, 0), 8, 1)
+    v8 = np.ascontiguousarray(np.hstack([v8, v8[::-1]]))
+    det.refined_saddle_points(v8, as_array=True)
+    check_frame(det, oracle, v8, 0, "all u8 values")
+    v16 = np.arange(65536, dtype=np.uint16).reshape(256, 256)
+    det.refined_saddle_points(v16, as_array=True)
+    check_frame(det, oracle, v16, 0, "all u16 values")
+    rng = np.random.default_rng(5)
+    rgb = rng.integers(0, 256, (96, 128, 3), dtype=np.uint8)
+    det.refined_saddle_points(rgb, as_array=True)
+    check_frame(det, oracle, rgb, 0, "random rgb")
+
+
+@pytest.mark.parametrize("shape", [(2, 2), (3, 5), (9, 9), (10, 11), (37, 53), (64, 64), (33, 260), (100, 1023),
+                                   (16, 2044), (24, 2100), (12, 4100)])
+def test_ragged_sizes(det, oracle, shape):
+    """Sizes that are not multiples of 4 / of the wave, narrower than the blur radius, wider
+    than one strip (multi-strip with halo lanes), tiny."""
+    rng = np.random.default_rng(shape[0] * 10007 + shape[1])
+    img = rng.integers(0, 256, shape, dtype=np.uint8)
+    got = det.refined_saddle_points(img, as_array=True)
+    ref = check_frame(det, oracle, img, 0, "random %dx%d" % shape)
+    check_saddles(got, ref, str(shape))
+
+
+def test_flat_and_empty(det, oracle):
+    """Flat image: min = 0, threshold 0, no candidates -> empty result (detector.rs:432-434)."""
+    img = np.full((64, 80), 77, np.uint8)
+    assert len(det.refined_saddle_points(img, as_array=True)) == 0
+    assert det.detect(img) == {}
+    check_frame(det, oracle, img, 0, "flat")
+
+
+def test_degenerate_and_bad_arguments(det):
+    import aprilgrid_rs_amd as A
+    with pytest.raises(A.AgxError) as e:
+        det.refined_saddle_points(np.zeros((1, 40), np.uint8))  # reference: height()-1 underflow panic
+    assert e.value.status == -1
+    with pytest.raises(A.AgxError) as e:
+        det.refined_saddle_points(np.zeros((8, 8), np.float32))
+    assert e.value.status == -2
+
+
+def test_params_change_filter(oracle):
+    import aprilgrid_rs_amd as A
+    img = load_image("EuRoC.png")
+    p = A.DetectorParams(0.3, 40.0, 50.0, 1)
+    d = A.TagDetector("t36h11", p, device=0)
+    op = oracle.default_params()
+    op.min_saddle_angle, op.max_saddle_angle, op.max_num_of_boards = 40.0, 50.0, 1
+    check_saddles(d.refined_saddle_points(img, as_array=True), oracle.refined_saddle_points(img, params=op), "params")
+    d.close()
+
+
+def test_batch_matches_oracle_and_is_deterministic(det, oracle):
+    """A batch of synthetic frames resident in HBM, every frame against the oracle; a second
+    run of the same batch must reproduce the first bit for bit (union-find / atomics order
+    must not leak into results)."""
+    import torch
+    synth = synth_module()
+    frames, gts = synth.render_batch(0, 6, 640, 400, device="cuda")
+    det.saddles_batch_enqueue(frames)
+    res, status = det.saddles_batch_fetch()
+    assert (status == 0).all()
+    host = frames.cpu().numpy()
+    for i in range(frames.shape[0]):
+        ref = check_frame(det, oracle, host[i], i, "synthetic frame %d" % i)
+        check_saddles(res[i], ref, "synthetic frame %d" % i)
+    det.saddles_batch_enqueue(frames)
+    res2, _ = det.saddles_batch_fetch()
+    for a, b in zip(res, res2):
+        assert a.tobytes() == b.tobytes()
+    # ground truth by construction: every detected tag has the right id and corners near truth
+    tags = det.detect(host[0])
+    assert len(tags) >= 30
+    for tid, c in tags.items():
+        g = gts[0][tid]
+        for p in c:
+            assert np.min(np.hypot(*(g - p).T)) < 0.5
+
+
+@pytest.mark.parametrize("fmt", ["L16", "RGB8"])
+def test_batch_other_formats(det, oracle, fmt):
+    synth = synth_module()
+    frames, _ = synth.render_batch(40, 3, 320, 240, device="cuda", fmt=fmt)
+    det.saddles_batch_enqueue(frames)
+    res, status = det.saddles_batch_fetch()
+    assert (status == 0).all()
+    host = frames.cpu().numpy()
+    if fmt == "L16":
+        host = host.view(np.uint16)
+    for i in range(len(res)):
+        ref = check_frame(det, oracle, host[i], i, "%s frame %d" % (fmt, i))
+        check_saddles(res[i], ref, "%s frame %d" % (fmt, i))
+
+
+def test_noise_frames_many_clusters(det, oracle):
+    """Worst case for the sparse stages: pure noise (about 30 % of the pixels are candidates)."""
+    synth = synth_module()
+    frames, _ = synth.render_batch(7, 2, 320, 200, device="cuda", pure_noise=True)
+    det.saddles_batch_enqueue(frames)
+    res, status = det.saddles_batch_fetch()
+    assert (status == 0).all()
+    host = frames.cpu().numpy()
+    for i in range(2):
+        ref = check_frame(det, oracle, host[i], i, "noise frame %d" % i)
+        check_saddles(res[i], ref, "noise %d" % i)
+
+
+def test_capacity_overflow_is_reported_not_truncated(oracle):
+    import aprilgrid_rs_amd as A
+    d = A.TagDetector("T36H11", None, device=0)
+    d.set_limits(max_candidates=4096, max_clusters=1024, max_saddles=256)
+    img = load_image("EuRoC.png")
+    with pytest.raises(A.AgxError) as e:
+        d.refined_saddle_points(img)
+    assert e.value.status == -3
+    d.set_limits(0, 0, 0)
+    check_saddles(d.refined_saddle_points(img, as_array=True), oracle.refined_saddle_points(img), "after reset")
+    d.close()
+
+
+def test_constants_match_oracle(det, oracle):
+    w, cone, pmat = det.constants()
+    assert bits_equal(w, oracle.blur_weights(1.5))
+    op, ok = oracle.refine_constants(2)
+    assert bits_equal(cone, ok)
+    assert bits_equal(pmat, op)
+
+
+def test_full_size_batch_properties(det, oracle):
+    """BASELINE configuration size (1280x800), a 16-frame slice: per-frame results are
+    independent of batch position and batch composition (frame i alone == frame i in the
+    batch), and two spot frames match the oracle."""
+    synth = synth_module()
+    frames, _ = synth.render_batch(100, 16, 1280, 800, device="cuda")
+    det.saddles_batch_enqueue(frames)
+    res, status = det.saddles_batch_fetch()
+    assert (status == 0).all()
+    host = frames.cpu().numpy()
+    for i in (0, 15):
+        check_saddles(res[i], oracle.refined_saddle_points(host[i]), "1280x800 frame %d" % i)
+    for i in (3, 9):
+        det.saddles_batch_enqueue(frames[i:i + 1].contiguous())
+        single, _ = det.saddles_batch_fetch()
+        assert single[0].tobytes() == res[i].tobytes()
+    rev = torch_flip(frames)
+    det.saddles_batch_enqueue(rev)
+    res_rev, _ = det.saddles_batch_fetch()
+    for i in range(16):
+        assert res_rev[15 - i].tobytes() == res[i].tobytes()
+
+
+def torch_flip(frames):
+    import torch
+    return torch.flip(frames, dims=[0]).contiguous()
