@@ -41,7 +41,7 @@ SYMBOLS = {
     "agx_detector_family_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                            C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_int)]),
     "agx_detector_set_limits": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint32]),
-    "agx_detector_set_stream": (C.c_int, [_P, _P]),
+    "agx_detector_set_stream": (C.c_int, [_P, _P, C.c_int]),
     "agx_detector_sync": (C.c_int, [_P]),
     "agx_refined_saddle_points": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_size_t, C.c_int, _P, C.c_uint32,
                                             C.POINTER(C.c_uint32)]),

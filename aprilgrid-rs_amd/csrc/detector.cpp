@@ -418,12 +418,13 @@ int agx_detector_set_limits(agx_detector *det, uint32_t max_candidates, uint32_t
     return AGX_OK;
 }
 
-int agx_detector_set_stream(agx_detector *det, void *hip_stream)
+int agx_detector_set_stream(agx_detector *det, void *hip_stream, int external)
 {
     if (!det) return AGX_ERR_ARG;
-    (void)hipSetDevice(det->device);
-    (void)hipStreamSynchronize(det->stream);
-    det->stream = hip_stream ? (hipStream_t)hip_stream : det->own_stream;
+    HIP_TRY(det, hipSetDevice(det->device));
+    HIP_TRY(det, hipStreamSynchronize(det->stream));
+    harvest_events(det);
+    det->stream = external ? (hipStream_t)hip_stream : det->own_stream;
     return AGX_OK;
 }
 

@@ -181,11 +181,23 @@ class TagDetector:
     def set_limits(self, max_candidates=0, max_clusters=0, max_saddles=0):
         self._check(self._lib.agx_detector_set_limits(self._h, max_candidates, max_clusters, max_saddles))
 
-    def set_stream(self, hip_stream_ptr):
-        self._check(self._lib.agx_detector_set_stream(self._h, C.c_void_p(hip_stream_ptr or 0)))
+    def set_stream(self, hip_stream_ptr, external=True):
+        """external=True: launch on the given hipStream_t (0 = HIP's default stream);
+        external=False: back to the detector's own stream."""
+        self._check(self._lib.agx_detector_set_stream(self._h, C.c_void_p(hip_stream_ptr or 0), 1 if external else 0))
+        self._stream_ptr = hip_stream_ptr if external else "own"
 
     def sync(self):
         self._check(self._lib.agx_detector_sync(self._h))
+
+    def _follow_torch_stream(self, frames):
+        """Stream-order the chain behind whatever produced `frames`: launch on torch's current
+        stream of that device (a detector otherwise uses its own non-blocking stream, which
+        does not wait for work queued on torch's streams)."""
+        import torch
+        s = torch.cuda.current_stream(frames.device).cuda_stream
+        if getattr(self, "_stream_ptr", "own") != s:
+            self.set_stream(s)
 
     @staticmethod
     def _tensor_format(frames):
@@ -204,6 +216,7 @@ class TagDetector:
         """frames: a torch tensor on this detector's GPU -- [N,H,W] uint8 (L8), [N,H,W] int16/uint16
         (L16) or [N,H,W,3] uint8 (RGB8), contiguous.  Returns immediately; see saddles_batch_fetch."""
         fmt, bpp = self._tensor_format(frames)
+        self._follow_torch_stream(frames)
         n, h, w = frames.shape[:3]
         self._check(self._lib.agx_saddles_batch_enqueue(self._h, frames.data_ptr(), n, w, h, w * bpp, w * h * bpp,
                                                         fmt))
@@ -213,6 +226,7 @@ class TagDetector:
         """Device-resident results: out_saddles float32 [capacity, 5] and frame_table int32
         [n_frames, 4] (count, offset, status, clusters) are torch tensors on the same GPU."""
         fmt, bpp = self._tensor_format(frames)
+        self._follow_torch_stream(frames)
         n, h, w = frames.shape[:3]
         assert out_saddles.is_cuda and out_saddles.is_contiguous() and out_saddles.shape[1] == 5
         assert frame_table.is_cuda and frame_table.is_contiguous() and tuple(frame_table.shape) == (n, 4)

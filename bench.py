@@ -73,7 +73,7 @@ def cpu_baseline(frames_host, fmt, budget_s):
     # one untimed warm-up call
     lib.orc_refined_saddle_points(frames_host[0].ctypes.data, w, h, stride, ofmt, C.addressof(prm),
                                   out.ctypes.data, len(out), None)
-    while t_used < budget_s and n_done < 4 * len(frames_host):
+    while t_used < budget_s:
         f = frames_host[n_done % len(frames_host)]
         t0 = time.perf_counter()
         lib.orc_refined_saddle_points(f.ctypes.data, w, h, stride, ofmt, C.addressof(prm), out.ctypes.data,

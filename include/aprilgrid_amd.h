@@ -103,9 +103,12 @@ int agx_detector_family_info(const agx_detector *det, int *edge_bits, int *borde
 int agx_detector_set_limits(agx_detector *det, uint32_t max_candidates, uint32_t max_clusters,
                             uint32_t max_saddles);
 
-/* Use the caller's HIP stream (hipStream_t as void*) instead of the detector's own, e.g. so
- * that events recorded by the caller bracket the kernels.  NULL restores the own stream. */
-int agx_detector_set_stream(agx_detector *det, void *hip_stream);
+/* Stream selection.  external != 0: launch on the caller's stream `hip_stream` (hipStream_t as
+ * void*; NULL is HIP's legacy default stream) so that the chain is stream-ordered behind the
+ * producer of the frames and in front of consumers of the results (e.g. an RCCL gather), and
+ * events the caller records bracket the kernels.  external == 0: back to the detector's own
+ * non-blocking stream (hip_stream ignored). */
+int agx_detector_set_stream(agx_detector *det, void *hip_stream, int external);
 
 /* ---- single frame, host memory in / host memory out ---------------------------------- */
 
