@@ -7,10 +7,12 @@
 namespace agx {
 
 enum Kernel : int {
-    K_BLUR_HESSIAN = 0,  // K1: luma -> 7-tap blur -> Hessian determinant -> per-frame min
-    K_THRESHOLD = 1,     // K2: resp < 0.05*min  -> candidate list + slot plane
-    K_UNION = 2,         // K3a: 4-connected union-find over candidates
-    K_CENTROID = 3,      // K3b: root lookup, centroid sums, root list
+    K_BLUR_HESSIAN = 0,  // K1: luma -> 7-tap blur (stored) -> Hessian determinant -> per-frame min
+    K_THRESHOLD = 1,     // K2: verify K1's candidate superset mask against the final threshold
+                         //     (exact response recomputed from the blur plane at set bits only),
+                         //     then mask scan -> flood seeds
+    K_FLOOD = 2,         // K3: bit-parallel flood fill per seed -> cluster records
+    K_GENERIC = 3,       // K3g: guarded fallback (4 launches) for frames with oversized clusters
     K_REFINE = 4,        // K4: rochade_refine per cluster
     K_FILTER_SORT = 5,   // K5: k/phi filter, reference-order emission
     K_COUNT = 6
@@ -24,21 +26,28 @@ struct RefinedRec {
 
 // Per-frame counters, zeroed (hipMemsetAsync) before every batch.
 struct FrameCounters {
+    // its own 128-byte line: every wave of K1 publishes to / polls this word
     uint32_t min_key_inv;  // ~order_preserving(min response); atomicMax
-    uint32_t n_cand;       // candidates appended by K2 (may exceed capacity -> flag)
-    uint32_t n_roots;      // clusters
+    uint32_t pad0[31];
+    uint32_t n_seeds;      // flood seeds
+    uint32_t n_clusters;   // cluster records
     uint32_t n_refined;    // rochade_refine survivors
     uint32_t max_k_bits;   // max k (k >= 0 so the raw bits order correctly)
     uint32_t flags;        // FLAG_* below
     uint32_t n_out;        // saddles after the filter
     uint32_t out_offset;   // start of this frame's saddles in the compact output array
+    uint32_t n_cand;       // generic path: candidate pixels
+    uint32_t n_roots;      // generic path: union-find roots
+    uint32_t n_big;        // seeds handed to the block-wide flood
+    uint32_t pad1[22];
 };
 enum : uint32_t {
-    FLAG_CAND_OVERFLOW = 1u,
-    FLAG_ROOT_OVERFLOW = 2u,
+    FLAG_CAND_OVERFLOW = 1u,   // seed list (fast path) or candidate list (generic path) full
+    FLAG_ROOT_OVERFLOW = 2u,   // cluster list full
     FLAG_OUT_OVERFLOW = 4u,
-    FLAG_CENTROID_INEXACT = 8u  // a cluster's coordinate sum reached 2^24 (f32 sums of the
-                                // reference would round there)
+    FLAG_CENTROID_INEXACT = 8u,  // a cluster's coordinate sum reached 2^24 (f32 sums of the
+                                 // reference would round there)
+    FLAG_BIG_CLUSTER = 16u       // a component left the flood windows: frame redone generically
 };
 
 struct RefineConsts {
@@ -64,13 +73,30 @@ struct ChainArgs {
     float w[7];  // blur taps
     // dense planes [n_frames][H][W]
     float *blur;
-    float *resp;
-    uint32_t *slot_plane;
+    uint32_t *slot_plane;  // generic path only (sparse-touched)
+    // Candidate bit mask, TRANSPOSED: one word = 32 consecutive rows of one column.
+    // mask[frame][yb][MASK_PAD_X + x] holds rows 32*yb .. 32*yb+31 of column x (bit = row & 31).
+    // MASK_PAD_X zero words on both sides of a word row and the word rows past the image are
+    // never written and stay zero from allocation (flood windows reach into them).
+    uint32_t *mask;
+    int mask_wpr;            // words per word-row: round_up4(W + 2*MASK_PAD_X)
+    int mask_yb;             // word rows: H/32 + 4
+    long long mask_plane;    // words per frame = mask_wpr * mask_yb
+    int force_generic;       // test hook: treat every frame as FLAG_BIG_CLUSTER
+    int dbg;                 // timing ablations only (results invalid): 1 = K1 skips blur stores,
+                             // 4 = K1 skips the Hessian/min, 8 = K1 stores into an L2-resident
+                             // region, 16 = no shared-min refresh
     // per-frame
     FrameCounters *ctr;
     uint32_t *total_out;  // single counter: compact output allocation
-    // candidate arrays [n_frames][cap_cand]
     uint32_t cap_cand, cap_roots, cap_out;
+    uint32_t *seeds;      // [n_frames][cap_roots] pixel index of each flood seed
+    uint32_t *big_seeds;  // [n_frames][cap_roots] seeds whose component left the 32x32 window
+    // cluster records [n_frames][cap_roots]
+    uint32_t *clu_key;    // smallest pixel index of the cluster
+    uint32_t *clu_cnt;
+    uint32_t *clu_sx, *clu_sy;  // integer coordinate sums (K4 leaves the f32 centroid bits here)
+    // generic path: candidate arrays [n_frames][cap_cand]
     uint32_t *cand;    // pixel index | left<<30 | up<<31
     uint32_t *parent;
     uint32_t *sumx, *sumy, *cnt, *minidx;
@@ -90,5 +116,10 @@ bool plan_k1(ChainArgs &a, int override_rows_per_seg);
 int launch_kernel(int which, const ChainArgs &a, const RefineConsts &rc, void *stream);
 
 size_t k5_lds_bytes(const ChainArgs &a);
+
+constexpr int MASK_PAD_X = 64;  // zero columns on each side of the transposed mask (flood windows)  // flood window rows below the last image row
+
+// Debug: recompute the Hessian response plane of `frame` from its blur plane into dst.
+int launch_debug_resp(const ChainArgs &a, int frame, float *dst, void *stream);
 
 }  // namespace agx

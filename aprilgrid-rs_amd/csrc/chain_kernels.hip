@@ -13,9 +13,16 @@
 //                       workgroup owns a column strip and walks down a segment of rows,
 //                       keeping the 7-row vertical window and the 3-row Hessian window in
 //                       registers; LDS carries only the +-4 column neighbour exchange.
-//   K2 k_threshold      resp < 0.05*min (detector.rs:418,177): candidate compaction
-//   K3a k_union         4-connected components (image_util.rs:208-236) as lock-free union-find
-//   K3b k_centroid      centroid sums (detector.rs:421-429), cluster list
+//                       The response is NOT stored.  K1 also writes a candidate SUPERSET as a
+//                       1 bit / pixel mask: resp < 0.05*m for a running minimum m >= min_frame.
+//   K2 k_verify         the exact threshold resp < 0.05*min_frame (detector.rs:418,177) at the set
+//                       bits only (response recomputed from the blur plane); k_seeds: flood seeds
+//                       (candidates with no left / upper candidate) from the mask
+//   K3 k_flood          4-connected components (image_util.rs:208-236) + centroid sums
+//                       (detector.rs:421-429): one component per lane, bit-parallel flood fill
+//                       of a 32x32 window of the mask held in registers
+//   K3g k_g_*           guarded generic fallback (mask -> candidate list -> lock-free
+//                       union-find -> sums) for frames where a component leaves the window
 //   K4 k_refine         rochade_refine (detector.rs:194-361), one cluster per lane
 //   K5 k_filter_sort    k/phi filter (detector.rs:436-445), emission in reference order
 #include <hip/hip_runtime.h>
@@ -50,6 +57,25 @@ __device__ __forceinline__ float div_const(float v)
     return __builtin_fmaf(e, r, q);
 }
 
+// Neighbour-lane exchange by DPP wave shifts (one VALU op, no LDS): lane l receives the value
+// of lane l-1 (from_left) or l+1 (from_right); lane 0 / lane 63 receive 0.
+__device__ __forceinline__ float from_left(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float from_right(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+__device__ __forceinline__ uint32_t from_left_u(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint32_t from_right_u(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false);
+}
+
 // Raw pixel words of 4 consecutive pixels: L8 1 dword, L16 2 dwords, RGB8 3 dwords.
 template <int FMT>
 struct RawPx {
@@ -62,18 +88,19 @@ __device__ __forceinline__ RawPx<FMT> load_raw(const uint8_t *__restrict__ rowp,
 {
     constexpr int BPP = RawPx<FMT>::BPP;
     RawPx<FMT> r;
-    if (c0 + 3 < W) {
+    if (c0 >= 0 && c0 + 3 < W) {
         const uint32_t *p = reinterpret_cast<const uint32_t *>(rowp + (size_t)c0 * BPP);
 #pragma unroll
         for (int i = 0; i < BPP; ++i) r.d[i] = p[i];
     } else {
-        // last partial lane / lanes right of the image: clamp-to-edge, byte gather
+        // lanes reaching over the left / right image edge: clamp-to-edge, byte gather
 #pragma unroll
         for (int i = 0; i < BPP; ++i) r.d[i] = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             int c = c0 + j;
             c = c < W - 1 ? c : W - 1;
+            c = c > 0 ? c : 0;
 #pragma unroll
             for (int b = 0; b < BPP; ++b) {
                 uint32_t byte = rowp[(size_t)c * BPP + b];
@@ -112,54 +139,71 @@ __device__ __forceinline__ void convert_px(const RawPx<FMT> &r, float m[4])
 }
 
 // ------------------------------------------------------------------------------------------
-// K1
+// K1: every wave is autonomous.  A wave owns a strip of up to 248 columns: lane l holds the 4
+// pixels of columns xs-4+4l .. xs-1+4l of the current row, lanes 0 and n+1 are halo lanes that
+// only feed their neighbours.  The wave marches down its row segment; per row it converts 4
+// pixels, pulls the 3+3 neighbouring pixels from the adjacent lanes by DPP, does the 7-tap
+// horizontal pass, pushes the result into a 7-row register window for the vertical pass,
+// stores the blur row, and evaluates the Hessian determinant of the previous row (its left /
+// right blur neighbours again by DPP) for the per-frame minimum.  No LDS, no barriers.
 // ------------------------------------------------------------------------------------------
-// LDS: two ping-pong row buffers for the converted input row and two for the freshly blurred
-// row; slot t+1 belongs to thread t, slots 0 and T+1 are the clamp pads.
-template <int FMT, bool STORE_RESP>
-__global__ void k_blur_hessian(ChainArgs a)
+template <int FMT>
+__global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
 {
-    extern __shared__ float4 lds4[];
-    const int T = blockDim.x;
-    const int t = threadIdx.x;
-    float4 *sIn = lds4;                 // [2][T+2]
-    float4 *sBl = lds4 + 2 * (T + 2);   // [2][T+2]
-
-    const int strip = blockIdx.x % a.n_strips;
-    const int seg = blockIdx.x / a.n_strips;
+    const int lane = threadIdx.x & 63;
+    // wave-uniform quantities are made scalar explicitly (the compiler cannot prove it)
+    const int unit = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    if (unit >= a.n_strips * a.n_segs) return;  // whole wave
+    const int strip = unit % a.n_strips;
+    const int seg = unit / a.n_strips;
     const int frame = blockIdx.y;
     const int W = a.W, H = a.H;
     const int xs = strip * a.strip_cols;
     const int xe = min(W, xs + a.strip_cols);
-    const int hl = xs > 0 ? 1 : 0;
-    const int c0 = xs + 4 * (t - hl);
-    const bool lane_valid = (c0 >= xs) && (c0 < xe);
+    const int c0 = xs - 4 + 4 * lane;
+    const bool lane_valid = (lane >= 1) && (c0 < xe);
     const int ys = seg * a.rows_per_seg;
     const int ye = min(H, ys + a.rows_per_seg);
 
     const uint8_t *fbase = a.frames + (size_t)frame * (size_t)a.frame_stride;
     float *blur_f = a.blur + (size_t)frame * (size_t)a.plane;
-    float *resp_f = a.resp + (size_t)frame * (size_t)a.plane;
     const bool vec_ok = ((W & 3) == 0) && (c0 + 3 < W);
 
     const float w0 = a.w[0], w1 = a.w[1], w2 = a.w[2], w3 = a.w[3], w4 = a.w[4], w5 = a.w[5],
                 w6 = a.w[6];
 
-    // vertical window of horizontally blurred rows (oldest first)
-    float h0[4], h1[4], h2[4], h3[4], h4[4], h5[4], h6[4];
-    // Hessian window: rows b-3 (up), b-2 (mid) complete with edge columns; bprev = row b-1
-    float up[6], mid[6], bprev[4];
+    // Vertical pass as 7 running sums: acc[s] is the partial sum of one blur row in flight.  An
+    // arriving horizontally-blurred row h is tap 0 of blur row r+3, tap 1 of row r+2, ... tap 6
+    // of row r-3, so every sum receives its taps in index order exactly as image_util.rs:192-201
+    // adds them; w[i] == w[6-i] bit for bit (image_util.rs:116-124 evaluates exp(-(x*x)/..) for
+    // x = -3..3), so the 7 products per pixel are only 4 distinct ones.  The row loop is
+    // unrolled by 7 so that the slot of every sum is a compile-time register.
+    float acc[7][4];
+    float up[6], mid[6];  // blur rows b-2, b-1 with their edge columns
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        h0[j] = h1[j] = h2[j] = h3[j] = h4[j] = h5[j] = h6[j] = 0.0f;
-        bprev[j] = 0.0f;
-    }
+    for (int s7 = 0; s7 < 7; ++s7)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[s7][j] = 0.0f;
 #pragma unroll
     for (int j = 0; j < 6; ++j) up[j] = mid[j] = 0.0f;
-
     float run_min = 0.0f;  // the frame always contains its zero border ring
+    // Candidate superset: a pixel can only end up below the final threshold 0.05*min_frame if it
+    // is below 0.05*m for every m >= min_frame; m = the smallest response this frame has shown so
+    // far (own rows + what other waves published in ctr.min_key_inv).  thr_run only ever moves
+    // down towards the final threshold, so nothing is lost; the list is filtered again in K2.
+    FrameCounters &ctr = a.ctr[frame];
+    uint32_t *mask_f = a.mask + (size_t)frame * (size_t)a.mask_plane;
+    float thr_run = 0.0f, published = 0.0f;
+    int rows_to_sync = 0, sync_gap = 1;
+    uint32_t mw[4] = {0u, 0u, 0u, 0u};  // this lane's 4 mask words (4 columns x 32 rows) in progress
 
-    const int r0 = ys - 4, r1 = ye + 4;
+    // per-pixel "takes part in the min" (interior column of this lane's strip)
+    bool min_ok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) min_ok[j] = lane_valid && (c0 + j > 0) && (c0 + j < W - 1);
+    const bool store_ok = lane_valid && !(a.dbg & 1);
+
+    const int r0 = ys - 4, r1 = ye + 3;
     auto rowptr = [&](int r) {
         int rr = r < 0 ? 0 : (r > H - 1 ? H - 1 : r);
         return fbase + (size_t)rr * (size_t)a.row_stride;
@@ -167,193 +211,442 @@ __global__ void k_blur_hessian(ChainArgs a)
     RawPx<FMT> raw_a = load_raw<FMT>(rowptr(r0), c0, W);
     RawPx<FMT> raw_b = load_raw<FMT>(rowptr(r0 + 1), c0, W);
     RawPx<FMT> raw_c = load_raw<FMT>(rowptr(r0 + 2), c0, W);
+    RawPx<FMT> raw_d = load_raw<FMT>(rowptr(r0 + 3), c0, W);
 
 #pragma unroll 1
-    for (int r = r0; r <= r1; ++r) {
-        const int buf = (r - r0) & 1;
-        float4 *in_row = sIn + buf * (T + 2);
-        float4 *bl_row = sBl + buf * (T + 2);
-
-        float m[4];
-        convert_px<FMT>(raw_a, m);
-        raw_a = raw_b;
-        raw_b = raw_c;
-        if (r + 3 <= r1) raw_c = load_raw<FMT>(rowptr(r + 3), c0, W);
-
-        in_row[t + 1] = make_float4(m[0], m[1], m[2], m[3]);
-        if (t == 0) in_row[0] = make_float4(m[0], m[0], m[0], m[0]);
-        if (t == T - 1) in_row[T + 1] = make_float4(m[3], m[3], m[3], m[3]);
-        bl_row[t + 1] = make_float4(bprev[0], bprev[1], bprev[2], bprev[3]);
-        __syncthreads();
-
-        const float4 L = in_row[t];
-        const float4 R = in_row[t + 2];
-        const float bl_edge = bl_row[t].w;      // blur(row b-1, column c0-1)
-        const float br_edge = bl_row[t + 2].x;  // blur(row b-1, column c0+4)
-
-        // horizontal pass, image_util.rs:137-185: taps in index order, mul then add
-        const float x[10] = {L.y, L.z, L.w, m[0], m[1], m[2], m[3], R.x, R.y, R.z};
-        float hn[4];
+    for (int rbase = r0; rbase <= r1; rbase += 7) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float v = x[j] * w0;
-            v = v + x[j + 1] * w1;
-            v = v + x[j + 2] * w2;
-            v = v + x[j + 3] * w3;
-            v = v + x[j + 4] * w4;
-            v = v + x[j + 5] * w5;
-            v = v + x[j + 6] * w6;
-            hn[j] = v;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            h0[j] = h1[j]; h1[j] = h2[j]; h2[j] = h3[j]; h3[j] = h4[j];
-            h4[j] = h5[j]; h5[j] = h6[j]; h6[j] = hn[j];
-        }
-        // vertical pass, image_util.rs:187-203: blur row b = r-3
-        const int b = r - 3;
-        float bcur[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float v = h0[j] * w0;
-            v = v + h1[j] * w1;
-            v = v + h2[j] * w2;
-            v = v + h3[j] * w3;
-            v = v + h4[j] * w4;
-            v = v + h5[j] * w5;
-            v = v + h6[j] * w6;
-            bcur[j] = v;
-        }
-        if (lane_valid && b >= ys && b < ye) {
-            float *dst = blur_f + (size_t)b * W + c0;
-            if (vec_ok) {
-                *reinterpret_cast<float4 *>(dst) = make_float4(bcur[0], bcur[1], bcur[2], bcur[3]);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (c0 + j < W) dst[j] = bcur[j];
-            }
-        }
+        for (int k = 0; k < 7; ++k) {
+            const int r = rbase + k;
+            if (r > r1) break;  // wave-uniform
+            float m[4];
+            convert_px<FMT>(raw_a, m);
+            raw_a = raw_b;
+            raw_b = raw_c;
+            raw_c = raw_d;
+            if (r + 4 <= r1) raw_d = load_raw<FMT>(rowptr(r + 4), c0, W);
 
-        // Hessian determinant of row y = b-2 (rows b-3, b-2, b-1), image_util.rs:88-106
-        const int y = b - 2;
-        const float dn[6] = {bl_edge, bprev[0], bprev[1], bprev[2], bprev[3], br_edge};
-        if (lane_valid && y >= ys && y < ye) {
-            float o[4];
-            const bool row_border = (y == 0) || (y == H - 1);
+            // horizontal pass, image_util.rs:137-185: taps in index order, mul then add
+            const float x[10] = {from_left(m[1]), from_left(m[2]), from_left(m[3]), m[0], m[1], m[2], m[3],
+                                 from_right(m[0]), from_right(m[1]), from_right(m[2])};
+            float bc[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float v11 = up[j], v12 = up[j + 1], v13 = up[j + 2];
-                const float v21 = mid[j], v22 = mid[j + 1], v23 = mid[j + 2];
-                const float v31 = dn[j], v32 = dn[j + 1], v33 = dn[j + 2];
-                const float t22 = v22 * 2.0f;
-                const float lxx = (v21 - t22) + v23;
-                const float lyy = (v12 - t22) + v32;
-                const float lxy = (((v13 - v11) + v31) - v33) * 0.25f;
-                float d = lxx * lyy - lxy * lxy;
-                const int c = c0 + j;
-                if (row_border || c == 0 || c >= W - 1) d = 0.0f;
-                o[j] = d;
-                if (c < W) run_min = fminf(run_min, d);
+                float v = x[j] * w0;
+                v = v + x[j + 1] * w1;
+                v = v + x[j + 2] * w2;
+                v = v + x[j + 3] * w3;
+                v = v + x[j + 4] * w4;
+                v = v + x[j + 5] * w5;
+                v = v + x[j + 6] * w6;
+                // vertical pass: blur row b = r-3 completes, rows r-2 .. r+3 advance
+                const float p0 = v * w0, p1 = v * w1, p2 = v * w2, p3 = v * w3;
+                bc[j] = acc[k][j] + p0;                              // tap 6 of row r-3
+                acc[(k + 1) % 7][j] = acc[(k + 1) % 7][j] + p1;      // tap 5 of row r-2
+                acc[(k + 2) % 7][j] = acc[(k + 2) % 7][j] + p2;      // tap 4 of row r-1
+                acc[(k + 3) % 7][j] = acc[(k + 3) % 7][j] + p3;      // tap 3 of row r
+                acc[(k + 4) % 7][j] = acc[(k + 4) % 7][j] + p2;      // tap 2 of row r+1
+                acc[(k + 5) % 7][j] = acc[(k + 5) % 7][j] + p1;      // tap 1 of row r+2
+                acc[(k + 6) % 7][j] = p0;                            // tap 0 of row r+3 (free slot)
             }
-            if (STORE_RESP) {
-                float *dst = resp_f + (size_t)y * W + c0;
+            const int b = r - 3;
+            if (store_ok && b >= ys && b < ye) {
+                float *dst = blur_f + (size_t)((a.dbg & 8) ? (b & 7) : b) * W + c0;  // dbg 8: L2-resident target
                 if (vec_ok) {
-                    *reinterpret_cast<float4 *>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+                    *reinterpret_cast<float4 *>(dst) = make_float4(bc[0], bc[1], bc[2], bc[3]);
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        if (c0 + j < W) dst[j] = o[j];
+                        if (c0 + j < W) dst[j] = bc[j];
+                }
+            }
+            // Hessian determinant of row y = b-1 (rows b-2, b-1, b), image_util.rs:88-106
+            const float dn[6] = {from_left(bc[3]), bc[0], bc[1], bc[2], bc[3], from_right(bc[0])};
+            const int y = b - 1;
+            if (y >= ys && y < ye && !(a.dbg & 4)) {  // wave-uniform
+                if (y > 0 && y < H - 1) {
+                    float dv[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float v11 = up[j], v12 = up[j + 1], v13 = up[j + 2];
+                        const float v21 = mid[j], v22 = mid[j + 1], v23 = mid[j + 2];
+                        const float v31 = dn[j], v32 = dn[j + 1], v33 = dn[j + 2];
+                        const float t22 = v22 * 2.0f;
+                        const float lxx = (v21 - t22) + v23;
+                        const float lyy = (v12 - t22) + v32;
+                        const float lxy = (((v13 - v11) + v31) - v33) * 0.25f;
+                        // the 1-pixel border ring is exactly 0 (already in run_min's initial value)
+                        const float d = min_ok[j] ? (lxx * lyy - lxy * lxy) : 0.0f;
+                        run_min = fminf(run_min, d);
+                        dv[j] = d;
+                    }
+                    // refresh the running threshold with exponential back-off (rows 0,1,2,4,8,..)
+                    if (rows_to_sync <= 0 && !(a.dbg & 16)) {
+                        float wmin = run_min;
+#pragma unroll
+                        for (int off = 32; off > 0; off >>= 1) wmin = fminf(wmin, __shfl_xor(wmin, off, 64));
+                        if (wmin < published) {
+                            if (lane == 0) atomicMax(&ctr.min_key_inv, ~f32_order_key(wmin));
+                            published = wmin;
+                        }
+                        const uint32_t gk = __hip_atomic_load(&ctr.min_key_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const float gmin = gk ? f32_from_order_key(~gk) : 0.0f;  // 0 = nothing published yet
+                        thr_run = fminf(wmin, gmin) * 0.05f;
+                        rows_to_sync = sync_gap;
+                        sync_gap = min(sync_gap * 2, 32);
+                    }
+                    --rows_to_sync;
+                    const int sh = y & 31;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) mw[j] |= (dv[j] < thr_run) ? (1u << sh) : 0u;
+                }
+                if ((y & 31) == 31 || y == ye - 1) {  // word row complete (segments are 32-row aligned)
+                    if (lane_valid) {
+                        uint32_t *dst = mask_f + (size_t)(y >> 5) * a.mask_wpr + MASK_PAD_X + c0;
+                        if (c0 + 3 < W) {
+                            *reinterpret_cast<uint4 *>(dst) = make_uint4(mw[0], mw[1], mw[2], mw[3]);
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (c0 + j < W) dst[j] = mw[j];
+                        }
+                    }
+                    mw[0] = mw[1] = mw[2] = mw[3] = 0u;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                up[j] = mid[j];
+                mid[j] = dn[j];
+            }
+        }
+    }
+    // per-frame min: wave reduction, one atomic per wave
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) run_min = fminf(run_min, __shfl_xor(run_min, off, 64));
+    if (lane == 0) atomicMax(&ctr.min_key_inv, ~f32_order_key(run_min));  // always: the word must end up valid
+}
+
+// ------------------------------------------------------------------------------------------
+// K2: verify.  K1 left a superset of the candidates in the mask (threshold from a running
+// minimum).  One thread per mask word: at every set bit recompute the Hessian determinant from
+// the blur plane -- same expression, same operands as K1 -- and keep the bit only if
+// resp < 0.05*min_frame (detector.rs:418, :177).  Each thread owns its word: no atomics.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_verify(ChainArgs a)
+{
+    const int frame = blockIdx.y;
+    const FrameCounters &ctr = a.ctr[frame];
+    const float thr = f32_from_order_key(~ctr.min_key_inv) * 0.05f;
+    uint32_t *mask = a.mask + (size_t)frame * (size_t)a.mask_plane;
+    const float *blur = a.blur + (size_t)frame * (size_t)a.plane;
+    const int W = a.W;
+    const int total = ((a.H + 31) >> 5) * W;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int yb = i / W, x = i - yb * W;
+        uint32_t *wp = mask + (size_t)yb * a.mask_wpr + MASK_PAD_X + x;
+        const uint32_t m0 = *wp;
+        if (!m0) continue;
+        uint32_t m = m0, keep = m0;
+        while (m) {
+            const int b = __ffs(m) - 1;
+            m &= m - 1;
+            const float *c = blur + (size_t)(yb * 32 + b) * W + x;  // interior pixel (K1 sets no border bits)
+            const float v11 = c[-W - 1], v12 = c[-W], v13 = c[-W + 1];
+            const float v21 = c[-1], v22 = c[0], v23 = c[1];
+            const float v31 = c[W - 1], v32 = c[W], v33 = c[W + 1];
+            const float t22 = v22 * 2.0f;
+            const float lxx = (v21 - t22) + v23;
+            const float lyy = (v12 - t22) + v32;
+            const float lxy = (((v13 - v11) + v31) - v33) * 0.25f;
+            const float d = lxx * lyy - lxy * lxy;
+            if (!(d < thr)) keep &= ~(1u << b);
+        }
+        if (keep != m0) *wp = keep;
+    }
+}
+
+// Flood seeds = candidates with no candidate to the left and none above, from the mask.
+__global__ void __launch_bounds__(256) k_seeds(ChainArgs a)
+{
+    const int frame = blockIdx.y;
+    FrameCounters &ctr = a.ctr[frame];
+    const uint32_t *mask = a.mask + (size_t)frame * (size_t)a.mask_plane;
+    const int W = a.W, wpr = a.mask_wpr;
+    const int total = ((a.H + 31) >> 5) * W;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int yb = i / W, x = i - yb * W;
+        const uint32_t *wp = mask + (size_t)yb * wpr + MASK_PAD_X + x;
+        const uint32_t m = wp[0];
+        if (!m) continue;
+        const uint32_t upm = (m << 1) | (yb > 0 ? (wp[-wpr] >> 31) : 0u);
+        uint32_t sd = m & ~wp[-1] & ~upm;
+        while (sd) {
+            const int b = __ffs(sd) - 1;
+            sd &= sd - 1;
+            const uint32_t o = atomicAdd(&ctr.n_seeds, 1u);
+            if (o < a.cap_roots) a.seeds[(size_t)frame * a.cap_roots + o] = (uint32_t)(yb * 32 + b) * (uint32_t)W + (uint32_t)x;
+            else atomicOr(&ctr.flags, FLAG_CAND_OVERFLOW);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K3: bit-parallel flood fill, one seed per lane.  Window: 32 columns [sx-16, sx+15] x 32 rows
+// [sy-1, sy+30]; comp[c] / cand[c] hold column c of the window as a 32-bit word (bit = row).
+// Each sweep ORs the two neighbouring columns into a column and fills whole vertical runs of
+// the mask that contain a set bit with a carry-propagation add (fill_runs).  The seed is the
+// canonical one iff its component contains no pixel with a smaller raster index: then the lane
+// emits the cluster with exact integer sums.  A component that touches the window's left /
+// right / bottom edge may continue outside: its seed goes to the second tier (k_flood_block,
+// 128 x 64 window); a component that leaves that window too sets FLAG_BIG_CLUSTER and the
+// whole frame is redone by the generic kernels.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t fill_runs(uint32_t s, uint32_t m)
+{
+    // all bits of the runs of m that contain a bit of s (s subset of m)
+    const uint32_t upw = (((m + s) ^ m) | s) & m;  // from each run's lowest seed upwards
+    const uint32_t mr = __brev(m), sr = __brev(s);
+    const uint32_t dnw = __brev((((mr + sr) ^ mr) | sr) & mr);
+    return upw | dnw;
+}
+
+__device__ __forceinline__ uint32_t bitpos_sum(uint32_t c)
+{
+    return (uint32_t)__popc(c & 0xAAAAAAAAu) + 2u * (uint32_t)__popc(c & 0xCCCCCCCCu) +
+           4u * (uint32_t)__popc(c & 0xF0F0F0F0u) + 8u * (uint32_t)__popc(c & 0xFF00FF00u) +
+           16u * (uint32_t)__popc(c & 0xFFFF0000u);
+}
+
+constexpr int FLOOD_COLS = 32;
+
+__global__ void __launch_bounds__(64) k_flood(ChainArgs a)
+{
+    const int frame = blockIdx.y;
+    FrameCounters &ctr = a.ctr[frame];
+    if (ctr.flags & FLAG_CAND_OVERFLOW) return;
+    const uint32_t n = min(ctr.n_seeds, a.cap_roots);
+    const uint32_t *mask = a.mask + (size_t)frame * (size_t)a.mask_plane;
+    const uint32_t W = (uint32_t)a.W;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t p = a.seeds[(size_t)frame * a.cap_roots + i];
+        const uint32_t sx = p % W, sy = p / W;
+        const int sh = (int)((sy - 1u) & 31u);
+        const uint32_t *wp = mask + (size_t)((sy - 1u) >> 5) * a.mask_wpr + MASK_PAD_X + ((int)sx - 16);
+        uint32_t cand[FLOOD_COLS], comp[FLOOD_COLS];
+#pragma unroll
+        for (int c = 0; c < FLOOD_COLS; ++c) {
+            const unsigned long long two = (unsigned long long)wp[c] | ((unsigned long long)wp[a.mask_wpr + c] << 32);
+            cand[c] = (uint32_t)(two >> sh);  // bit r = row sy-1+r of column sx-16+c
+            comp[c] = 0u;
+        }
+        comp[16] = 2u;  // the seed: column sx, row sy
+        uint32_t changed;
+        do {
+            changed = 0u;
+#pragma unroll
+            for (int c = 0; c < FLOOD_COLS; ++c) {  // left-to-right sweep
+                uint32_t s = comp[c];
+                if (c > 0) s |= comp[c - 1];
+                if (c < FLOOD_COLS - 1) s |= comp[c + 1];
+                const uint32_t f = fill_runs(s & cand[c], cand[c]);
+                changed |= f ^ comp[c];
+                comp[c] = f;
+            }
+#pragma unroll
+            for (int c = FLOOD_COLS - 1; c >= 0; --c) {  // right-to-left sweep
+                uint32_t s = comp[c];
+                if (c > 0) s |= comp[c - 1];
+                if (c < FLOOD_COLS - 1) s |= comp[c + 1];
+                const uint32_t f = fill_runs(s & cand[c], cand[c]);
+                changed |= f ^ comp[c];
+                comp[c] = f;
+            }
+        } while (changed);
+        uint32_t all = 0u, left_of_seed = 0u;
+#pragma unroll
+        for (int c = 0; c < FLOOD_COLS; ++c) {
+            all |= comp[c];
+            if (c < 16) left_of_seed |= comp[c];
+        }
+        // a pixel of the component precedes the seed in raster order -> not the canonical seed
+        if ((all & 1u) || (left_of_seed & 2u)) continue;
+        if ((all >> 31) || comp[0] || comp[FLOOD_COLS - 1]) {  // may continue outside the window
+            const uint32_t o = atomicAdd(&ctr.n_big, 1u);
+            if (o < a.cap_roots) a.big_seeds[(size_t)frame * a.cap_roots + o] = p;
+            else atomicOr(&ctr.flags, FLAG_BIG_CLUSTER);
+            continue;
+        }
+        uint32_t cnt = 0, sumx = 0, sumy = 0;
+#pragma unroll
+        for (int c = 0; c < FLOOD_COLS; ++c) {
+            const uint32_t w = comp[c];
+            const uint32_t nc = (uint32_t)__popc(w);
+            cnt += nc;
+            sumy += bitpos_sum(w);
+            sumx += nc * (uint32_t)c;
+        }
+        sumx += cnt * (sx - 16u);  // window column 0 is image column sx-16 (mod 2^32 arithmetic)
+        sumy += cnt * (sy - 1u);   // window row 0 is image row sy-1
+        const uint32_t o = atomicAdd(&ctr.n_clusters, 1u);
+        if (o < a.cap_roots) {
+            const size_t q = (size_t)frame * a.cap_roots + o;
+            a.clu_key[q] = p;
+            a.clu_cnt[q] = cnt;
+            a.clu_sx[q] = sumx;
+            a.clu_sy[q] = sumy;
+        } else {
+            atomicOr(&ctr.flags, FLAG_ROOT_OVERFLOW);
+        }
+    }
+}
+
+// K3 second tier: one 128-thread workgroup per oversized component.  Thread t holds column
+// sx-64+t of a 128-column x 64-row window [sy-1, sy+62] as a 64-bit word (bit = row); each round
+// ORs the two neighbouring columns (through LDS) and fills vertical runs; rounds repeat until
+// no column changes.
+__device__ __forceinline__ unsigned long long brev64(unsigned long long v)
+{
+    return ((unsigned long long)__brev((uint32_t)v) << 32) | (unsigned long long)__brev((uint32_t)(v >> 32));
+}
+__device__ __forceinline__ unsigned long long fill_runs64(unsigned long long s, unsigned long long m)
+{
+    const unsigned long long upw = (((m + s) ^ m) | s) & m;
+    const unsigned long long mr = brev64(m), sr = brev64(s);
+    const unsigned long long dnw = brev64((((mr + sr) ^ mr) | sr) & mr);
+    return upw | dnw;
+}
+__device__ __forceinline__ uint32_t bitpos_sum64(unsigned long long c)
+{
+    return (uint32_t)__popcll(c & 0xAAAAAAAAAAAAAAAAull) + 2u * (uint32_t)__popcll(c & 0xCCCCCCCCCCCCCCCCull) +
+           4u * (uint32_t)__popcll(c & 0xF0F0F0F0F0F0F0F0ull) + 8u * (uint32_t)__popcll(c & 0xFF00FF00FF00FF00ull) +
+           16u * (uint32_t)__popcll(c & 0xFFFF0000FFFF0000ull) + 32u * (uint32_t)__popcll(c & 0xFFFFFFFF00000000ull);
+}
+
+__global__ void __launch_bounds__(128) k_flood_block(ChainArgs a)
+{
+    __shared__ unsigned long long s_comp[130];
+    __shared__ int s_changed[2];
+    __shared__ uint32_t s_sum[3];
+    const int frame = blockIdx.y;
+    FrameCounters &ctr = a.ctr[frame];
+    const uint32_t n = min(ctr.n_big, a.cap_roots);
+    if (n == 0) return;
+    const int t = threadIdx.x;
+    const uint32_t *mask = a.mask + (size_t)frame * (size_t)a.mask_plane;
+    const uint32_t W = (uint32_t)a.W;
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+        const uint32_t p = a.big_seeds[(size_t)frame * a.cap_roots + i];
+        const uint32_t sx = p % W, sy = p / W;
+        const int sh = (int)((sy - 1u) & 31u);
+        const uint32_t *wp = mask + (size_t)((sy - 1u) >> 5) * a.mask_wpr + MASK_PAD_X + ((int)sx - 64) + t;
+        const unsigned long long w01 = (unsigned long long)wp[0] | ((unsigned long long)wp[a.mask_wpr] << 32);
+        const unsigned long long w2 = wp[2 * a.mask_wpr];
+        const unsigned long long cand = sh ? ((w01 >> sh) | (w2 << (64 - sh))) : w01;  // bit r = row sy-1+r
+        unsigned long long comp = (t == 64) ? 2ull : 0ull;  // the seed: column sx, row sy
+        if (t == 0) {
+            s_comp[0] = 0ull;
+            s_comp[129] = 0ull;
+            s_changed[0] = s_changed[1] = 0;
+            s_sum[0] = s_sum[1] = s_sum[2] = 0u;
+        }
+        __syncthreads();
+        for (int it = 0;; ++it) {
+            s_comp[t + 1] = comp;
+            if (t == 0) s_changed[(it + 1) & 1] = 0;
+            __syncthreads();
+            const unsigned long long f = fill_runs64((comp | s_comp[t] | s_comp[t + 2]) & cand, cand);
+            if (f != comp) s_changed[it & 1] = 1;
+            comp = f;
+            __syncthreads();
+            if (!s_changed[it & 1]) break;
+        }
+        // not the canonical seed: a pixel of the component precedes it in raster order
+        const int earlier = ((comp & 1ull) != 0ull) || (t < 64 && (comp & 2ull) != 0ull);
+        const int edge = ((t == 0 || t == 127) && comp != 0ull) || ((comp >> 63) != 0ull);
+        const int any_earlier = __syncthreads_or(earlier);
+        const int any_edge = __syncthreads_or(edge);
+        if (!any_earlier) {
+            if (any_edge) {
+                if (t == 0) atomicOr(&ctr.flags, FLAG_BIG_CLUSTER);
+            } else {
+                const uint32_t nc = (uint32_t)__popcll(comp);
+                if (nc) {
+                    atomicAdd(&s_sum[0], nc);
+                    atomicAdd(&s_sum[1], nc * (sx - 64u + (uint32_t)t));
+                    atomicAdd(&s_sum[2], bitpos_sum64(comp) + nc * (sy - 1u));
+                }
+                __syncthreads();
+                if (t == 0) {
+                    const uint32_t o = atomicAdd(&ctr.n_clusters, 1u);
+                    if (o < a.cap_roots) {
+                        const size_t q = (size_t)frame * a.cap_roots + o;
+                        a.clu_key[q] = p;
+                        a.clu_cnt[q] = s_sum[0];
+                        a.clu_sx[q] = s_sum[1];
+                        a.clu_sy[q] = s_sum[2];
+                    } else {
+                        atomicOr(&ctr.flags, FLAG_ROOT_OVERFLOW);
+                    }
                 }
             }
         }
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            up[j] = mid[j];
-            mid[j] = dn[j];
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bprev[j] = bcur[j];
-    }
-
-    // per-frame min: wave shuffle reduction -> LDS -> one atomic per workgroup
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) run_min = fminf(run_min, __shfl_xor(run_min, off, 64));
-    __syncthreads();
-    float *red = reinterpret_cast<float *>(lds4);
-    if ((t & 63) == 0) red[t >> 6] = run_min;
-    __syncthreads();
-    if (t == 0) {
-        float mn = red[0];
-        for (int i = 1; i < (T >> 6); ++i) mn = fminf(mn, red[i]);
-        atomicMax(&a.ctr[frame].min_key_inv, ~f32_order_key(mn));
+        __syncthreads();
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// K2: threshold + candidate compaction.  A candidate gets a slot s in the frame's compact
-// arrays: cand[s] = pixel | left<<30 | up<<31 (is the left / upper 4-neighbour a candidate
-// too), parent[s] = s, zeroed sums; slot_plane[pixel] = s for the neighbour lookups of K3a.
+// K3g: generic fallback, run only for frames flagged FLAG_BIG_CLUSTER (every block checks the
+// flag and leaves at once otherwise).  Works for components of any size and shape.
+//   k_g_compact   mask -> candidate list (pixel | left<<30 | up<<31), slot plane
+//   k_g_union     lock-free union-find; links go from the larger slot to the smaller; every
+//                 access to parent[] is an agent-scope atomic (blocks run on any XCD)
+//   k_g_sums      per-root integer sums and smallest pixel; root list
+//   k_g_emit      roots -> cluster records (replacing the fast path's records of the frame)
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void emit_candidate(const ChainArgs &a, int frame, uint32_t p, bool left,
-                                               bool upn)
+__device__ __forceinline__ bool frame_is_generic(const ChainArgs &a, const FrameCounters &ctr)
 {
-    uint32_t slot = atomicAdd(&a.ctr[frame].n_cand, 1u);
-    if (slot < a.cap_cand) {
-        size_t o = (size_t)frame * a.cap_cand + slot;
-        a.cand[o] = p | (left ? 0x40000000u : 0u) | (upn ? 0x80000000u : 0u);
-        a.parent[o] = slot;
-        a.sumx[o] = 0u;
-        a.sumy[o] = 0u;
-        a.cnt[o] = 0u;
-        a.minidx[o] = 0xffffffffu;
-        a.slot_plane[(size_t)frame * (size_t)a.plane + p] = slot;
-    } else {
-        atomicOr(&a.ctr[frame].flags, FLAG_CAND_OVERFLOW);
-    }
+    return a.force_generic || (ctr.flags & FLAG_BIG_CLUSTER);
 }
 
-template <bool VEC>
-__global__ void k_threshold(ChainArgs a)
+__global__ void k_g_compact(ChainArgs a)
 {
     const int frame = blockIdx.y;
-    const float *resp = a.resp + (size_t)frame * (size_t)a.plane;
-    const float mn = f32_from_order_key(~a.ctr[frame].min_key_inv);
-    const float thr = mn * 0.05f;  // detector.rs:418
-    const int W = a.W;
-    if (VEC) {
-        const long long n4 = a.plane >> 2;
-        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
-             i += (long long)gridDim.x * blockDim.x) {
-            const float4 v = reinterpret_cast<const float4 *>(resp)[i];
-            const bool c0 = v.x < thr, c1 = v.y < thr, c2 = v.z < thr, c3 = v.w < thr;
-            if (c0 | c1 | c2 | c3) {
-                const uint32_t p0 = (uint32_t)(i << 2);
-                const uint32_t x0 = p0 % (uint32_t)W;
-                // candidates are interior pixels (the border ring is exactly 0 >= thr), so
-                // p-1 and p-W exist
-                if (c0) emit_candidate(a, frame, p0, (x0 > 0) && (resp[p0 - 1] < thr), resp[p0 - W] < thr);
-                if (c1) emit_candidate(a, frame, p0 + 1, c0, resp[p0 + 1 - W] < thr);
-                if (c2) emit_candidate(a, frame, p0 + 2, c1, resp[p0 + 2 - W] < thr);
-                if (c3) emit_candidate(a, frame, p0 + 3, c2, resp[p0 + 3 - W] < thr);
-            }
-        }
-    } else {
-        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.plane;
-             i += (long long)gridDim.x * blockDim.x) {
-            const float v = resp[i];
-            if (v < thr) {
-                const uint32_t p = (uint32_t)i;
-                emit_candidate(a, frame, p, resp[p - 1] < thr, resp[p - W] < thr);
+    FrameCounters &ctr = a.ctr[frame];
+    if (!frame_is_generic(a, ctr)) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctr.n_clusters = 0u;  // discard fast-path records
+    const uint32_t *mask = a.mask + (size_t)frame * (size_t)a.mask_plane;
+    const int wpr = a.mask_wpr, W = a.W;
+    const long long total = (long long)((a.H + 31) >> 5) * W;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int yb = (int)(i / W), x = (int)(i % W);
+        const uint32_t *wp = mask + (size_t)yb * wpr + MASK_PAD_X + x;
+        uint32_t m = wp[0];
+        if (!m) continue;
+        const uint32_t lm = wp[-1];                                          // candidate to the left
+        const uint32_t um = (m << 1) | (yb > 0 ? (wp[-wpr] >> 31) : 0u);     // candidate above
+        while (m) {
+            const int b = __ffs(m) - 1;
+            m &= m - 1;
+            const uint32_t p = (uint32_t)(yb * 32 + b) * (uint32_t)W + (uint32_t)x;
+            const uint32_t slot = atomicAdd(&ctr.n_cand, 1u);
+            if (slot < a.cap_cand) {
+                const size_t o = (size_t)frame * a.cap_cand + slot;
+                a.cand[o] = p | (((lm >> b) & 1u) << 30) | (((um >> b) & 1u) << 31);
+                a.parent[o] = slot;
+                a.sumx[o] = 0u;
+                a.sumy[o] = 0u;
+                a.cnt[o] = 0u;
+                a.minidx[o] = 0xffffffffu;
+                a.slot_plane[(size_t)frame * (size_t)a.plane + p] = slot;
+            } else {
+                atomicOr(&ctr.flags, FLAG_CAND_OVERFLOW);
             }
         }
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// K3a: union-find.  Links always point from the larger slot to the smaller one; all accesses
-// to parent[] are agent-scope atomics (workgroups of one frame run on any XCD).
-// ------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t uf_find_atomic(uint32_t *parent, uint32_t x)
 {
     for (;;) {
@@ -377,11 +670,13 @@ __device__ __forceinline__ void uf_unite(uint32_t *parent, uint32_t x, uint32_t 
     }
 }
 
-__global__ void k_union(ChainArgs a)
+__global__ void k_g_union(ChainArgs a)
 {
     const int frame = blockIdx.y;
-    if (a.ctr[frame].n_cand > a.cap_cand) return;  // overflow: slot_plane is incomplete
-    const uint32_t n = a.ctr[frame].n_cand;
+    const FrameCounters &ctr = a.ctr[frame];
+    if (!frame_is_generic(a, ctr)) return;
+    if (ctr.n_cand > a.cap_cand) return;  // overflow: slot_plane is incomplete, frame reported
+    const uint32_t n = ctr.n_cand;
     const size_t base = (size_t)frame * a.cap_cand;
     uint32_t *parent = a.parent + base;
     const uint32_t *slot_plane = a.slot_plane + (size_t)frame * (size_t)a.plane;
@@ -393,15 +688,13 @@ __global__ void k_union(ChainArgs a)
     }
 }
 
-// K3b: every candidate adds its coordinates to its root's sums (integer: exact and order
-// independent; the reference's f32 running sums, detector.rs:424-427, are exact too while
-// they stay below 2^24 -- FLAG_CENTROID_INEXACT marks the frames where they would not be);
-// roots append themselves to the cluster list.
-__global__ void k_centroid(ChainArgs a)
+__global__ void k_g_sums(ChainArgs a)
 {
     const int frame = blockIdx.y;
-    if (a.ctr[frame].n_cand > a.cap_cand) return;  // overflow: frame is reported, not processed
-    const uint32_t n = a.ctr[frame].n_cand;
+    FrameCounters &ctr = a.ctr[frame];
+    if (!frame_is_generic(a, ctr)) return;
+    if (ctr.n_cand > a.cap_cand) return;
+    const uint32_t n = ctr.n_cand;
     const size_t base = (size_t)frame * a.cap_cand;
     const uint32_t *parent = a.parent + base;
     for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
@@ -412,63 +705,130 @@ __global__ void k_centroid(ChainArgs a)
             if (q == r) break;
             r = q;
         }
-        const uint32_t x = p % (uint32_t)a.W, y = p / (uint32_t)a.W;
-        atomicAdd(&a.sumx[base + r], x);
-        atomicAdd(&a.sumy[base + r], y);
+        atomicAdd(&a.sumx[base + r], p % (uint32_t)a.W);
+        atomicAdd(&a.sumy[base + r], p / (uint32_t)a.W);
         atomicAdd(&a.cnt[base + r], 1u);
         atomicMin(&a.minidx[base + r], p);
         if (r == s) {
-            uint32_t i = atomicAdd(&a.ctr[frame].n_roots, 1u);
+            uint32_t i = atomicAdd(&ctr.n_roots, 1u);
             if (i < a.cap_roots) a.roots[(size_t)frame * a.cap_roots + i] = s;
-            else atomicOr(&a.ctr[frame].flags, FLAG_ROOT_OVERFLOW);
+            else atomicOr(&ctr.flags, FLAG_ROOT_OVERFLOW);
         }
+    }
+}
+
+__global__ void k_g_emit(ChainArgs a)
+{
+    const int frame = blockIdx.y;
+    FrameCounters &ctr = a.ctr[frame];
+    if (!frame_is_generic(a, ctr)) return;
+    const uint32_t n = min(ctr.n_roots, a.cap_roots);
+    const size_t base = (size_t)frame * a.cap_cand;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t s = a.roots[(size_t)frame * a.cap_roots + i];
+        const size_t q = (size_t)frame * a.cap_roots + i;
+        a.clu_key[q] = a.minidx[base + s];
+        a.clu_cnt[q] = a.cnt[base + s];
+        a.clu_sx[q] = a.sumx[base + s];
+        a.clu_sy[q] = a.sumy[base + s];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctr.n_clusters = n;
+}
+
+// Debug only (agx_debug_fetch AGX_DBG_RESP): the response plane K2 thresholds, materialised.
+__global__ void k_debug_resp(const float *__restrict__ blur, float *__restrict__ resp, int W, int H)
+{
+    const long long n = (long long)W * H;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W), y = (int)(i / W);
+        float d = 0.0f;
+        if (x > 0 && x < W - 1 && y > 0 && y < H - 1) {
+            const float *c = blur + i;
+            const float v11 = c[-W - 1], v12 = c[-W], v13 = c[-W + 1];
+            const float v21 = c[-1], v22 = c[0], v23 = c[1];
+            const float v31 = c[W - 1], v32 = c[W], v33 = c[W + 1];
+            const float t22 = v22 * 2.0f;
+            const float lxx = (v21 - t22) + v23;
+            const float lyy = (v12 - t22) + v32;
+            const float lxy = (((v13 - v11) + v31) - v33) * 0.25f;
+            d = lxx * lyy - lxy * lxy;
+        }
+        resp[i] = d;
     }
 }
 
 // ------------------------------------------------------------------------------------------
 // K4: rochade_refine, detector.rs:265-359, one cluster per lane.
 // ------------------------------------------------------------------------------------------
+template <bool VEC>
 __global__ void __launch_bounds__(64) k_refine(ChainArgs a, RefineConsts rc)
 {
     const int frame = blockIdx.y;
-    const uint32_t n = min(a.ctr[frame].n_roots, a.cap_roots);
-    const size_t cbase = (size_t)frame * a.cap_cand;
+    if (a.ctr[frame].flags & (FLAG_CAND_OVERFLOW | FLAG_ROOT_OVERFLOW)) return;
+    const uint32_t n = min(a.ctr[frame].n_clusters, a.cap_roots);
+    const size_t cbase = (size_t)frame * a.cap_roots;
     const float *img = a.blur + (size_t)frame * (size_t)a.plane;
     const int W = a.W, H = a.H;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint32_t s = a.roots[(size_t)frame * a.cap_roots + i];
-        const uint32_t sx = a.sumx[cbase + s], sy = a.sumy[cbase + s], cn = a.cnt[cbase + s];
+        const uint32_t s = i;
+        const uint32_t sx = a.clu_sx[cbase + s], sy = a.clu_sy[cbase + s], cn = a.clu_cnt[cbase + s];
         if (sx >= (1u << 24) || sy >= (1u << 24)) atomicOr(&a.ctr[frame].flags, FLAG_CENTROID_INEXACT);
         const float fn = (float)cn;
         const float initial_x = (float)sx / fn;  // detector.rs:427
         const float initial_y = (float)sy / fn;
-        a.sumx[cbase + s] = __float_as_uint(initial_x);  // kept for agx_debug_fetch
-        a.sumy[cbase + s] = __float_as_uint(initial_y);
+        a.clu_sx[cbase + s] = __float_as_uint(initial_x);  // kept for agx_debug_fetch
+        a.clu_sy[cbase + s] = __float_as_uint(initial_y);
         const float rxf = roundf(initial_x), ryf = roundf(initial_y);
         const int round_x = (int)rxf, round_y = (int)ryf;
         if (round_y - 4 < 0 || round_y + 4 >= H || round_x - 4 < 0 || round_x + 4 >= W) continue;
-        const float *win = img + (size_t)(round_y - 4) * W + (round_x - 4);
-        float v[81];
+        // The 9x9 window is streamed row by row through 25 running sums.  Patch value (r,c)
+        // receives its 25 taps in the reference's order (:283-297): window rows r..r+4 arrive in
+        // ascending order and the 5 taps of a row are added left to right.  Patch row r is
+        // complete after window row r+4 and is then folded into the 6 parameter sums (:321-328,
+        // i = r*5+c ascending).
+        const int wx0 = round_x - 4;
+        const int al = VEC ? (wx0 & 3) : 0;
+        const float *win = img + (size_t)(round_y - 4) * W + (wx0 - al);
+        float conv[25];
 #pragma unroll
-        for (int r = 0; r < 9; ++r)
-#pragma unroll
-            for (int c = 0; c < 9; ++c) v[r * 9 + c] = win[(size_t)r * W + c];
-        // cone-filtered 5x5 patch (:283-297) folded straight into the 6 parameter sums
-        // (:321-328): params[j] = sum_i pmat[i][j]*patch[i], i ascending
+        for (int q = 0; q < 25; ++q) conv[q] = 0.0f;
         float prm[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int r = 0; r < 5; ++r)
+        for (int wr = 0; wr < 9; ++wr) {
+            float v[9];
+            if (VEC) {
+                // three aligned 16-byte loads cover the 9 floats; shift by the misalignment
+                const float4 q0 = *reinterpret_cast<const float4 *>(win + (size_t)wr * W);
+                const float4 q1 = *reinterpret_cast<const float4 *>(win + (size_t)wr * W + 4);
+                const float4 q2 = *reinterpret_cast<const float4 *>(win + (size_t)wr * W + 8);
+                const bool s1 = (al & 1) != 0, s2 = (al & 2) != 0;
+                // shift left by 1 if s1, then by 2 if s2 (all indices compile-time)
+                const float u0 = s1 ? q0.y : q0.x, u1 = s1 ? q0.z : q0.y, u2 = s1 ? q0.w : q0.z, u3 = s1 ? q1.x : q0.w;
+                const float u4 = s1 ? q1.y : q1.x, u5 = s1 ? q1.z : q1.y, u6 = s1 ? q1.w : q1.z, u7 = s1 ? q2.x : q1.w;
+                const float u8 = s1 ? q2.y : q2.x, u9 = s1 ? q2.z : q2.y, u10 = s1 ? q2.w : q2.z;
+                v[0] = s2 ? u2 : u0; v[1] = s2 ? u3 : u1; v[2] = s2 ? u4 : u2; v[3] = s2 ? u5 : u3; v[4] = s2 ? u6 : u4;
+                v[5] = s2 ? u7 : u5; v[6] = s2 ? u8 : u6; v[7] = s2 ? u9 : u7; v[8] = s2 ? u10 : u8;
+            } else {
 #pragma unroll
-            for (int c = 0; c < 5; ++c) {
-                float conv = 0.0f;
-#pragma unroll
-                for (int pr = 0; pr < 5; ++pr)
-#pragma unroll
-                    for (int pc = 0; pc < 5; ++pc)
-                        conv = conv + v[(r + pr) * 9 + (c + pc)] * rc.cone[pr * 5 + pc];
-#pragma unroll
-                for (int j = 0; j < 6; ++j) prm[j] = prm[j] + rc.pmat[(r * 5 + c) * 6 + j] * conv;
+                for (int e = 0; e < 9; ++e) v[e] = win[(size_t)wr * W + e];
             }
+#pragma unroll
+            for (int r = 0; r < 5; ++r) {
+                const int pr = wr - r;
+                if (pr < 0 || pr > 4) continue;
+#pragma unroll
+                for (int c = 0; c < 5; ++c)
+#pragma unroll
+                    for (int pc = 0; pc < 5; ++pc) conv[r * 5 + c] = conv[r * 5 + c] + v[c + pc] * rc.cone[pr * 5 + pc];
+            }
+            if (wr >= 4) {
+                const int r = wr - 4;
+#pragma unroll
+                for (int c = 0; c < 5; ++c)
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) prm[j] = prm[j] + rc.pmat[(r * 5 + c) * 6 + j] * conv[r * 5 + c];
+            }
+        }
         const float a1 = prm[0], a2 = prm[1], a3 = prm[2], a4 = prm[3], a5 = prm[4];
         const float fxx = 2.0f * a1, fyy = 2.0f * a3, fxy = a2;
         const float d = fxx * fyy - fxy * fxy;
@@ -499,9 +859,9 @@ __global__ void __launch_bounds__(64) k_refine(ChainArgs a, RefineConsts rc)
         const float PI_F = 3.14159274101257324219f;
         const float phi = acosf(-c5 / k) / 2.0f / PI_F * 180.0f;
         const float theta = atan2f(c3, c4) / 2.0f / PI_F * 180.0f;
-        uint32_t o = atomicAdd(&a.ctr[frame].n_refined, 1u);  // o < n_roots <= cap_roots
+        uint32_t o = atomicAdd(&a.ctr[frame].n_refined, 1u);  // o < n_clusters <= cap_roots
         RefinedRec rec;
-        rec.key = a.minidx[cbase + s];
+        rec.key = a.clu_key[cbase + s];
         rec.x = rxf + x0;
         rec.y = ryf + y0;
         rec.k = k;
@@ -590,7 +950,7 @@ __global__ void k_filter_sort(ChainArgs a, uint32_t lds_entries)
             row[0] = bad ? 0u : nf;
             row[1] = off;
             row[2] = flags;
-            row[3] = ctr.n_roots;
+            row[3] = ctr.n_clusters;
         }
     }
     __syncthreads();
@@ -619,29 +979,26 @@ bool plan_k1(ChainArgs &a, int override_rows_per_seg)
 {
     const int W = a.W, H = a.H;
     if (W < 2 || H < 2) return false;
-    const int max_threads = 512;              // <= 8 waves per workgroup
-    const int max_cols = 4 * (max_threads - 2);
-    int n_strips = (W + max_cols - 1) / max_cols;
+    // K1 strips: at most 62 value lanes (248 columns) per wave, balanced over the width
+    int n_strips = (W + 247) / 248;
     int strip_cols = (((W + n_strips - 1) / n_strips) + 3) & ~3;
     n_strips = (W + strip_cols - 1) / strip_cols;
-    int lanes = strip_cols / 4 + (n_strips > 1 ? 2 : 0);
-    int threads = ((lanes + 63) / 64) * 64;
     a.n_strips = n_strips;
     a.strip_cols = strip_cols;
-    a.threads = threads;
-    // rows per segment: enough workgroups to fill 256 CUs a few times over, but segments
-    // long enough that the 9 warm-up rows stay a small fraction
+    a.threads = 256;
+    // rows per segment: enough waves to fill the chip several times over, but segments long
+    // enough that the 8 warm-up rows stay a small fraction
     int rps = override_rows_per_seg > 0 ? override_rows_per_seg : env_int("AGX_K1_ROWS", 0);
     if (rps <= 0) {
-        const long long target_wgs = 2048;
-        long long segs = (target_wgs + (long long)a.n_frames * n_strips - 1) /
-                         ((long long)a.n_frames * n_strips);
+        const long long target_waves = 24576;
+        long long segs = (target_waves + (long long)a.n_frames * n_strips - 1) / ((long long)a.n_frames * n_strips);
         if (segs < 1) segs = 1;
         rps = (int)((H + segs - 1) / segs);
-        if (rps < 16) rps = 16;
-        if (rps > 256) rps = 256;
     }
-    if (rps > H) rps = H;
+    // segments are aligned to the 32-row words of the transposed mask
+    rps = ((rps + 31) / 32) * 32;
+    if (rps < 32) rps = 32;
+    if (rps > 128) rps = 128;
     a.rows_per_seg = rps;
     a.n_segs = (H + rps - 1) / rps;
     return true;
@@ -657,9 +1014,9 @@ size_t k5_lds_bytes(const ChainArgs &a)
 template <int FMT>
 static hipError_t launch_k1(const ChainArgs &a, hipStream_t st)
 {
-    dim3 grid(a.n_strips * a.n_segs, a.n_frames), block(a.threads);
-    size_t lds = (size_t)4 * (a.threads + 2) * sizeof(float4);
-    hipLaunchKernelGGL((k_blur_hessian<FMT, true>), grid, block, lds, st, a);
+    const int units = a.n_strips * a.n_segs;
+    dim3 grid((units + 3) / 4, a.n_frames), block(256);
+    hipLaunchKernelGGL((k_blur_hessian<FMT>), grid, block, 0, st, a);
     return hipGetLastError();
 }
 
@@ -681,30 +1038,30 @@ int launch_kernel(int which, const ChainArgs &a, const RefineConsts &rc, void *s
         if (a.fmt == 1) return launch_k1<1>(a, st);
         return launch_k1<2>(a, st);
     case K_THRESHOLD: {
-        const bool vec = (a.W & 3) == 0;
-        long long items = vec ? (a.plane >> 2) : a.plane;
-        long long gx = (items + 255) / 256;
-        long long cap = 8192 / (a.n_frames > 0 ? a.n_frames : 1);
-        if (cap < 16) cap = 16;
-        if (gx > cap) gx = cap;
-        dim3 grid((unsigned)gx, a.n_frames), block(256);
-        if (vec) hipLaunchKernelGGL(k_threshold<true>, grid, block, 0, st, a);
-        else hipLaunchKernelGGL(k_threshold<false>, grid, block, 0, st, a);
+        dim3 grid(sparse_grid_x(a, 32), a.n_frames), block(256);
+        hipLaunchKernelGGL(k_verify, grid, block, 0, st, a);
+        hipLaunchKernelGGL(k_seeds, grid, block, 0, st, a);
         return hipGetLastError();
     }
-    case K_UNION: {
-        dim3 grid(sparse_grid_x(a, 8), a.n_frames), block(256);
-        hipLaunchKernelGGL(k_union, grid, block, 0, st, a);
+    case K_FLOOD: {
+        dim3 grid(sparse_grid_x(a, 16), a.n_frames), block(64);
+        hipLaunchKernelGGL(k_flood, grid, block, 0, st, a);
+        dim3 grid2(sparse_grid_x(a, 4), a.n_frames), block2(128);
+        hipLaunchKernelGGL(k_flood_block, grid2, block2, 0, st, a);
         return hipGetLastError();
     }
-    case K_CENTROID: {
+    case K_GENERIC: {
         dim3 grid(sparse_grid_x(a, 8), a.n_frames), block(256);
-        hipLaunchKernelGGL(k_centroid, grid, block, 0, st, a);
+        hipLaunchKernelGGL(k_g_compact, grid, block, 0, st, a);
+        hipLaunchKernelGGL(k_g_union, grid, block, 0, st, a);
+        hipLaunchKernelGGL(k_g_sums, grid, block, 0, st, a);
+        hipLaunchKernelGGL(k_g_emit, grid, block, 0, st, a);
         return hipGetLastError();
     }
     case K_REFINE: {
         dim3 grid(sparse_grid_x(a, 16), a.n_frames), block(64);
-        hipLaunchKernelGGL(k_refine, grid, block, 0, st, a, rc);
+        if ((a.W & 3) == 0) hipLaunchKernelGGL(k_refine<true>, grid, block, 0, st, a, rc);
+        else hipLaunchKernelGGL(k_refine<false>, grid, block, 0, st, a, rc);
         return hipGetLastError();
     }
     case K_FILTER_SORT: {
@@ -723,6 +1080,13 @@ int launch_kernel(int which, const ChainArgs &a, const RefineConsts &rc, void *s
     default:
         return hipErrorInvalidValue;
     }
+}
+
+int launch_debug_resp(const ChainArgs &a, int frame, float *dst, void *stream)
+{
+    hipLaunchKernelGGL(k_debug_resp, dim3(1024), dim3(256), 0, (hipStream_t)stream,
+                       a.blur + (size_t)frame * (size_t)a.plane, dst, a.W, a.H);
+    return hipGetLastError();
 }
 
 }  // namespace agx

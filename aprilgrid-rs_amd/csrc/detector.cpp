@@ -20,8 +20,8 @@ using namespace agx;
 
 namespace {
 
-const char *kKernelNames[K_COUNT] = {"k_blur_hessian", "k_threshold", "k_union",
-                                     "k_centroid",     "k_refine",    "k_filter_sort"};
+const char *kKernelNames[K_COUNT] = {"k_blur_hessian", "k_threshold", "k_flood",
+                                     "k_generic_x4",   "k_refine",    "k_filter_sort"};
 
 struct EventPair {
     hipEvent_t a, b;
@@ -37,9 +37,23 @@ struct agx_detector {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
+    // chunk pipeline: the frames of a batch are split into chunks that run the chain on
+    // different streams, so that the ALU-bound and the HBM-bound kernels of different chunks
+    // overlap; fork/join events order them behind / in front of `stream`
+    static constexpr int kMaxStreams = 8;
+    hipStream_t aux[kMaxStreams] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[kMaxStreams] = {};
+    int n_streams = 1;     // option "streams" (1 = everything on `stream`)
+    int chunk_frames = 1 << 20;  // option "chunk_frames"
     RefineConsts rc{};
     float blur_w[7]{};
     uint32_t lim_cand = 0, lim_roots = 0, lim_out = 0;
+    int force_generic = 0;
+    int k1_rows = 0;
+    int dbg = 0;
+    float *d_dbg_resp = nullptr;  // lazily allocated plane for agx_debug_fetch(AGX_DBG_RESP)
+    long long dbg_resp_plane = 0;
+    int ws_W = 0, ws_H = 0;       // geometry the mask plane was last zeroed for
 
     // workspace (device)
     ChainArgs args{};
@@ -57,6 +71,7 @@ struct agx_detector {
     float *h_out = nullptr;
     size_t h_out_records = 0;
     float *d_out_internal = nullptr;  // workspace copy of args.out
+    size_t mask_words = 0;
     bool external_out = false;       // last batch wrote into caller-owned device memory
 
     bool enqueued = false;
@@ -181,31 +196,59 @@ uint32_t clamp_u32(unsigned long long v, uint32_t lo, uint32_t hi)
     return (uint32_t)std::min<unsigned long long>(std::max<unsigned long long>(v, lo), hi);
 }
 
+size_t mask_words_per_frame(int W, int H) { return (size_t)((W + 2 * MASK_PAD_X + 3) & ~3) * (size_t)(H / 32 + 4); }
+
+// The mask's pad words / pad rows are never written by the kernels and must read as zero: the
+// plane is cleared whenever the frame geometry (hence the mask layout) changes.
+int set_mask_geometry(agx_detector *d, int W, int H)
+{
+    ChainArgs &a = d->args;
+    a.mask_wpr = (W + 2 * MASK_PAD_X + 3) & ~3;
+    a.mask_yb = H / 32 + 4;
+    a.mask_plane = (long long)a.mask_wpr * a.mask_yb;
+    if (d->ws_W != W || d->ws_H != H) {
+        HIP_TRY(d, hipMemsetAsync(a.mask, 0, d->mask_words * sizeof(uint32_t), d->stream));
+        d->ws_W = W;
+        d->ws_H = H;
+    }
+    return AGX_OK;
+}
+
 // (Re)allocate the workspace for n_frames frames of W x H.  Never called inside a timed
 // region once a configuration has been seen.
 int ensure_workspace(agx_detector *d, int n_frames, int W, int H)
 {
     const long long plane = (long long)W * H;
     const uint32_t cap_cand = d->lim_cand ? d->lim_cand : clamp_u32((unsigned long long)plane / 2, 4096, 1u << 28);
-    const uint32_t cap_roots = d->lim_roots ? d->lim_roots : clamp_u32((unsigned long long)plane / 16, 1024, 1u << 26);
+    const uint32_t cap_roots = d->lim_roots ? d->lim_roots : clamp_u32((unsigned long long)plane / 8, 1024, 1u << 26);
     const uint32_t cap_out = d->lim_out ? d->lim_out : clamp_u32((unsigned long long)plane / 64, 256, 8192);
     ChainArgs &a = d->args;
-    if ((size_t)n_frames <= d->cap_frames && plane <= d->cap_plane && cap_cand <= d->alloc_cand &&
-        cap_roots <= d->alloc_roots && cap_out <= d->alloc_out) {
+    const bool fits = (size_t)n_frames <= d->cap_frames && plane <= d->cap_plane && cap_cand <= d->alloc_cand &&
+                      cap_roots <= d->alloc_roots && cap_out <= d->alloc_out &&
+                      (size_t)n_frames * mask_words_per_frame(W, H) <= d->mask_words;
+    if (fits) {
         a.cap_cand = cap_cand;
         a.cap_roots = cap_roots;
         a.cap_out = cap_out;
-        return AGX_OK;
+        return set_mask_geometry(d, W, H);
     }
     HIP_TRY(d, hipStreamSynchronize(d->stream));
     free_workspace(d);
     const size_t F = (size_t)n_frames;
     int rc;
-    if ((rc = dev_alloc(d, a.blur, F * plane))) return rc;
-    if ((rc = dev_alloc(d, a.resp, F * plane))) return rc;
+    const size_t mask_plane = mask_words_per_frame(W, H);
+    if ((rc = dev_alloc(d, a.blur, F * plane + 16))) return rc;  // +16: aligned window loads may touch 3 floats past the end
     if ((rc = dev_alloc(d, a.slot_plane, F * plane))) return rc;
+    if ((rc = dev_alloc(d, a.mask, F * mask_plane))) return rc;
+    d->mask_words = F * mask_plane;
     if ((rc = dev_alloc(d, a.ctr, F))) return rc;
     if ((rc = dev_alloc(d, a.total_out, 1))) return rc;
+    if ((rc = dev_alloc(d, a.seeds, F * cap_roots))) return rc;
+    if ((rc = dev_alloc(d, a.big_seeds, F * cap_roots))) return rc;
+    if ((rc = dev_alloc(d, a.clu_key, F * cap_roots))) return rc;
+    if ((rc = dev_alloc(d, a.clu_cnt, F * cap_roots))) return rc;
+    if ((rc = dev_alloc(d, a.clu_sx, F * cap_roots))) return rc;
+    if ((rc = dev_alloc(d, a.clu_sy, F * cap_roots))) return rc;
     if ((rc = dev_alloc(d, a.cand, F * cap_cand))) return rc;
     if ((rc = dev_alloc(d, a.parent, F * cap_cand))) return rc;
     if ((rc = dev_alloc(d, a.sumx, F * cap_cand))) return rc;
@@ -215,6 +258,7 @@ int ensure_workspace(agx_detector *d, int n_frames, int W, int H)
     if ((rc = dev_alloc(d, a.roots, F * cap_roots))) return rc;
     if ((rc = dev_alloc(d, a.refined, F * cap_roots))) return rc;
     if ((rc = dev_alloc(d, d->d_out_internal, F * cap_out * 5))) return rc;
+    d->ws_W = d->ws_H = 0;  // forces the mask to be zeroed below
     HIP_TRY(d, hipHostMalloc((void **)&d->h_ctr, (F + 1) * sizeof(FrameCounters), hipHostMallocDefault));
     d->h_total = (uint32_t *)(d->h_ctr + F);
     d->h_ctr_frames = F;
@@ -225,7 +269,7 @@ int ensure_workspace(agx_detector *d, int n_frames, int W, int H)
     d->alloc_cand = a.cap_cand = cap_cand;
     d->alloc_roots = a.cap_roots = cap_roots;
     d->alloc_out = a.cap_out = cap_out;
-    return AGX_OK;
+    return set_mask_geometry(d, W, H);
 }
 
 hipEvent_t get_event(agx_detector *d)
@@ -255,26 +299,74 @@ void harvest_events(agx_detector *d)
     d->pending_events.clear();
 }
 
-int enqueue_chain(agx_detector *d)
+// The chain of one chunk (frames [f0, f0+nf) of the batch) on stream `st`.
+int enqueue_chunk(agx_detector *d, int f0, int nf, hipStream_t st)
 {
-    ChainArgs &a = d->args;
-    HIP_TRY(d, hipMemsetAsync(a.ctr, 0, (size_t)a.n_frames * sizeof(FrameCounters), d->stream));
-    HIP_TRY(d, hipMemsetAsync(a.total_out, 0, sizeof(uint32_t), d->stream));
+    ChainArgs a = d->args;  // shifted copy
+    const size_t F0 = (size_t)f0;
+    a.n_frames = nf;
+    a.frames += F0 * (size_t)a.frame_stride;
+    a.blur += F0 * (size_t)a.plane;
+    a.slot_plane += F0 * (size_t)a.plane;
+    a.mask += F0 * (size_t)a.mask_plane;
+    a.ctr += F0;
+    a.seeds += F0 * a.cap_roots;
+    a.big_seeds += F0 * a.cap_roots;
+    a.clu_key += F0 * a.cap_roots;
+    a.clu_cnt += F0 * a.cap_roots;
+    a.clu_sx += F0 * a.cap_roots;
+    a.clu_sy += F0 * a.cap_roots;
+    a.cand += F0 * a.cap_cand;
+    a.parent += F0 * a.cap_cand;
+    a.sumx += F0 * a.cap_cand;
+    a.sumy += F0 * a.cap_cand;
+    a.cnt += F0 * a.cap_cand;
+    a.minidx += F0 * a.cap_cand;
+    a.roots += F0 * a.cap_roots;
+    a.refined += F0 * a.cap_roots;
+    if (a.frame_table) a.frame_table += F0 * 4;
     for (int k = 0; k < K_COUNT; ++k) {
         EventPair ev{nullptr, nullptr, k};
         if (d->profiling) {
             ev.a = get_event(d);
             ev.b = get_event(d);
-            HIP_TRY(d, hipEventRecord(ev.a, d->stream));
+            HIP_TRY(d, hipEventRecord(ev.a, st));
         }
-        hipError_t e = (hipError_t)launch_kernel(k, a, d->rc, d->stream);
+        hipError_t e = (hipError_t)launch_kernel(k, a, d->rc, st);
         if (e != hipSuccess)
             return fail(d, AGX_ERR_HIP, std::string("launch ") + kKernelNames[k] + ": " + hipGetErrorString(e));
         if (d->profiling) {
-            HIP_TRY(d, hipEventRecord(ev.b, d->stream));
+            HIP_TRY(d, hipEventRecord(ev.b, st));
             d->pending_events.push_back(ev);
         }
     }
+    return AGX_OK;
+}
+
+int enqueue_chain(agx_detector *d)
+{
+    ChainArgs &a = d->args;
+    HIP_TRY(d, hipMemsetAsync(a.ctr, 0, (size_t)a.n_frames * sizeof(FrameCounters), d->stream));
+    HIP_TRY(d, hipMemsetAsync(a.total_out, 0, sizeof(uint32_t), d->stream));
+    const int F = a.n_frames;
+    const int chunk = std::max(1, d->chunk_frames);
+    const int n_chunks = (F + chunk - 1) / chunk;
+    const int S = std::min(d->n_streams, n_chunks);
+    int rc = AGX_OK;
+    if (S <= 1) {
+        for (int c = 0; c < n_chunks && rc == AGX_OK; ++c)
+            rc = enqueue_chunk(d, c * chunk, std::min(chunk, F - c * chunk), d->stream);
+    } else {
+        HIP_TRY(d, hipEventRecord(d->ev_fork, d->stream));
+        for (int i = 0; i < S; ++i) HIP_TRY(d, hipStreamWaitEvent(d->aux[i], d->ev_fork, 0));
+        for (int c = 0; c < n_chunks && rc == AGX_OK; ++c)
+            rc = enqueue_chunk(d, c * chunk, std::min(chunk, F - c * chunk), d->aux[c % S]);
+        for (int i = 0; i < S; ++i) {
+            HIP_TRY(d, hipEventRecord(d->ev_join[i], d->aux[i]));
+            HIP_TRY(d, hipStreamWaitEvent(d->stream, d->ev_join[i], 0));
+        }
+    }
+    if (rc) return rc;
     d->enqueued = true;
     return AGX_OK;
 }
@@ -377,6 +469,14 @@ int agx_detector_create(int family, const agx_params *params, int device, agx_de
         return AGX_ERR_HIP;
     }
     d->stream = d->own_stream;
+    for (int i = 0; i < agx_detector::kMaxStreams; ++i) {
+        if (hipStreamCreateWithFlags(&d->aux[i], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&d->ev_join[i], hipEventDisableTiming) != hipSuccess) {
+            g_create_error = "creating pipeline streams failed";
+            return AGX_ERR_HIP;
+        }
+    }
+    if (hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming) != hipSuccess) return AGX_ERR_HIP;
     make_blur_weights(1.5f, d->blur_w);
     make_refine_consts(d->rc);
     *out = d.release();
@@ -392,6 +492,13 @@ void agx_detector_destroy(agx_detector *det)
     for (hipEvent_t e : det->free_events) (void)hipEventDestroy(e);
     free_workspace(det);
     if (det->d_stage) (void)hipFree(det->d_stage);
+    if (det->d_dbg_resp) (void)hipFree(det->d_dbg_resp);
+    for (int i = 0; i < agx_detector::kMaxStreams; ++i) {
+        if (det->aux[i]) (void)hipStreamSynchronize(det->aux[i]);
+        if (det->aux[i]) (void)hipStreamDestroy(det->aux[i]);
+        if (det->ev_join[i]) (void)hipEventDestroy(det->ev_join[i]);
+    }
+    if (det->ev_fork) (void)hipEventDestroy(det->ev_fork);
     if (det->own_stream) (void)hipStreamDestroy(det->own_stream);
     delete det;
 }
@@ -425,6 +532,18 @@ int agx_detector_set_stream(agx_detector *det, void *hip_stream, int external)
     HIP_TRY(det, hipStreamSynchronize(det->stream));
     harvest_events(det);
     det->stream = external ? (hipStream_t)hip_stream : det->own_stream;
+    return AGX_OK;
+}
+
+int agx_detector_set_option(agx_detector *det, const char *name, int value)
+{
+    if (!det || !name) return AGX_ERR_ARG;
+    if (!std::strcmp(name, "force_generic")) det->force_generic = value != 0;
+    else if (!std::strcmp(name, "k1_rows_per_segment")) det->k1_rows = value > 0 ? value : 0;
+    else if (!std::strcmp(name, "debug_ablation")) det->dbg = value;  // timing only, results invalid
+    else if (!std::strcmp(name, "streams")) det->n_streams = std::min(std::max(value, 1), (int)agx_detector::kMaxStreams);
+    else if (!std::strcmp(name, "chunk_frames")) det->chunk_frames = std::max(value, 1);
+    else return fail(det, AGX_ERR_ARG, std::string("unknown option ") + name);
     return AGX_OK;
 }
 
@@ -475,7 +594,9 @@ static int batch_enqueue_impl(agx_detector *det, const void *d_frames, int n_fra
         a.frame_table = nullptr;
         det->external_out = false;
     }
-    if (!plan_k1(a, 0)) return fail(det, AGX_ERR_ARG, "unsupported frame geometry");
+    a.force_generic = det->force_generic;
+    a.dbg = det->dbg;
+    if (!plan_k1(a, det->k1_rows)) return fail(det, AGX_ERR_ARG, "unsupported frame geometry");
     return enqueue_chain(det);
 }
 
@@ -527,8 +648,8 @@ int agx_saddles_batch_fetch(agx_detector *det, agx_saddle *out, uint32_t cap_per
                 first_bad = st;
                 char buf[160];
                 std::snprintf(buf, sizeof buf,
-                              "frame %zu: capacity exceeded (flags=0x%x candidates=%u clusters=%u saddles=%u)", f,
-                              c.flags, c.n_cand, c.n_roots, c.n_out);
+                              "frame %zu: capacity exceeded (flags=0x%x seeds=%u clusters=%u candidates=%u saddles=%u)", f,
+                              c.flags, c.n_seeds, c.n_clusters, c.n_cand, c.n_out);
                 det->last_error = buf;
             }
             continue;
@@ -678,12 +799,35 @@ int agx_debug_fetch(agx_detector *det, int frame, int what, void *host_out, size
     FrameCounters c;
     HIP_TRY(det, hipMemcpy(&c, a.ctr + frame, sizeof c, hipMemcpyDeviceToHost));
     switch (what) {
-    case AGX_DBG_BLUR:
-    case AGX_DBG_RESP: {
+    case AGX_DBG_BLUR: {
         *n_items = plane;
         if (cap_bytes < plane * sizeof(float)) return AGX_ERR_CAPACITY;
-        const float *src = (what == AGX_DBG_BLUR ? a.blur : a.resp) + (size_t)frame * plane;
-        HIP_TRY(det, hipMemcpy(host_out, src, plane * sizeof(float), hipMemcpyDeviceToHost));
+        HIP_TRY(det, hipMemcpy(host_out, a.blur + (size_t)frame * plane, plane * sizeof(float), hipMemcpyDeviceToHost));
+        return AGX_OK;
+    }
+    case AGX_DBG_RESP: {
+        // the chain never stores the response; materialise it from the blur plane on demand
+        *n_items = plane;
+        if (cap_bytes < plane * sizeof(float)) return AGX_ERR_CAPACITY;
+        if (det->dbg_resp_plane < (long long)plane) {
+            if (det->d_dbg_resp) (void)hipFree(det->d_dbg_resp);
+            det->d_dbg_resp = nullptr;
+            det->dbg_resp_plane = 0;
+            HIP_TRY(det, hipMalloc((void **)&det->d_dbg_resp, plane * sizeof(float)));
+            det->dbg_resp_plane = (long long)plane;
+        }
+        hipError_t e = (hipError_t)launch_debug_resp(a, frame, det->d_dbg_resp, det->stream);
+        if (e != hipSuccess) return fail(det, AGX_ERR_HIP, std::string("k_debug_resp: ") + hipGetErrorString(e));
+        HIP_TRY(det, hipStreamSynchronize(det->stream));
+        HIP_TRY(det, hipMemcpy(host_out, det->d_dbg_resp, plane * sizeof(float), hipMemcpyDeviceToHost));
+        return AGX_OK;
+    }
+    case AGX_DBG_COUNTERS: {
+        // flags, seeds, second-tier seeds, clusters, generic candidates, generic roots, refined, out
+        *n_items = 8;
+        if (cap_bytes < 8 * sizeof(uint32_t)) return AGX_ERR_CAPACITY;
+        const uint32_t v[8] = {c.flags, c.n_seeds, c.n_big, c.n_clusters, c.n_cand, c.n_roots, c.n_refined, c.n_out};
+        std::memcpy(host_out, v, sizeof v);
         return AGX_OK;
     }
     case AGX_DBG_MIN: {
@@ -695,24 +839,21 @@ int agx_debug_fetch(agx_detector *det, int frame, int what, void *host_out, size
         return AGX_OK;
     }
     case AGX_DBG_CENTERS: {
-        const uint32_t n = std::min(c.n_roots, a.cap_roots);
+        const uint32_t n = std::min(c.n_clusters, a.cap_roots);
         *n_items = n;
         if (cap_bytes < (size_t)n * sizeof(agx_cluster_info)) return AGX_ERR_CAPACITY;
-        const uint32_t nc = std::min(c.n_cand, a.cap_cand);
-        std::vector<uint32_t> roots(n), sumx(nc), sumy(nc), cnt(nc), minidx(nc);
-        const size_t cb = (size_t)frame * a.cap_cand;
-        HIP_TRY(det, hipMemcpy(roots.data(), a.roots + (size_t)frame * a.cap_roots, n * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(det, hipMemcpy(sumx.data(), a.sumx + cb, (size_t)nc * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(det, hipMemcpy(sumy.data(), a.sumy + cb, (size_t)nc * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(det, hipMemcpy(cnt.data(), a.cnt + cb, (size_t)nc * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(det, hipMemcpy(minidx.data(), a.minidx + cb, (size_t)nc * 4, hipMemcpyDeviceToHost));
+        std::vector<uint32_t> key(n), cnt(n), sx(n), sy(n);
+        const size_t cb = (size_t)frame * a.cap_roots;
+        HIP_TRY(det, hipMemcpy(key.data(), a.clu_key + cb, (size_t)n * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(det, hipMemcpy(cnt.data(), a.clu_cnt + cb, (size_t)n * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(det, hipMemcpy(sx.data(), a.clu_sx + cb, (size_t)n * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(det, hipMemcpy(sy.data(), a.clu_sy + cb, (size_t)n * 4, hipMemcpyDeviceToHost));
         std::vector<agx_cluster_info> info(n);
         for (uint32_t i = 0; i < n; ++i) {
-            const uint32_t s = roots[i];
-            info[i].first_index = minidx[s];
-            info[i].size = cnt[s];
-            std::memcpy(&info[i].cx, &sumx[s], 4);  // K4 leaves the f32 centroid here
-            std::memcpy(&info[i].cy, &sumy[s], 4);
+            info[i].first_index = key[i];
+            info[i].size = cnt[i];
+            std::memcpy(&info[i].cx, &sx[i], 4);  // K4 leaves the f32 centroid here
+            std::memcpy(&info[i].cy, &sy[i], 4);
         }
         std::sort(info.begin(), info.end(),
                   [](const agx_cluster_info &p, const agx_cluster_info &q) { return p.first_index < q.first_index; });

@@ -187,6 +187,9 @@ class TagDetector:
         self._check(self._lib.agx_detector_set_stream(self._h, C.c_void_p(hip_stream_ptr or 0), 1 if external else 0))
         self._stream_ptr = hip_stream_ptr if external else "own"
 
+    def set_option(self, name, value):
+        self._check(self._lib.agx_detector_set_option(self._h, name.encode(), int(value)))
+
     def sync(self):
         self._check(self._lib.agx_detector_sync(self._h))
 
@@ -279,13 +282,15 @@ class TagDetector:
     def debug_fetch(self, frame, what, shape=None):
         """Intermediate product of the last batch: 'blur', 'resp' (HxW f32), 'min' (f32),
         'centers' (cluster table sorted by first pixel), 'refined' (unfiltered saddles)."""
-        code = {"blur": 0, "resp": 1, "min": 2, "centers": 3, "refined": 4}[what]
+        code = {"blur": 0, "resp": 1, "min": 2, "centers": 3, "refined": 4, "counters": 5}[what]
         n = C.c_size_t(0)
         if code in (0, 1):
             assert shape is not None
             buf = np.empty(shape, np.float32)
         elif code == 2:
             buf = np.empty(1, np.float32)
+        elif code == 5:
+            buf = np.empty(8, np.uint32)
         elif code == 3:
             buf = np.empty(1 << 20, _CLUSTER_DTYPE)
         else:
@@ -293,6 +298,9 @@ class TagDetector:
         self._check(self._lib.agx_debug_fetch(self._h, frame, code, buf.ctypes.data, buf.nbytes, C.byref(n)))
         if code == 2:
             return buf[0]
+        if code == 5:
+            return dict(zip(["flags", "seeds", "big_seeds", "clusters", "generic_candidates", "generic_roots",
+                             "refined", "saddles"], [int(v) for v in buf]))
         if code in (3, 4):
             return buf[: n.value].copy()
         return buf

@@ -148,6 +148,7 @@ def main():
     fence()
     tb = table.cpu().numpy()
     assert (tb[:, 2] & 7 == 0).all(), "capacity overflow in the bench workload: %s" % tb[tb[:, 2] != 0][:4]
+    generic_frames = int(((tb[:, 2] & 16) != 0).sum())
     saddles_per_frame = float(tb[:, 0].mean())
     clusters_per_frame = float(tb[:, 3].mean())
 
@@ -175,10 +176,11 @@ def main():
         in_b = IN_BYTES[args.format]
         k1_ms, k1_n = prof["k_blur_hessian"]
         k1_avg_ms = k1_ms / max(k1_n, 1)
-        k1_bytes = px_per_step_rank * (in_b + 8)  # read input, write blur f32 + response f32
+        k1_bytes = px_per_step_rank * (in_b + 4)  # K1 reads the input once and writes the blur plane (f32)
         k1_gbps = k1_bytes / (k1_avg_ms * 1e-3) / 1e9
         chain_ms = sum(v[0] for v in prof.values()) / max(k1_n, 1)
-        a_mat = in_b + 12  # input + blur write + response write + response re-read
+        a_mat = in_b + 12  # SURVEY.md 8(d) A_mat: input + blur write + response write + response re-read
+        a_design = in_b + 8 + 0.03125  # this design: input + blur write (K1) + blur read + 1 bit mask (K2)
         result = {
             "metric": "Mpix/s through the saddle chain (blur->threshold->gradient->saddle), frames resident in HBM",
             "value": round(mpix, 1),
@@ -212,7 +214,7 @@ def main():
                 "frac": round(k1_gbps / HBM_PEAK_GBPS, 4),
                 "frac_of_measured_copy_ceiling": round(k1_gbps / HBM_MEASURED_GBPS, 4),
                 "traffic": args.pmc_traffic,
-                "algorithmic_bytes_per_px": in_b + 8,
+                "algorithmic_bytes_per_px": in_b + 4,
                 "bytes_per_launch": k1_bytes,
                 "avg_launch_ms": round(k1_avg_ms, 5),
                 "launches_timed": k1_n,
@@ -223,6 +225,9 @@ def main():
                 "sum_kernel_ms_per_step": round(chain_ms, 5),
                 "a_mat_GBps": round(px_per_step_rank * a_mat / (chain_ms * 1e-3) / 1e9, 1),
                 "a_mat_frac_of_peak": round(px_per_step_rank * a_mat / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                "design_bytes_per_px": a_design,
+                "design_GBps": round(px_per_step_rank * a_design / (chain_ms * 1e-3) / 1e9, 1),
+                "frames_on_generic_path": generic_frames,
             },
         }
         if world == 1 and not args.no_cpu_baseline:

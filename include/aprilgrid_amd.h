@@ -98,10 +98,20 @@ int agx_detector_family_info(const agx_detector *det, int *edge_bits, int *borde
                              int *hamming_distance, const uint64_t **codes, int *n_codes);
 
 /* Internal list capacities per frame (0 = keep default).  Defaults scale with the frame:
- * candidates W*H/2, clusters W*H/16, saddles min(W*H/64, 16384).  Overflow of any of them
+ * candidates W*H/2, clusters W*H/8, saddles min(W*H/64, 16384).  Overflow of any of them
  * is reported as AGX_ERR_CAPACITY for that frame, never truncated. */
 int agx_detector_set_limits(agx_detector *det, uint32_t max_candidates, uint32_t max_clusters,
                             uint32_t max_saddles);
+
+/* Tuning / test switches (integers by name):
+ *   "force_generic"        1 = cluster every frame with the generic union-find kernels instead
+ *                          of the windowed flood fill (results are identical; test hook)
+ *   "k1_rows_per_segment"  rows one wave of the blur kernel walks (0 = automatic)
+ *   "streams"              HIP streams the chunks of a batch are pipelined over (default 1 =
+ *                          the whole chain in order on the detector's stream)
+ *   "chunk_frames"         frames per chunk (default: the whole batch)
+ *   "debug_ablation"       timing experiments only -- results are INVALID when non-zero */
+int agx_detector_set_option(agx_detector *det, const char *name, int value);
 
 /* Stream selection.  external != 0: launch on the caller's stream `hip_stream` (hipStream_t as
  * void*; NULL is HIP's legacy default stream) so that the chain is stream-ordered behind the
@@ -161,7 +171,9 @@ enum {
     AGX_FRAME_CANDIDATE_OVERFLOW = 1,
     AGX_FRAME_CLUSTER_OVERFLOW = 2,
     AGX_FRAME_SADDLE_OVERFLOW = 4,
-    AGX_FRAME_CENTROID_INEXACT = 8 /* informational: a cluster's coordinate sum reached 2^24 */
+    AGX_FRAME_CENTROID_INEXACT = 8, /* informational: a cluster's coordinate sum reached 2^24 */
+    AGX_FRAME_GENERIC_PATH = 16,    /* informational: clustered by the generic kernels         */
+    AGX_FRAME_DENSE_THRESHOLD = 32  /* informational: thresholded by the dense fallback kernel */
 };
 int agx_saddles_batch_enqueue_to(agx_detector *det, const void *d_frames, int n_frames, int width,
                                  int height, size_t row_stride_bytes, size_t frame_stride_bytes,
@@ -198,7 +210,9 @@ int agx_profile_read(agx_detector *det, const char **names, double *ms_total, ui
  * first_index), AGX_DBG_REFINED (unfiltered rochade_refine output, agx_saddle each, in
  * cluster order).  *n_items receives the element count; returns AGX_ERR_CAPACITY if
  * cap_bytes is too small. */
-enum { AGX_DBG_BLUR = 0, AGX_DBG_RESP = 1, AGX_DBG_MIN = 2, AGX_DBG_CENTERS = 3, AGX_DBG_REFINED = 4 };
+enum { AGX_DBG_BLUR = 0, AGX_DBG_RESP = 1, AGX_DBG_MIN = 2, AGX_DBG_CENTERS = 3, AGX_DBG_REFINED = 4,
+       AGX_DBG_COUNTERS = 5 /* 8 x uint32: status flags (AGX_FRAME_*), flood seeds, second-tier seeds,
+                               clusters, generic-path candidates, generic-path roots, refined, saddles */ };
 typedef struct agx_cluster_info {
     uint32_t first_index, size;
     float cx, cy;

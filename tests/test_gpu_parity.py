@@ -62,6 +62,10 @@ def test_fixture_images_chain(det, oracle, name):
     got = det.refined_saddle_points(img, as_array=True)
     ref = check_frame(det, oracle, img, 0, name)
     check_saddles(got, ref, name)
+    c = det.debug_fetch(0, "counters")
+    assert not (c["flags"] & 16) and c["generic_candidates"] == 0, c  # real frames stay on the flood path
+    if name in ("EuRoC.png", "TUM_VI.png", "two_boards.png"):
+        assert c["big_seeds"] > 0, c  # ... and these have components for the wave-wide second tier
 
 
 @pytest.mark.parametrize("name,expected", REFERENCE_TAG_COUNTS)
@@ -198,6 +202,47 @@ def test_noise_frames_many_clusters(det, oracle):
     for i in range(2):
         ref = check_frame(det, oracle, host[i], i, "noise frame %d" % i)
         check_saddles(res[i], ref, "noise %d" % i)
+
+
+@pytest.mark.parametrize("name", ["EuRoC.png", "r45.png", "two_boards.png"])
+def test_generic_cluster_path_equals_flood_path(oracle, name):
+    """The guarded union-find fallback must give exactly what the windowed flood fill gives."""
+    import aprilgrid_rs_amd as A
+    d = A.TagDetector("t36h11", None, device=0)
+    d.set_option("force_generic", 1)
+    img = load_image(name)
+    got = d.refined_saddle_points(img, as_array=True)
+    ref = check_frame(d, oracle, img, 0, name + " (generic path)")
+    check_saddles(got, ref, name + " (generic path)")
+    d.close()
+
+
+def test_oversized_components_take_second_tier_and_generic_path(det, oracle):
+    """Components larger than the 32x32 flood window go to the wave-wide 128x64 flood; larger
+    ones still (here sin*sin in 16 bit: diamonds of ~9000 px) send the frame to the generic
+    kernels.  Results must match the oracle in every case, and the neighbouring frame of the
+    batch stays on the fast path."""
+    import torch
+    h, w = 240, 320
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    om = 2 * np.pi / 150.0
+    big = (32768 + 25000 * np.sin(om * xx) * np.sin(om * yy)).astype(np.uint16)
+    om2 = 2 * np.pi / 64.0
+    mid = (32768 + 25000 * np.sin(om2 * xx) * np.sin(om2 * yy)).astype(np.uint16)  # ~30 px diamonds
+    synth = synth_module()
+    board, _ = synth.render_batch(3, 1, w, h, device="cpu", fmt="L16")
+    frames = np.stack([big, board[0].numpy().view(np.uint16), mid])
+    t = torch.from_numpy(frames.view(np.int16)).cuda()
+    det.saddles_batch_enqueue(t)
+    res, status = det.saddles_batch_fetch()
+    assert (status == 0).all()
+    for i in range(3):
+        ref = check_frame(det, oracle, frames[i], i, "frame %d" % i)
+        check_saddles(res[i], ref, "frame %d" % i)
+    c = [det.debug_fetch(i, "counters") for i in range(3)]
+    assert c[0]["flags"] & 16 and c[0]["generic_roots"] > 0, c[0]      # generic path
+    assert not (c[1]["flags"] & 16) and c[1]["generic_candidates"] == 0, c[1]  # fast path
+    assert c[2]["big_seeds"] > 0, c[2]                                 # second tier exercised
 
 
 def test_capacity_overflow_is_reported_not_truncated(oracle):
