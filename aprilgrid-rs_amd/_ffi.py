@@ -54,6 +54,8 @@ SYMBOLS = {
                                                _P, C.c_uint32, _P]),
     "agx_detect_from_saddles": (C.c_int, [_P, _P, C.c_uint32, _P, C.c_int, C.c_int, C.c_size_t, _P, C.c_uint32,
                                           C.POINTER(C.c_uint32)]),
+    "agx_detect_tail": (C.c_int, [C.c_int, C.POINTER(Params), _P, C.c_uint32, _P, C.c_int, C.c_int, C.c_size_t, _P,
+                                  C.c_uint32, C.POINTER(C.c_uint32)]),
     "agx_luma8": (C.c_int, [_P, C.c_int, C.c_int, C.c_size_t, C.c_int, _P]),
     "agx_profile_enable": (C.c_int, [_P, C.c_int]),
     "agx_profile_reset": (C.c_int, [_P]),

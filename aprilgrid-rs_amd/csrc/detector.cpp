@@ -716,6 +716,25 @@ int agx_detect_from_saddles(const agx_detector *det, const agx_saddle *saddles, 
     return AGX_OK;
 }
 
+int agx_detect_tail(int family, const agx_params *params, const agx_saddle *saddles, uint32_t n_saddles,
+                    const uint8_t *luma, int width, int height, size_t row_stride_bytes, agx_tag *out, uint32_t cap,
+                    uint32_t *n_out)
+{
+    if (!luma || !n_out || (!saddles && n_saddles) || (!out && cap) || width < 1 || height < 1) return AGX_ERR_ARG;
+    FamilyInfo fam;
+    if (!family_info(family, fam)) return AGX_ERR_FAMILY;
+    agx_params prm;
+    if (params) prm = *params;
+    else agx_default_params(&prm);
+    std::vector<agx_saddle> refined(saddles, saddles + n_saddles);
+    std::vector<agx_tag> tags;
+    detect_tail(fam, prm.max_num_of_boards, std::move(refined), luma, width, height, row_stride_bytes, tags);
+    *n_out = (uint32_t)tags.size();
+    if (tags.size() > cap) return AGX_ERR_CAPACITY;
+    if (!tags.empty()) std::memcpy(out, tags.data(), tags.size() * sizeof(agx_tag));
+    return AGX_OK;
+}
+
 int agx_detect(agx_detector *det, const void *pixels, int width, int height, size_t row_stride_bytes, int format,
                agx_tag *out, uint32_t cap, uint32_t *n_out)
 {

@@ -93,7 +93,7 @@ def main():
     import torch
     import torch.distributed as dist
     import aprilgrid_rs_amd as A
-    from aprilgrid_rs_amd import synth
+    from aprilgrid_rs_amd import synth, sharding
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -113,7 +113,8 @@ def main():
     # ---- synthetic workload: frames [rank*F, rank*F + F) of the seeded generator, rendered
     # straight into HBM; `unique` distinct frames tiled (rendering is outside the timed region)
     uniq = max(1, min(args.unique, F))
-    base, gts = synth.render_batch(rank * F, uniq, W, H, device=dev, fmt=args.format, pure_noise=args.noise)
+    first_frame, _ = sharding.shard_range(rank, world, F)
+    base, gts = synth.render_batch(first_frame, uniq, W, H, device=dev, fmt=args.format, pure_noise=args.noise)
     reps = (F + uniq - 1) // uniq
     frames = base.repeat((reps,) + (1,) * (base.dim() - 1))[:F].contiguous()
     del base
@@ -123,19 +124,13 @@ def main():
     stream = torch.cuda.current_stream(dev)
     det.set_stream(stream.cuda_stream)  # kernels, events and the RCCL gather share torch's stream order
 
-    SLAB = 1024  # saddle records per frame in the result slab (20 KB / frame)
-    out_saddles = torch.zeros((F * SLAB, 5), dtype=torch.float32, device=dev)
-    table = torch.zeros((F, 4), dtype=torch.int32, device=dev)
-    if world > 1 and rank == 0:
-        g_saddles = [torch.empty_like(out_saddles) for _ in range(world)]
-        g_tables = [torch.empty_like(table) for _ in range(world)]
+    out_saddles, table = sharding.alloc_result_buffers(F, dev)
 
     def step():
         det.saddles_batch_enqueue_to(frames, out_saddles, table)
         if world > 1:
             # the one collective of the path: result gather to rank 0 (RCCL over xGMI)
-            dist.gather(table, g_tables if rank == 0 else None, dst=0)
-            dist.gather(out_saddles, g_saddles if rank == 0 else None, dst=0)
+            sharding.gather_results(out_saddles, table, dst=0)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -176,11 +171,13 @@ def main():
         in_b = IN_BYTES[args.format]
         k1_ms, k1_n = prof["k_blur_hessian"]
         k1_avg_ms = k1_ms / max(k1_n, 1)
-        k1_bytes = px_per_step_rank * (in_b + 4)  # K1 reads the input once and writes the blur plane (f32)
+        # K1 reads the input once, writes the blur plane (f32) and 1 bit / px of candidate mask
+        k1_bytes = px_per_step_rank * (in_b + 4 + 0.125)
         k1_gbps = k1_bytes / (k1_avg_ms * 1e-3) / 1e9
         chain_ms = sum(v[0] for v in prof.values()) / max(k1_n, 1)
         a_mat = in_b + 12  # SURVEY.md 8(d) A_mat: input + blur write + response write + response re-read
-        a_design = in_b + 8 + 0.03125  # this design: input + blur write (K1) + blur read + 1 bit mask (K2)
+        a_design = in_b + 4 + 0.125 + 0.125  # this design: input + blur write + mask write (K1) + mask read (K2);
+        # the sparse stages (verify / refine gathers at ~2.4 % of the pixels, lists) add < 0.5 B/px
         result = {
             "metric": "Mpix/s through the saddle chain (blur->threshold->gradient->saddle), frames resident in HBM",
             "value": round(mpix, 1),
@@ -214,7 +211,7 @@ def main():
                 "frac": round(k1_gbps / HBM_PEAK_GBPS, 4),
                 "frac_of_measured_copy_ceiling": round(k1_gbps / HBM_MEASURED_GBPS, 4),
                 "traffic": args.pmc_traffic,
-                "algorithmic_bytes_per_px": in_b + 4,
+                "algorithmic_bytes_per_px": in_b + 4.125,
                 "bytes_per_launch": k1_bytes,
                 "avg_launch_ms": round(k1_avg_ms, 5),
                 "launches_timed": k1_n,

@@ -190,6 +190,12 @@ int agx_detect_from_saddles(const agx_detector *det, const agx_saddle *saddles, 
                             const uint8_t *luma8, int width, int height, size_t row_stride_bytes,
                             agx_tag *out, uint32_t cap, uint32_t *n_out);
 
+/* The same host tail without a detector handle (no device needed): family and params as in
+ * agx_detector_create (params may be NULL). */
+int agx_detect_tail(int family, const agx_params *params, const agx_saddle *saddles, uint32_t n_saddles,
+                    const uint8_t *luma8, int width, int height, size_t row_stride_bytes, agx_tag *out,
+                    uint32_t cap, uint32_t *n_out);
+
 /* to_luma8 (src/detector.rs:507) of a host image into a tightly packed host plane. */
 int agx_luma8(const void *pixels, int width, int height, size_t row_stride_bytes, int format,
               uint8_t *out);

@@ -1,0 +1,137 @@
+"""The C-ABI library without a GPU: it loads, exports every symbol include/aprilgrid_amd.h
+declares, mirrors the reference's constructor-level behaviour, refuses to work without a
+device (no CPU fallback), and its host tail agrees with the oracle's."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from tests.util import ROOT, bits_equal, load_image, synth_module
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from aprilgrid_rs_amd import _ffi
+    return _ffi.lib()
+
+
+def declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "aprilgrid_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(agx_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    from aprilgrid_rs_amd import _ffi
+    names = declared_symbols()
+    assert len(names) >= 24
+    for n in names:
+        assert hasattr(lib, n), "library does not export %s" % n
+    assert sorted(_ffi.SYMBOLS) == names, "ctypes table and header disagree"
+    assert lib.agx_abi_version() == 1
+
+
+def test_family_from_str_like_the_reference(lib):
+    """src/tag_families.rs:661-685: lower and upper case accepted, 'invalid' rejected."""
+    import aprilgrid_rs_amd as A
+    assert A.TagFamily.from_str("t36h11") == A.TagFamily.T36H11 == A.TagFamily.from_str("T36H11")
+    assert A.TagFamily.from_str("t16h5") == A.TagFamily.T16H5
+    assert A.TagFamily.from_str("T36H11B1") == A.TagFamily.T36H11B1
+    with pytest.raises(ValueError):
+        A.TagFamily.from_str("invalid")
+
+
+def test_default_params(lib):
+    import aprilgrid_rs_amd as A
+    p = A.DetectorParams.default_params()
+    assert (p.min_saddle_angle, p.max_saddle_angle, p.max_num_of_boards) == (30.0, 60.0, 2)
+    assert abs(p.tag_spacing_ratio - 0.3) < 1e-6
+
+
+def test_no_device_means_no_results(lib):
+    """There is no CPU fallback: without a gfx950 device the constructor fails loudly."""
+    import torch
+    import aprilgrid_rs_amd as A
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(A.AgxError) as e:
+        A.TagDetector(A.TagFamily.T36H11)
+    assert e.value.status == -5
+
+
+def test_constants_equal_the_oracles(lib):
+    from oracle import oracle as O
+    w = np.zeros(7, np.float32)
+    cone = np.zeros(25, np.float32)
+    pm = np.zeros((25, 6), np.float32)
+    assert lib.agx_detector_constants(None, w.ctypes.data, cone.ctypes.data, pm.ctypes.data) == 0
+    op, ok = O.refine_constants(2)
+    assert bits_equal(w, O.blur_weights(1.5)) and bits_equal(cone, ok) and bits_equal(pm, op)
+
+
+def test_luma8_matches_oracle(lib):
+    import aprilgrid_rs_amd as A
+    from oracle import oracle as O
+    rng = np.random.default_rng(3)
+    for img in (rng.integers(0, 256, (9, 13), dtype=np.uint8), rng.integers(0, 65536, (9, 13), dtype=np.uint16),
+                rng.integers(0, 256, (9, 13, 3), dtype=np.uint8)):
+        assert np.array_equal(A.TagDetector.luma8(img), O.luma_u8(img))
+
+
+@pytest.mark.parametrize("name", ["EuRoC.png", "TUM_VI.png", "r45.png", "two_boards.png", "iphone.png"])
+def test_host_tail_matches_oracle_tail_on_fixtures(name):
+    """Board search + decode (host C++, aprilgrid-rs_amd/csrc/host_tail.cpp) against the oracle's
+    tail, both fed the oracle's saddles: identical ids, bit-identical corners, and the reference's
+    tag count (tests/test_detector.rs:26-32)."""
+    import aprilgrid_rs_amd as A
+    from oracle import oracle as O
+    from tests.util import REFERENCE_TAG_COUNTS
+    img = load_image(name)
+    saddles = O.refined_saddle_points(img)
+    grey = O.luma_u8(img)
+    got = A.TagDetector.detect_tail("t36h11", saddles, grey)
+    ref = O.detect_tail(grey, saddles)
+    assert sorted(got) == sorted(ref)
+    assert len(got) == dict(REFERENCE_TAG_COUNTS)[name]
+    for tid in ref:
+        assert bits_equal(got[tid], ref[tid])
+
+
+def test_host_tail_matches_oracle_tail_on_synthetic_and_other_families():
+    import aprilgrid_rs_amd as A
+    from oracle import oracle as O
+    synth = synth_module()
+    for i in range(4):
+        frame, gt = synth.render_frame(20 + i, 640, 400)
+        img = frame.numpy()
+        saddles = O.refined_saddle_points(img)
+        got = A.TagDetector.detect_tail(A.TagFamily.T36H11, saddles, img)
+        ref = O.detect_tail(img, saddles)
+        assert sorted(got) == sorted(ref) and len(got) >= 30
+        for tid in ref:
+            assert bits_equal(got[tid], ref[tid])
+    # a family that does not match the drawn tags decodes (almost) nothing, identically
+    for fam in ("T16H5", "T25H9", "T36H11B1"):
+        got = A.TagDetector.detect_tail(fam, saddles, img)
+        ref = O.detect_tail(img, saddles, family=fam)
+        assert sorted(got) == sorted(ref)
+    # max_num_of_boards = 1 vs 2 on the two-board fixture
+    two = load_image("two_boards.png")
+    s2, g2 = O.refined_saddle_points(two), O.luma_u8(two)
+    p1 = A.DetectorParams(0.3, 30.0, 60.0, 1)
+    op = O.default_params(); op.max_num_of_boards = 1
+    a1 = A.TagDetector.detect_tail("t36h11", s2, g2, p1)
+    assert sorted(a1) == sorted(O.detect_tail(g2, s2, params=op)) and 30 <= len(a1) <= 36
+    assert A.TagDetector.detect_tail("t36h11", s2[:0], g2) == {}
+
+
+def test_host_tail_library_entry_points_via_cpu_handle(lib):
+    """The host tail itself is CPU code; exercise it here through the exported helpers that do
+    not need a handle."""
+    assert lib.agx_luma8(None, 4, 4, 4, 0, None) == -1
+    fam = C.c_int(-1)
+    assert lib.agx_family_from_str(b"t25h9", C.byref(fam)) == 0 and fam.value == 2
+    assert lib.agx_family_from_str(b"nope", C.byref(fam)) == -6
+    assert lib.agx_status_string(-3) == b"capacity exceeded"
