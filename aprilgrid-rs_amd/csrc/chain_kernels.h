@@ -73,6 +73,7 @@ struct ChainArgs {
     float w[7];  // blur taps
     // dense planes [n_frames][H][W]
     float *blur;
+    float *dummy;          // one row (W + 8 floats): target of K1's out-of-segment stores
     uint32_t *slot_plane;  // generic path only (sparse-touched)
     // Candidate bit mask, TRANSPOSED: one word = 32 consecutive rows of one column.
     // mask[frame][yb][MASK_PAD_X + x] holds rows 32*yb .. 32*yb+31 of column x (bit = row & 31).

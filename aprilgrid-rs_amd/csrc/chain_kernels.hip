@@ -83,11 +83,20 @@ struct RawPx {
     uint32_t d[BPP];
 };
 
-template <int FMT>
+template <int FMT, bool A4>
 __device__ __forceinline__ RawPx<FMT> load_raw(const uint8_t *__restrict__ rowp, int c0, int W)
 {
     constexpr int BPP = RawPx<FMT>::BPP;
     RawPx<FMT> r;
+    if (FMT == 0 && A4) {  // A4: W is a multiple of 4
+        // always exactly one dword load: lanes left / right of the image read the first / last
+        // dword of the row and replicate its edge pixel (clamp-to-edge)
+        const int cc = c0 < 0 ? 0 : (c0 > W - 4 ? W - 4 : c0);
+        const uint32_t d = *reinterpret_cast<const uint32_t *>(rowp + cc);
+        const uint32_t first = (d & 0xffu) * 0x01010101u, last = (d >> 24) * 0x01010101u;
+        r.d[0] = c0 < 0 ? first : (c0 >= W ? last : d);
+        return r;
+    }
     if (c0 >= 0 && c0 + 3 < W) {
         const uint32_t *p = reinterpret_cast<const uint32_t *>(rowp + (size_t)c0 * BPP);
 #pragma unroll
@@ -147,7 +156,7 @@ __device__ __forceinline__ void convert_px(const RawPx<FMT> &r, float m[4])
 // stores the blur row, and evaluates the Hessian determinant of the previous row (its left /
 // right blur neighbours again by DPP) for the per-frame minimum.  No LDS, no barriers.
 // ------------------------------------------------------------------------------------------
-template <int FMT>
+template <int FMT, bool A4>
 __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
 {
     const int lane = threadIdx.x & 63;
@@ -167,8 +176,6 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
 
     const uint8_t *fbase = a.frames + (size_t)frame * (size_t)a.frame_stride;
     float *blur_f = a.blur + (size_t)frame * (size_t)a.plane;
-    const bool vec_ok = ((W & 3) == 0) && (c0 + 3 < W);
-
     const float w0 = a.w[0], w1 = a.w[1], w2 = a.w[2], w3 = a.w[3], w4 = a.w[4], w5 = a.w[5],
                 w6 = a.w[6];
 
@@ -195,6 +202,7 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
     uint32_t *mask_f = a.mask + (size_t)frame * (size_t)a.mask_plane;
     float thr_run = 0.0f, published = 0.0f;
     int rows_to_sync = 0, sync_gap = 1;
+    uint32_t polled = 0u;  // ctr.min_key_inv as fetched at the previous sync point
     uint32_t mw[4] = {0u, 0u, 0u, 0u};  // this lane's 4 mask words (4 columns x 32 rows) in progress
 
     // per-pixel "takes part in the min" (interior column of this lane's strip)
@@ -208,23 +216,55 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
         int rr = r < 0 ? 0 : (r > H - 1 ? H - 1 : r);
         return fbase + (size_t)rr * (size_t)a.row_stride;
     };
-    RawPx<FMT> raw_a = load_raw<FMT>(rowptr(r0), c0, W);
-    RawPx<FMT> raw_b = load_raw<FMT>(rowptr(r0 + 1), c0, W);
-    RawPx<FMT> raw_c = load_raw<FMT>(rowptr(r0 + 2), c0, W);
-    RawPx<FMT> raw_d = load_raw<FMT>(rowptr(r0 + 3), c0, W);
+    // Input prefetch.  L8 frames with W % 4 == 0 (FAST): the 7 input dwords of a 7-row body are
+    // loaded together one body ahead.  At the top of a body they are copied into working
+    // registers -- the only place the wave waits for memory -- and the next body's 7 loads are
+    // issued at once.  gfx9 counts loads and stores in one in-order vmcnt and the compiler waits
+    // with vmcnt(0) here, i.e. it also drains the blur stores issued so far; batching makes that
+    // happen once per 7 rows, on loads that are a whole body old, instead of before every row.
+    constexpr bool FAST = (FMT == 0) && A4;
+    uint32_t ring[7];
+    RawPx<FMT> raw_a, raw_b, raw_c, raw_d;
+    const int cc = c0 < 0 ? 0 : (c0 > W - 4 ? W - 4 : c0);  // FAST: clamped column of this lane's dword
+    auto issue_load = [&](int r) -> uint32_t { return *reinterpret_cast<const uint32_t *>(rowptr(r) + cc); };
+    if (FAST) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) ring[k] = issue_load(r0 + k);
+    } else {
+        raw_a = load_raw<FMT, A4>(rowptr(r0), c0, W);
+        raw_b = load_raw<FMT, A4>(rowptr(r0 + 1), c0, W);
+        raw_c = load_raw<FMT, A4>(rowptr(r0 + 2), c0, W);
+        raw_d = load_raw<FMT, A4>(rowptr(r0 + 3), c0, W);
+    }
 
 #pragma unroll 1
     for (int rbase = r0; rbase <= r1; rbase += 7) {
+        uint32_t cur[7];
+        if (FAST) {
+#pragma unroll
+            for (int k = 0; k < 7; ++k) cur[k] = ring[k];
+#pragma unroll
+            for (int k = 0; k < 7; ++k) ring[k] = issue_load(rbase + 7 + k);  // rows past the end clamp to H-1
+        }
 #pragma unroll
         for (int k = 0; k < 7; ++k) {
             const int r = rbase + k;
             if (r > r1) break;  // wave-uniform
             float m[4];
-            convert_px<FMT>(raw_a, m);
-            raw_a = raw_b;
-            raw_b = raw_c;
-            raw_c = raw_d;
-            if (r + 4 <= r1) raw_d = load_raw<FMT>(rowptr(r + 4), c0, W);
+            if (FAST) {
+                const uint32_t d = cur[k];
+                // lanes left / right of the image replicate the edge pixel (clamp-to-edge)
+                const uint32_t first = (d & 0xffu) * 0x01010101u, last = (d >> 24) * 0x01010101u;
+                RawPx<FMT> rp;
+                rp.d[0] = c0 < 0 ? first : (c0 >= W ? last : d);
+                convert_px<FMT>(rp, m);
+            } else {
+                convert_px<FMT>(raw_a, m);
+                raw_a = raw_b;
+                raw_b = raw_c;
+                raw_c = raw_d;
+                raw_d = load_raw<FMT, A4>(rowptr(r + 4), c0, W);
+            }
 
             // horizontal pass, image_util.rs:137-185: taps in index order, mul then add
             const float x[10] = {from_left(m[1]), from_left(m[2]), from_left(m[3]), m[0], m[1], m[2], m[3],
@@ -250,9 +290,12 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
                 acc[(k + 6) % 7][j] = p0;                            // tap 0 of row r+3 (free slot)
             }
             const int b = r - 3;
-            if (store_ok && b >= ys && b < ye) {
-                float *dst = blur_f + (size_t)((a.dbg & 8) ? (b & 7) : b) * W + c0;  // dbg 8: L2-resident target
-                if (vec_ok) {
+            // the store is issued for every row (rows outside the segment go to a dummy row) so
+            // that the number of memory operations per row is fixed and the compiler can wait
+            // with a counted vmcnt(N) instead of draining the stores before every row
+            if (store_ok) {
+                float *dst = (b >= ys && b < ye) ? blur_f + (size_t)((a.dbg & 8) ? (b & 7) : b) * W + c0 : a.dummy + c0;
+                if (A4) {  // valid lanes hold 4 in-image pixels
                     *reinterpret_cast<float4 *>(dst) = make_float4(bc[0], bc[1], bc[2], bc[3]);
                 } else {
 #pragma unroll
@@ -280,20 +323,23 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
                         run_min = fminf(run_min, d);
                         dv[j] = d;
                     }
-                    // refresh the running threshold with exponential back-off (rows 0,1,2,4,8,..)
+                    // refresh the running threshold with exponential back-off (rows 0,1,5,21,85,..).
+                    // The poll of the frame's published minimum is asynchronous: a sync point uses
+                    // the value fetched at the previous one and issues the next fetch without
+                    // waiting for it (a staler threshold is only a slightly larger superset).
                     if (rows_to_sync <= 0 && !(a.dbg & 16)) {
                         float wmin = run_min;
 #pragma unroll
                         for (int off = 32; off > 0; off >>= 1) wmin = fminf(wmin, __shfl_xor(wmin, off, 64));
-                        if (wmin < published) {
+                        if (wmin < published * 1.125f || (published == 0.0f && wmin < 0.0f)) {  // >12 % better
                             if (lane == 0) atomicMax(&ctr.min_key_inv, ~f32_order_key(wmin));
                             published = wmin;
                         }
-                        const uint32_t gk = __hip_atomic_load(&ctr.min_key_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const float gmin = gk ? f32_from_order_key(~gk) : 0.0f;  // 0 = nothing published yet
+                        const float gmin = polled ? f32_from_order_key(~polled) : 0.0f;  // 0 = nothing seen yet
                         thr_run = fminf(wmin, gmin) * 0.05f;
+                        polled = __hip_atomic_load(&ctr.min_key_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         rows_to_sync = sync_gap;
-                        sync_gap = min(sync_gap * 2, 32);
+                        sync_gap = min(sync_gap * 4, 128);
                     }
                     --rows_to_sync;
                     const int sh = y & 31;
@@ -303,7 +349,7 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
                 if ((y & 31) == 31 || y == ye - 1) {  // word row complete (segments are 32-row aligned)
                     if (lane_valid) {
                         uint32_t *dst = mask_f + (size_t)(y >> 5) * a.mask_wpr + MASK_PAD_X + c0;
-                        if (c0 + 3 < W) {
+                        if (A4) {
                             *reinterpret_cast<uint4 *>(dst) = make_uint4(mw[0], mw[1], mw[2], mw[3]);
                         } else {
 #pragma unroll
@@ -990,7 +1036,7 @@ bool plan_k1(ChainArgs &a, int override_rows_per_seg)
     // enough that the 8 warm-up rows stay a small fraction
     int rps = override_rows_per_seg > 0 ? override_rows_per_seg : env_int("AGX_K1_ROWS", 0);
     if (rps <= 0) {
-        const long long target_waves = 24576;
+        const long long target_waves = 10240;
         long long segs = (target_waves + (long long)a.n_frames * n_strips - 1) / ((long long)a.n_frames * n_strips);
         if (segs < 1) segs = 1;
         rps = (int)((H + segs - 1) / segs);
@@ -1016,7 +1062,8 @@ static hipError_t launch_k1(const ChainArgs &a, hipStream_t st)
 {
     const int units = a.n_strips * a.n_segs;
     dim3 grid((units + 3) / 4, a.n_frames), block(256);
-    hipLaunchKernelGGL((k_blur_hessian<FMT>), grid, block, 0, st, a);
+    if ((a.W & 3) == 0) hipLaunchKernelGGL((k_blur_hessian<FMT, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((k_blur_hessian<FMT, false>), grid, block, 0, st, a);
     return hipGetLastError();
 }
 

@@ -238,6 +238,7 @@ int ensure_workspace(agx_detector *d, int n_frames, int W, int H)
     int rc;
     const size_t mask_plane = mask_words_per_frame(W, H);
     if ((rc = dev_alloc(d, a.blur, F * plane + 16))) return rc;  // +16: aligned window loads may touch 3 floats past the end
+    if ((rc = dev_alloc(d, a.dummy, (size_t)1 << 16))) return rc;  // any W < 65520
     if ((rc = dev_alloc(d, a.slot_plane, F * plane))) return rc;
     if ((rc = dev_alloc(d, a.mask, F * mask_plane))) return rc;
     d->mask_words = F * mask_plane;
@@ -562,7 +563,7 @@ static int batch_enqueue_impl(agx_detector *det, const void *d_frames, int n_fra
     if (!det || !d_frames || n_frames <= 0) return fail(det, AGX_ERR_ARG, "null frames or n_frames <= 0");
     if (!valid_format(format)) return fail(det, AGX_ERR_FORMAT, "format must be AGX_L8, AGX_L16 or AGX_RGB8");
     if (width < 2 || height < 2) return fail(det, AGX_ERR_ARG, "width and height must be >= 2");
-    if ((long long)width * height >= (1ll << 30)) return fail(det, AGX_ERR_ARG, "frame too large (>= 2^30 px)");
+    if ((long long)width * height >= (1ll << 30) || width > 65000) return fail(det, AGX_ERR_ARG, "frame too large (>= 2^30 px or wider than 65000)");
     if (row_stride_bytes < (size_t)width * bytes_per_px(format) || (row_stride_bytes & 3) ||
         ((uintptr_t)d_frames & 3) || (frame_stride_bytes & 3) ||
         (n_frames > 1 && frame_stride_bytes < row_stride_bytes * (size_t)height))
