@@ -74,6 +74,9 @@ struct ChainArgs {
     // dense planes [n_frames][H][W]
     float *blur;
     float *dummy;          // one row (W + 8 floats): target of K1's out-of-segment stores
+    // weakest (largest) response among the candidates K1 admitted, per 4 columns x 32 rows:
+    // [n_frames][mask_yb][mask_wpr / 4] (same indexing as the mask, x/4); -inf where none
+    float *cand_max;
     uint32_t *slot_plane;  // generic path only (sparse-touched)
     // Candidate bit mask, TRANSPOSED: one word = 32 consecutive rows of one column.
     // mask[frame][yb][MASK_PAD_X + x] holds rows 32*yb .. 32*yb+31 of column x (bit = row & 31).

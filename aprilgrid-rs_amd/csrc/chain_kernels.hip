@@ -203,6 +203,7 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
     float thr_run = 0.0f, published = 0.0f;
     int rows_to_sync = 0, sync_gap = 1;
     uint32_t polled = 0u;  // ctr.min_key_inv as fetched at the previous sync point
+    float cmax = -__builtin_inff();  // weakest candidate response of this lane in the current 32-row block
     uint32_t mw[4] = {0u, 0u, 0u, 0u};  // this lane's 4 mask words (4 columns x 32 rows) in progress
 
     // per-pixel "takes part in the min" (interior column of this lane's strip)
@@ -344,10 +345,15 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
                     --rows_to_sync;
                     const int sh = y & 31;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) mw[j] |= (dv[j] < thr_run) ? (1u << sh) : 0u;
+                    for (int j = 0; j < 4; ++j) {
+                        const bool cj = dv[j] < thr_run;
+                        mw[j] |= cj ? (1u << sh) : 0u;
+                        cmax = fmaxf(cmax, cj ? dv[j] : -__builtin_inff());
+                    }
                 }
                 if ((y & 31) == 31 || y == ye - 1) {  // word row complete (segments are 32-row aligned)
                     if (lane_valid) {
+                        a.cand_max[((size_t)frame * a.mask_yb + (y >> 5)) * (a.mask_wpr >> 2) + ((MASK_PAD_X + c0) >> 2)] = cmax;
                         uint32_t *dst = mask_f + (size_t)(y >> 5) * a.mask_wpr + MASK_PAD_X + c0;
                         if (A4) {
                             *reinterpret_cast<uint4 *>(dst) = make_uint4(mw[0], mw[1], mw[2], mw[3]);
@@ -358,6 +364,7 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
                         }
                     }
                     mw[0] = mw[1] = mw[2] = mw[3] = 0u;
+                    cmax = -__builtin_inff();
                 }
             }
 #pragma unroll
@@ -393,6 +400,9 @@ __global__ void __launch_bounds__(256) k_verify(ChainArgs a)
         uint32_t *wp = mask + (size_t)yb * a.mask_wpr + MASK_PAD_X + x;
         const uint32_t m0 = *wp;
         if (!m0) continue;
+        // every candidate K1 admitted in this word's 4-column x 32-row block is <= cand_max: if that
+        // is below the final threshold they all pass and nothing needs recomputing
+        if (a.cand_max[((size_t)frame * a.mask_yb + yb) * (a.mask_wpr >> 2) + ((MASK_PAD_X + x) >> 2)] < thr) continue;
         uint32_t m = m0, keep = m0;
         while (m) {
             const int b = __ffs(m) - 1;
@@ -412,27 +422,37 @@ __global__ void __launch_bounds__(256) k_verify(ChainArgs a)
     }
 }
 
-// Flood seeds = candidates with no candidate to the left and none above, from the mask.
+// Flood seeds = candidates with no candidate to the left and none above, from the mask; one
+// thread per 4 mask words (16-byte loads).
 __global__ void __launch_bounds__(256) k_seeds(ChainArgs a)
 {
     const int frame = blockIdx.y;
     FrameCounters &ctr = a.ctr[frame];
     const uint32_t *mask = a.mask + (size_t)frame * (size_t)a.mask_plane;
-    const int W = a.W, wpr = a.mask_wpr;
-    const int total = ((a.H + 31) >> 5) * W;
+    const int W = a.W, wpr = a.mask_wpr, W4 = (W + 3) >> 2;
+    const int total = ((a.H + 31) >> 5) * W4;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const int yb = i / W, x = i - yb * W;
-        const uint32_t *wp = mask + (size_t)yb * wpr + MASK_PAD_X + x;
-        const uint32_t m = wp[0];
-        if (!m) continue;
-        const uint32_t upm = (m << 1) | (yb > 0 ? (wp[-wpr] >> 31) : 0u);
-        uint32_t sd = m & ~wp[-1] & ~upm;
-        while (sd) {
-            const int b = __ffs(sd) - 1;
-            sd &= sd - 1;
-            const uint32_t o = atomicAdd(&ctr.n_seeds, 1u);
-            if (o < a.cap_roots) a.seeds[(size_t)frame * a.cap_roots + o] = (uint32_t)(yb * 32 + b) * (uint32_t)W + (uint32_t)x;
-            else atomicOr(&ctr.flags, FLAG_CAND_OVERFLOW);
+        const int yb = i / W4, x = (i - yb * W4) * 4;
+        const uint32_t *wp = mask + (size_t)yb * wpr + MASK_PAD_X + x;  // 16-byte aligned
+        const uint4 m4 = *reinterpret_cast<const uint4 *>(wp);          // words past W are zero padding
+        if (!(m4.x | m4.y | m4.z | m4.w)) continue;
+        const uint4 u4 = yb > 0 ? *reinterpret_cast<const uint4 *>(wp - wpr) : make_uint4(0u, 0u, 0u, 0u);
+        const uint32_t mm[4] = {m4.x, m4.y, m4.z, m4.w};
+        const uint32_t uu[4] = {u4.x, u4.y, u4.z, u4.w};
+        uint32_t left = wp[-1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t m = mm[j];
+            uint32_t sd = m & ~left & ~((m << 1) | (uu[j] >> 31));
+            left = m;
+            while (sd) {
+                const int b = __ffs(sd) - 1;
+                sd &= sd - 1;
+                const uint32_t o = atomicAdd(&ctr.n_seeds, 1u);
+                if (o < a.cap_roots)
+                    a.seeds[(size_t)frame * a.cap_roots + o] = (uint32_t)(yb * 32 + b) * (uint32_t)W + (uint32_t)(x + j);
+                else atomicOr(&ctr.flags, FLAG_CAND_OVERFLOW);
+            }
         }
     }
 }
@@ -1085,13 +1105,13 @@ int launch_kernel(int which, const ChainArgs &a, const RefineConsts &rc, void *s
         if (a.fmt == 1) return launch_k1<1>(a, st);
         return launch_k1<2>(a, st);
     case K_THRESHOLD: {
-        dim3 grid(sparse_grid_x(a, 32), a.n_frames), block(256);
+        dim3 grid(sparse_grid_x(a, 32), a.n_frames), grid4(sparse_grid_x(a, 16), a.n_frames), block(256);
         hipLaunchKernelGGL(k_verify, grid, block, 0, st, a);
-        hipLaunchKernelGGL(k_seeds, grid, block, 0, st, a);
+        hipLaunchKernelGGL(k_seeds, grid4, block, 0, st, a);
         return hipGetLastError();
     }
     case K_FLOOD: {
-        dim3 grid(sparse_grid_x(a, 16), a.n_frames), block(64);
+        dim3 grid(sparse_grid_x(a, 48), a.n_frames), block(64);
         hipLaunchKernelGGL(k_flood, grid, block, 0, st, a);
         dim3 grid2(sparse_grid_x(a, 4), a.n_frames), block2(128);
         hipLaunchKernelGGL(k_flood_block, grid2, block2, 0, st, a);

@@ -239,6 +239,7 @@ int ensure_workspace(agx_detector *d, int n_frames, int W, int H)
     const size_t mask_plane = mask_words_per_frame(W, H);
     if ((rc = dev_alloc(d, a.blur, F * plane + 16))) return rc;  // +16: aligned window loads may touch 3 floats past the end
     if ((rc = dev_alloc(d, a.dummy, (size_t)1 << 16))) return rc;  // any W < 65520
+    if ((rc = dev_alloc(d, a.cand_max, F * mask_plane / 4 + 16))) return rc;
     if ((rc = dev_alloc(d, a.slot_plane, F * plane))) return rc;
     if ((rc = dev_alloc(d, a.mask, F * mask_plane))) return rc;
     d->mask_words = F * mask_plane;
@@ -309,6 +310,7 @@ int enqueue_chunk(agx_detector *d, int f0, int nf, hipStream_t st)
     a.frames += F0 * (size_t)a.frame_stride;
     a.blur += F0 * (size_t)a.plane;
     a.slot_plane += F0 * (size_t)a.plane;
+    a.cand_max += F0 * (size_t)(a.mask_plane / 4);
     a.mask += F0 * (size_t)a.mask_plane;
     a.ctr += F0;
     a.seeds += F0 * a.cap_roots;
