@@ -75,7 +75,7 @@ struct agx_detector {
     bool external_out = false;       // last batch wrote into caller-owned device memory
 
     bool enqueued = false;
-    bool profiling = false;
+    int profiling = 0;  // 0 off, 1 = K1 only, 2 = every kernel
     std::vector<EventPair> pending_events;
     std::vector<hipEvent_t> free_events;
     double prof_ms[K_COUNT]{};
@@ -243,8 +243,8 @@ int ensure_workspace(agx_detector *d, int n_frames, int W, int H)
     if ((rc = dev_alloc(d, a.slot_plane, F * plane))) return rc;
     if ((rc = dev_alloc(d, a.mask, F * mask_plane))) return rc;
     d->mask_words = F * mask_plane;
-    if ((rc = dev_alloc(d, a.ctr, F))) return rc;
-    if ((rc = dev_alloc(d, a.total_out, 1))) return rc;
+    if ((rc = dev_alloc(d, a.ctr, F + 1))) return rc;  // + one extra record: its first word is total_out
+    a.total_out = &a.ctr[F].min_key_inv;
     if ((rc = dev_alloc(d, a.seeds, F * cap_roots))) return rc;
     if ((rc = dev_alloc(d, a.big_seeds, F * cap_roots))) return rc;
     if ((rc = dev_alloc(d, a.clu_key, F * cap_roots))) return rc;
@@ -330,7 +330,8 @@ int enqueue_chunk(agx_detector *d, int f0, int nf, hipStream_t st)
     if (a.frame_table) a.frame_table += F0 * 4;
     for (int k = 0; k < K_COUNT; ++k) {
         EventPair ev{nullptr, nullptr, k};
-        if (d->profiling) {
+        const bool timed = d->profiling >= 2 || (d->profiling == 1 && k == K_BLUR_HESSIAN);
+        if (timed) {
             ev.a = get_event(d);
             ev.b = get_event(d);
             HIP_TRY(d, hipEventRecord(ev.a, st));
@@ -338,7 +339,7 @@ int enqueue_chunk(agx_detector *d, int f0, int nf, hipStream_t st)
         hipError_t e = (hipError_t)launch_kernel(k, a, d->rc, st);
         if (e != hipSuccess)
             return fail(d, AGX_ERR_HIP, std::string("launch ") + kKernelNames[k] + ": " + hipGetErrorString(e));
-        if (d->profiling) {
+        if (timed) {
             HIP_TRY(d, hipEventRecord(ev.b, st));
             d->pending_events.push_back(ev);
         }
@@ -349,8 +350,9 @@ int enqueue_chunk(agx_detector *d, int f0, int nf, hipStream_t st)
 int enqueue_chain(agx_detector *d)
 {
     ChainArgs &a = d->args;
-    HIP_TRY(d, hipMemsetAsync(a.ctr, 0, (size_t)a.n_frames * sizeof(FrameCounters), d->stream));
-    HIP_TRY(d, hipMemsetAsync(a.total_out, 0, sizeof(uint32_t), d->stream));
+    // counters of the batch's frames and the compact-output cursor in one clear
+    a.total_out = &a.ctr[a.n_frames].min_key_inv;
+    HIP_TRY(d, hipMemsetAsync(a.ctr, 0, ((size_t)a.n_frames + 1) * sizeof(FrameCounters), d->stream));
     const int F = a.n_frames;
     const int chunk = std::max(1, d->chunk_frames);
     const int n_chunks = (F + chunk - 1) / chunk;
@@ -760,7 +762,7 @@ int agx_detect(agx_detector *det, const void *pixels, int width, int height, siz
 int agx_profile_enable(agx_detector *det, int on)
 {
     if (!det) return AGX_ERR_ARG;
-    det->profiling = on != 0;
+    det->profiling = on < 0 ? 0 : (on > 2 ? 2 : on);
     return AGX_OK;
 }
 

@@ -275,8 +275,10 @@ class TagDetector:
         return res, status
 
     # ---- measurement / parity hooks ------------------------------------------------------
-    def profile_enable(self, on=True):
-        self._check(self._lib.agx_profile_enable(self._h, 1 if on else 0))
+    def profile_enable(self, level=2):
+        """0/False off, 1 = time the blur kernel only, 2/True = time every kernel."""
+        level = 2 if level is True else (0 if level is False else int(level))
+        self._check(self._lib.agx_profile_enable(self._h, level))
 
     def profile_reset(self):
         self._check(self._lib.agx_profile_reset(self._h))

@@ -147,7 +147,8 @@ def main():
     saddles_per_frame = float(tb[:, 0].mean())
     clusters_per_frame = float(tb[:, 3].mean())
 
-    det.profile_enable(True)
+    # timed region: hipEvents (on the launch stream) around K1 only -- 2 records per step
+    det.profile_enable(1)
     det.profile_reset()
     fence()
     t0 = time.perf_counter()
@@ -155,8 +156,15 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
+    k1_prof = det.profile_read()["k_blur_hessian"]
+    # separate, untimed pass for the per-kernel breakdown (events around every launch)
+    det.profile_enable(2)
+    det.profile_reset()
+    for _ in range(min(args.steps, 10)):
+        step()
+    fence()
     prof = det.profile_read()
-    det.profile_enable(False)
+    det.profile_enable(0)
 
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -169,12 +177,23 @@ def main():
         ms_per_step = 1e3 * dt / args.steps
         mpix = total_px / dt / 1e6
         in_b = IN_BYTES[args.format]
-        k1_ms, k1_n = prof["k_blur_hessian"]
+        k1_ms, k1_n = k1_prof
         k1_avg_ms = k1_ms / max(k1_n, 1)
         # K1 reads the input once, writes the blur plane (f32) and 1 bit / px of candidate mask
         k1_bytes = px_per_step_rank * (in_b + 4 + 0.125)
         k1_gbps = k1_bytes / (k1_avg_ms * 1e-3) / 1e9
-        chain_ms = sum(v[0] for v in prof.values()) / max(k1_n, 1)
+        chain_ms = sum(v[0] / max(v[1], 1) for v in prof.values())
+        # HBM bytes per K1 launch from rocprofv3 PMC passes (FETCH_SIZE x2 per the calibration,
+        # + WRITE_SIZE), collected separately (tools/final_profile.sh) and kept under profiles/
+        traffic, traffic_src = args.pmc_traffic, "--pmc-traffic" if args.pmc_traffic else None
+        if traffic is None and world == 1:
+            try:
+                rec = json.load(open(os.path.join(ROOT, "profiles", "k1_traffic.json")))
+                key = "%dx%dx%d_%s" % (F, W, H, args.format)
+                if key in rec:
+                    traffic, traffic_src = rec[key]["bytes_per_launch"], rec[key]["source"]
+            except Exception:
+                pass
         a_mat = in_b + 12  # SURVEY.md 8(d) A_mat: input + blur write + response write + response re-read
         a_design = in_b + 4 + 0.125 + 0.125  # this design: input + blur write + mask write (K1) + mask read (K2);
         # the sparse stages (verify / refine gathers at ~2.4 % of the pixels, lists) add < 0.5 B/px
@@ -210,7 +229,7 @@ def main():
                 "unit": "GB/s",
                 "frac": round(k1_gbps / HBM_PEAK_GBPS, 4),
                 "frac_of_measured_copy_ceiling": round(k1_gbps / HBM_MEASURED_GBPS, 4),
-                "traffic": args.pmc_traffic,
+                "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_px": in_b + 4.125,
                 "bytes_per_launch": k1_bytes,
                 "avg_launch_ms": round(k1_avg_ms, 5),

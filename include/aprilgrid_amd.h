@@ -206,7 +206,7 @@ int agx_luma8(const void *pixels, int width, int height, size_t row_stride_bytes
  * around each launch while profiling is on.  names/ms/launches are arrays of
  * AGX_N_KERNELS entries; ms accumulates since the last reset. */
 #define AGX_N_KERNELS 6
-int agx_profile_enable(agx_detector *det, int on);
+int agx_profile_enable(agx_detector *det, int on); /* 0 off, 1 = the blur kernel only (2 events per batch), 2 = every kernel */
 int agx_profile_reset(agx_detector *det);
 int agx_profile_read(agx_detector *det, const char **names, double *ms_total, uint64_t *launches);
 
