@@ -1087,8 +1087,12 @@ static hipError_t launch_k1(const ChainArgs &a, hipStream_t st)
     return hipGetLastError();
 }
 
-static int sparse_grid_x(const ChainArgs &a, int per_frame_default)
+static int sparse_grid_x(const ChainArgs &a, int per_frame_default, const char *env = nullptr)
 {
+    if (env) {  // tuning override: workgroups per frame
+        const int v = env_int(env, 0);
+        if (v > 0) return v;
+    }
     // few frames -> more workgroups per frame
     long long gx = 4096 / (a.n_frames > 0 ? a.n_frames : 1);
     if (gx < per_frame_default) gx = per_frame_default;
@@ -1105,13 +1109,13 @@ int launch_kernel(int which, const ChainArgs &a, const RefineConsts &rc, void *s
         if (a.fmt == 1) return launch_k1<1>(a, st);
         return launch_k1<2>(a, st);
     case K_THRESHOLD: {
-        dim3 grid(sparse_grid_x(a, 32), a.n_frames), grid4(sparse_grid_x(a, 16), a.n_frames), block(256);
+        dim3 grid(sparse_grid_x(a, 32, "AGX_G_VERIFY"), a.n_frames), grid4(sparse_grid_x(a, 16, "AGX_G_SEEDS"), a.n_frames), block(256);
         hipLaunchKernelGGL(k_verify, grid, block, 0, st, a);
         hipLaunchKernelGGL(k_seeds, grid4, block, 0, st, a);
         return hipGetLastError();
     }
     case K_FLOOD: {
-        dim3 grid(sparse_grid_x(a, 48), a.n_frames), block(64);
+        dim3 grid(sparse_grid_x(a, 48, "AGX_G_FLOOD"), a.n_frames), block(64);
         hipLaunchKernelGGL(k_flood, grid, block, 0, st, a);
         dim3 grid2(sparse_grid_x(a, 4), a.n_frames), block2(128);
         hipLaunchKernelGGL(k_flood_block, grid2, block2, 0, st, a);
@@ -1126,7 +1130,7 @@ int launch_kernel(int which, const ChainArgs &a, const RefineConsts &rc, void *s
         return hipGetLastError();
     }
     case K_REFINE: {
-        dim3 grid(sparse_grid_x(a, 16), a.n_frames), block(64);
+        dim3 grid(sparse_grid_x(a, 24, "AGX_G_REFINE"), a.n_frames), block(64);
         if ((a.W & 3) == 0) hipLaunchKernelGGL(k_refine<true>, grid, block, 0, st, a, rc);
         else hipLaunchKernelGGL(k_refine<false>, grid, block, 0, st, a, rc);
         return hipGetLastError();

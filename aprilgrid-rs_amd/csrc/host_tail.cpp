@@ -71,8 +71,11 @@ bool is_valid_quad(const agx_saddle &s0, const agx_saddle &d0, const agx_saddle 
 
 namespace {
 
-// Nearest-neighbour queries over the saddle set (the reference uses kdtree 0.8.0's
-// nearest(): ascending squared distance; ties resolved here by ascending index).
+// Nearest-neighbour queries over the saddle set.  The reference uses kdtree 0.8.0's nearest():
+// ascending squared distance (f32, folded from 0.0); exact-distance ties are resolved here by
+// ascending index.  Implementation: uniform grid buckets, rings of cells around the query are
+// examined until k hits are known that are strictly closer than anything outside the examined
+// block can be -- so the result is exactly what an exhaustive search returns.
 class SaddleIndex {
 public:
     struct Hit {
@@ -80,25 +83,98 @@ public:
         int idx;
         bool operator<(const Hit &o) const { return d2 < o.d2 || (d2 == o.d2 && idx < o.idx); }
     };
-    explicit SaddleIndex(const std::vector<agx_saddle> &pts) : pts_(pts), scratch_(pts.size()) {}
+    explicit SaddleIndex(const std::vector<agx_saddle> &pts) : pts_(pts)
+    {
+        const int n = (int)pts.size();
+        float x0 = 0, x1 = 1, y0 = 0, y1 = 1;
+        if (n) {
+            x0 = x1 = pts[0].x;
+            y0 = y1 = pts[0].y;
+            for (const agx_saddle &p : pts) {
+                x0 = std::min(x0, p.x); x1 = std::max(x1, p.x);
+                y0 = std::min(y0, p.y); y1 = std::max(y1, p.y);
+            }
+        }
+        ox_ = x0;
+        oy_ = y0;
+        const double w = std::max(1e-3, (double)x1 - x0), h = std::max(1e-3, (double)y1 - y0);
+        cell_ = std::max(1.0, std::sqrt(w * h / std::max(1, n)) * 1.5);  // ~2 points per cell
+        nx_ = std::max(1, (int)std::floor(w / cell_) + 1);
+        ny_ = std::max(1, (int)std::floor(h / cell_) + 1);
+        start_.assign((size_t)nx_ * ny_ + 1, 0);
+        std::vector<int> cell_of(n);
+        for (int i = 0; i < n; ++i) {
+            cell_of[i] = cell_y(pts[i].y) * nx_ + cell_x(pts[i].x);
+            start_[cell_of[i] + 1]++;
+        }
+        for (size_t c = 0; c < (size_t)nx_ * ny_; ++c) start_[c + 1] += start_[c];
+        items_.resize(n);
+        std::vector<int> fill(start_.begin(), start_.end() - 1);
+        for (int i = 0; i < n; ++i) items_[fill[cell_of[i]]++] = i;  // ascending index inside a cell
+    }
 
-    // k nearest, ascending
+    // k nearest, ascending; returns how many were found (min(k, n))
     int nearest(float qx, float qy, int k, Hit *out)
     {
         const int n = (int)pts_.size();
-        for (int i = 0; i < n; ++i) {
-            const float dx = qx - pts_[i].x, dy = qy - pts_[i].y;
-            scratch_[i] = {(0.0f + dx * dx) + dy * dy, i};
+        const int want = std::min(k, n);
+        if (want <= 0) return 0;
+        const int cx = cell_x(qx), cy = cell_y(qy);
+        cand_.clear();
+        int xlo = cx, xhi = cx, ylo = cy, yhi = cy;  // examined block of cells (inclusive)
+        scan(xlo, xhi, ylo, yhi, qx, qy);
+        for (;;) {
+            const bool all = xlo == 0 && ylo == 0 && xhi == nx_ - 1 && yhi == ny_ - 1;
+            if ((int)cand_.size() >= want) {
+                std::partial_sort(cand_.begin(), cand_.begin() + want, cand_.end());
+                if (all) break;
+                // distance from the query to the nearest still unexamined region; sides of the
+                // block that coincide with the grid border have nothing beyond them
+                double gap = 1e300;
+                if (xlo > 0) gap = std::min(gap, (double)qx - (ox_ + xlo * cell_));
+                if (xhi < nx_ - 1) gap = std::min(gap, (ox_ + (xhi + 1) * cell_) - (double)qx);
+                if (ylo > 0) gap = std::min(gap, (double)qy - (oy_ + ylo * cell_));
+                if (yhi < ny_ - 1) gap = std::min(gap, (oy_ + (yhi + 1) * cell_) - (double)qy);
+                if (gap > 0 && (double)cand_[want - 1].d2 < gap * gap * (1.0 - 1e-6)) break;
+            } else if (all) {
+                std::sort(cand_.begin(), cand_.end());
+                break;
+            }
+            // grow the block by one ring and scan only the new cells
+            const int nxlo = std::max(0, xlo - 1), nxhi = std::min(nx_ - 1, xhi + 1);
+            const int nylo = std::max(0, ylo - 1), nyhi = std::min(ny_ - 1, yhi + 1);
+            if (nylo < ylo) scan(nxlo, nxhi, nylo, nylo, qx, qy);
+            if (nyhi > yhi) scan(nxlo, nxhi, nyhi, nyhi, qx, qy);
+            if (nxlo < xlo) scan(nxlo, nxlo, ylo, yhi, qx, qy);
+            if (nxhi > xhi) scan(nxhi, nxhi, ylo, yhi, qx, qy);
+            xlo = nxlo; xhi = nxhi; ylo = nylo; yhi = nyhi;
         }
-        const int m = std::min(k, n);
-        std::partial_sort(scratch_.begin(), scratch_.begin() + m, scratch_.end());
-        std::copy(scratch_.begin(), scratch_.begin() + m, out);
+        const int m = std::min(want, (int)cand_.size());
+        std::copy(cand_.begin(), cand_.begin() + m, out);
         return m;
     }
 
 private:
+    int cell_x(float x) const { return std::min(nx_ - 1, std::max(0, (int)std::floor(((double)x - ox_) / cell_))); }
+    int cell_y(float y) const { return std::min(ny_ - 1, std::max(0, (int)std::floor(((double)y - oy_) / cell_))); }
+    void scan(int xa, int xb, int ya, int yb, float qx, float qy)
+    {
+        for (int y = ya; y <= yb; ++y)
+            for (int x = xa; x <= xb; ++x) {
+                const size_t c = (size_t)y * nx_ + x;
+                for (int t = start_[c]; t < start_[c + 1]; ++t) {
+                    const int i = items_[t];
+                    const float dx = qx - pts_[i].x, dy = qy - pts_[i].y;
+                    cand_.push_back({(0.0f + dx * dx) + dy * dy, i});
+                }
+            }
+    }
+
     const std::vector<agx_saddle> &pts_;
-    std::vector<Hit> scratch_;
+    double ox_ = 0, oy_ = 0, cell_ = 1;
+    int nx_ = 1, ny_ = 1;
+    std::vector<int> start_, items_;
+    std::vector<Hit> cand_;
 };
 
 struct CellKey {

@@ -103,7 +103,7 @@ def test_host_tail_matches_oracle_tail_on_synthetic_and_other_families():
     import aprilgrid_rs_amd as A
     from oracle import oracle as O
     synth = synth_module()
-    for i in range(4):
+    for i in range(12):
         frame, gt = synth.render_frame(20 + i, 640, 400)
         img = frame.numpy()
         saddles = O.refined_saddle_points(img)
