@@ -160,6 +160,13 @@ template <int FMT, bool A4>
 __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
 {
     const int lane = threadIdx.x & 63;
+    // u8 -> luma table (v / 255, true division once per entry): the per-pixel lookups run on the
+    // LDS pipe, which this kernel otherwise leaves idle, instead of 3 VALU ops per pixel
+    __shared__ float s_lut[256];
+    if (FMT == 0) {
+        if (threadIdx.x < 256) s_lut[threadIdx.x] = (float)threadIdx.x / 255.0f;
+        __syncthreads();
+    }
     // wave-uniform quantities are made scalar explicitly (the compiler cannot prove it)
     const int unit = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     if (unit >= a.n_strips * a.n_segs) return;  // whole wave
@@ -256,9 +263,9 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
                 const uint32_t d = cur[k];
                 // lanes left / right of the image replicate the edge pixel (clamp-to-edge)
                 const uint32_t first = (d & 0xffu) * 0x01010101u, last = (d >> 24) * 0x01010101u;
-                RawPx<FMT> rp;
-                rp.d[0] = c0 < 0 ? first : (c0 >= W ? last : d);
-                convert_px<FMT>(rp, m);
+                const uint32_t dd = c0 < 0 ? first : (c0 >= W ? last : d);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) m[j] = s_lut[(dd >> (8 * j)) & 0xffu];
             } else {
                 convert_px<FMT>(raw_a, m);
                 raw_a = raw_b;

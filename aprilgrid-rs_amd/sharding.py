@@ -9,7 +9,8 @@ the tests.
 import torch
 import torch.distributed as dist
 
-SLAB_RECORDS = 1024  # saddle records per frame in the fixed-size result slab (20 KB / frame)
+SLAB_RECORDS = 512  # average saddle records per frame the packed result buffer holds (the chain
+# packs the frames' lists back to back; a batch that needs more is flagged, never truncated)
 
 
 def shard_range(rank, world, frames_per_rank):
@@ -41,6 +42,63 @@ def gather_results(saddles, table, dst=0, group=None):
     dist.gather(table, None, dst=dst, group=group)
     dist.gather(saddles, None, dst=dst, group=group)
     return None, None
+
+
+class GatherPipeline:
+    """Double-buffered result buffers with asynchronous gathers, so that the gather of step i
+    overlaps the chain of step i+1 (which writes the other buffer pair).
+
+        pipe = GatherPipeline(n_frames, device)
+        for step in ...:
+            out, table = pipe.acquire()      # waits (stream-side) for the gather that last used them
+            det.saddles_batch_enqueue_to(frames, out, table)
+            pipe.submit()                    # async gather of (out, table) to rank `dst`
+        gathered = pipe.finish()             # on dst: (list_of_saddles, list_of_tables) of the LAST step
+    """
+
+    def __init__(self, n_frames, device, dst=0, group=None, depth=2):
+        self.dst, self.group = dst, group
+        self.multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.world = dist.get_world_size(group) if self.multi else 1
+        self.rank = dist.get_rank(group) if self.multi else 0
+        self.bufs = [alloc_result_buffers(n_frames, device) for _ in range(depth if self.multi else 1)]
+        self.recv = None
+        if self.multi and self.rank == dst:
+            self.recv = [([torch.empty_like(s) for _ in range(self.world)], [torch.empty_like(t) for _ in range(self.world)])
+                         for (s, t) in self.bufs]
+        self.works = [None] * len(self.bufs)
+        self.i = -1
+
+    def acquire(self):
+        self.i = (self.i + 1) % len(self.bufs)
+        w = self.works[self.i]
+        if w is not None:
+            for h in w:
+                h.wait()  # the current stream waits for the gather that was reading these buffers
+            self.works[self.i] = None
+        return self.bufs[self.i]
+
+    def submit(self):
+        if not self.multi:
+            return
+        s, t = self.bufs[self.i]
+        if self.rank == self.dst:
+            gs, gt = self.recv[self.i]
+            self.works[self.i] = [dist.gather(t, gt, dst=self.dst, group=self.group, async_op=True),
+                                  dist.gather(s, gs, dst=self.dst, group=self.group, async_op=True)]
+        else:
+            self.works[self.i] = [dist.gather(t, None, dst=self.dst, group=self.group, async_op=True),
+                                  dist.gather(s, None, dst=self.dst, group=self.group, async_op=True)]
+
+    def finish(self):
+        for w in self.works:
+            if w is not None:
+                for h in w:
+                    h.wait()
+        self.works = [None] * len(self.bufs)
+        if not self.multi:
+            return [self.bufs[self.i][0]], [self.bufs[self.i][1]]
+        return self.recv[self.i] if self.rank == self.dst else (None, None)
 
 
 def unpack_frames(saddles, table):

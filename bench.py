@@ -124,15 +124,19 @@ def main():
     stream = torch.cuda.current_stream(dev)
     det.set_stream(stream.cuda_stream)  # kernels, events and the RCCL gather share torch's stream order
 
-    out_saddles, table = sharding.alloc_result_buffers(F, dev)
+    # result buffers stay in HBM; for N > 1 they are double-buffered and gathered to rank 0
+    # asynchronously (RCCL over xGMI), so the gather of step i overlaps the chain of step i+1
+    pipe = sharding.GatherPipeline(F, dev, dst=0)
+    last = {}
 
     def step():
+        out_saddles, table = pipe.acquire()
         det.saddles_batch_enqueue_to(frames, out_saddles, table)
-        if world > 1:
-            # the one collective of the path: result gather to rank 0 (RCCL over xGMI)
-            sharding.gather_results(out_saddles, table, dst=0)
+        pipe.submit()  # the one collective of the path: result gather to rank 0
+        last["table"] = table
 
     def fence():
+        pipe.finish()
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
@@ -141,7 +145,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    tb = table.cpu().numpy()
+    tb = last["table"].cpu().numpy()
     assert (tb[:, 2] & 7 == 0).all(), "capacity overflow in the bench workload: %s" % tb[tb[:, 2] != 0][:4]
     generic_frames = int(((tb[:, 2] & 16) != 0).sum())
     saddles_per_frame = float(tb[:, 0].mean())

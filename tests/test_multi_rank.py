@@ -53,6 +53,19 @@ def _worker(rank, world, port, q):
         table[i] = torch.tensor([len(s), off, 0, 0], dtype=torch.int32)
         off += len(s)
     gs, gt = sharding.gather_results(saddles, table, dst=0)
+    # the same through the double-buffered asynchronous pipeline bench.py uses: 3 "steps", the
+    # buffers of the last one must arrive intact
+    pipe = sharding.GatherPipeline(FRAMES_PER_RANK, "cpu", dst=0)
+    for step in range(3):
+        ps, pt = pipe.acquire()
+        ps.zero_(); pt.zero_()
+        ps.copy_(saddles * (1.0 if step == 2 else 0.5))
+        pt.copy_(table)
+        pipe.submit()
+    ps_all, pt_all = pipe.finish()
+    if rank == 0:
+        for r in range(world):
+            assert torch.equal(pt_all[r], gt[r]) and torch.equal(ps_all[r], gs[r]), "pipeline gather differs"
     if rank == 0:
         frames = []
         for r in range(world):
