@@ -21,7 +21,7 @@
 //   K3 k_flood          4-connected components (image_util.rs:208-236) + centroid sums
 //                       (detector.rs:421-429): one component per lane, bit-parallel flood fill
 //                       of a 32x32 window of the mask held in registers
-//   K3g k_g_*           guarded generic fallback (mask -> candidate list -> lock-free
+//   K3g k_generic       guarded generic fallback (mask -> candidate list -> lock-free
 //                       union-find -> sums) for frames where a component leaves the window
 //   K4 k_refine         rochade_refine (detector.rs:194-361), one cluster per lane
 //   K5 k_filter_sort    k/phi filter (detector.rs:436-445), emission in reference order
@@ -669,55 +669,28 @@ __global__ void __launch_bounds__(128) k_flood_block(ChainArgs a)
 }
 
 // ------------------------------------------------------------------------------------------
-// K3g: generic fallback, run only for frames flagged FLAG_BIG_CLUSTER (every block checks the
+// K3g: generic fallback, run only for frames flagged FLAG_BIG_CLUSTER (every workgroup checks the
 // flag and leaves at once otherwise).  Works for components of any size and shape.
-//   k_g_compact   mask -> candidate list (pixel | left<<30 | up<<31), slot plane
-//   k_g_union     lock-free union-find; links go from the larger slot to the smaller; every
-//                 access to parent[] is an agent-scope atomic (blocks run on any XCD)
-//   k_g_sums      per-root integer sums and smallest pixel; root list
-//   k_g_emit      roots -> cluster records (replacing the fast path's records of the frame)
+//   phase 1   mask -> candidate list (pixel | left<<30 | up<<31), slot plane
+//   phase 2   lock-free union-find; links go from the larger slot to the smaller; every access
+//             to parent[] is an agent-scope atomic
+//   phase 3   per-root integer sums and smallest pixel; root list
+//   phase 4   roots -> cluster records (replacing the flood path's records of the frame)
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool frame_is_generic(const ChainArgs &a, const FrameCounters &ctr)
 {
     return a.force_generic || (ctr.flags & FLAG_BIG_CLUSTER);
 }
 
-__global__ void k_g_compact(ChainArgs a)
+// One 1024-thread workgroup per flagged frame runs the four phases back to back; phases are
+// separated by a workgroup barrier plus agent-scope release / acquire fences, because the
+// phases communicate through global memory (atomics execute at L2 / memory and do not refresh
+// this CU's L1).  Unflagged frames cost one launch of workgroups that return at once.
+__device__ __forceinline__ void phase_barrier()
 {
-    const int frame = blockIdx.y;
-    FrameCounters &ctr = a.ctr[frame];
-    if (!frame_is_generic(a, ctr)) return;
-    if (blockIdx.x == 0 && threadIdx.x == 0) ctr.n_clusters = 0u;  // discard fast-path records
-    const uint32_t *mask = a.mask + (size_t)frame * (size_t)a.mask_plane;
-    const int wpr = a.mask_wpr, W = a.W;
-    const long long total = (long long)((a.H + 31) >> 5) * W;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int yb = (int)(i / W), x = (int)(i % W);
-        const uint32_t *wp = mask + (size_t)yb * wpr + MASK_PAD_X + x;
-        uint32_t m = wp[0];
-        if (!m) continue;
-        const uint32_t lm = wp[-1];                                          // candidate to the left
-        const uint32_t um = (m << 1) | (yb > 0 ? (wp[-wpr] >> 31) : 0u);     // candidate above
-        while (m) {
-            const int b = __ffs(m) - 1;
-            m &= m - 1;
-            const uint32_t p = (uint32_t)(yb * 32 + b) * (uint32_t)W + (uint32_t)x;
-            const uint32_t slot = atomicAdd(&ctr.n_cand, 1u);
-            if (slot < a.cap_cand) {
-                const size_t o = (size_t)frame * a.cap_cand + slot;
-                a.cand[o] = p | (((lm >> b) & 1u) << 30) | (((um >> b) & 1u) << 31);
-                a.parent[o] = slot;
-                a.sumx[o] = 0u;
-                a.sumy[o] = 0u;
-                a.cnt[o] = 0u;
-                a.minidx[o] = 0xffffffffu;
-                a.slot_plane[(size_t)frame * (size_t)a.plane + p] = slot;
-            } else {
-                atomicOr(&ctr.flags, FLAG_CAND_OVERFLOW);
-            }
-        }
-    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
 __device__ __forceinline__ uint32_t uf_find_atomic(uint32_t *parent, uint32_t x)
@@ -743,41 +716,64 @@ __device__ __forceinline__ void uf_unite(uint32_t *parent, uint32_t x, uint32_t 
     }
 }
 
-__global__ void k_g_union(ChainArgs a)
+__global__ void __launch_bounds__(1024) k_generic(ChainArgs a)
 {
-    const int frame = blockIdx.y;
-    const FrameCounters &ctr = a.ctr[frame];
-    if (!frame_is_generic(a, ctr)) return;
-    if (ctr.n_cand > a.cap_cand) return;  // overflow: slot_plane is incomplete, frame reported
-    const uint32_t n = ctr.n_cand;
+    const int frame = blockIdx.x;
+    FrameCounters &ctr = a.ctr[frame];
+    if (!frame_is_generic(a, ctr)) return;  // whole workgroup
+    const uint32_t T = blockDim.x, t = threadIdx.x;
+    const uint32_t *mask = a.mask + (size_t)frame * (size_t)a.mask_plane;
+    const int wpr = a.mask_wpr, W = a.W;
     const size_t base = (size_t)frame * a.cap_cand;
     uint32_t *parent = a.parent + base;
-    const uint32_t *slot_plane = a.slot_plane + (size_t)frame * (size_t)a.plane;
-    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
+    uint32_t *slot_plane = a.slot_plane + (size_t)frame * (size_t)a.plane;
+
+    // phase 1: mask -> candidate list (pixel | left<<30 | up<<31), slot plane
+    const long long total = (long long)((a.H + 31) >> 5) * W;
+    for (long long i = t; i < total; i += T) {
+        const int yb = (int)(i / W), x = (int)(i % W);
+        const uint32_t *wp = mask + (size_t)yb * wpr + MASK_PAD_X + x;
+        uint32_t m = wp[0];
+        if (!m) continue;
+        const uint32_t lm = wp[-1];                                       // candidate to the left
+        const uint32_t um = (m << 1) | (yb > 0 ? (wp[-wpr] >> 31) : 0u);  // candidate above
+        while (m) {
+            const int b = __ffs(m) - 1;
+            m &= m - 1;
+            const uint32_t p = (uint32_t)(yb * 32 + b) * (uint32_t)W + (uint32_t)x;
+            const uint32_t slot = atomicAdd(&ctr.n_cand, 1u);
+            if (slot < a.cap_cand) {
+                const size_t o = base + slot;
+                a.cand[o] = p | (((lm >> b) & 1u) << 30) | (((um >> b) & 1u) << 31);
+                a.parent[o] = slot;
+                a.sumx[o] = 0u;
+                a.sumy[o] = 0u;
+                a.cnt[o] = 0u;
+                a.minidx[o] = 0xffffffffu;
+                slot_plane[p] = slot;
+            } else {
+                atomicOr(&ctr.flags, FLAG_CAND_OVERFLOW);
+            }
+        }
+    }
+    phase_barrier();
+    const uint32_t n = __hip_atomic_load(&ctr.n_cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (n > a.cap_cand) {  // overflow: slot_plane is incomplete; the frame is reported, not processed
+        if (t == 0) ctr.n_clusters = 0u;
+        return;
+    }
+    // phase 2: lock-free union-find; links go from the larger slot to the smaller
+    for (uint32_t s = t; s < n; s += T) {
         const uint32_t e = a.cand[base + s];
         const uint32_t p = e & 0x3fffffffu;
         if (e & 0x40000000u) uf_unite(parent, s, slot_plane[p - 1]);
         if (e & 0x80000000u) uf_unite(parent, s, slot_plane[p - a.W]);
     }
-}
-
-__global__ void k_g_sums(ChainArgs a)
-{
-    const int frame = blockIdx.y;
-    FrameCounters &ctr = a.ctr[frame];
-    if (!frame_is_generic(a, ctr)) return;
-    if (ctr.n_cand > a.cap_cand) return;
-    const uint32_t n = ctr.n_cand;
-    const size_t base = (size_t)frame * a.cap_cand;
-    const uint32_t *parent = a.parent + base;
-    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
+    phase_barrier();
+    // phase 3: per-root integer sums and smallest pixel; root list
+    for (uint32_t s = t; s < n; s += T) {
         const uint32_t p = a.cand[base + s] & 0x3fffffffu;
-        uint32_t r = s;
-        for (;;) {
-            uint32_t q = parent[r];
-            if (q == r) break;
-            r = q;
-        }
+        const uint32_t r = uf_find_atomic(parent, s);
         atomicAdd(&a.sumx[base + r], p % (uint32_t)a.W);
         atomicAdd(&a.sumy[base + r], p / (uint32_t)a.W);
         atomicAdd(&a.cnt[base + r], 1u);
@@ -788,24 +784,18 @@ __global__ void k_g_sums(ChainArgs a)
             else atomicOr(&ctr.flags, FLAG_ROOT_OVERFLOW);
         }
     }
-}
-
-__global__ void k_g_emit(ChainArgs a)
-{
-    const int frame = blockIdx.y;
-    FrameCounters &ctr = a.ctr[frame];
-    if (!frame_is_generic(a, ctr)) return;
-    const uint32_t n = min(ctr.n_roots, a.cap_roots);
-    const size_t base = (size_t)frame * a.cap_cand;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint32_t s = a.roots[(size_t)frame * a.cap_roots + i];
+    phase_barrier();
+    // phase 4: roots -> cluster records (replacing the flood path's records of this frame)
+    const uint32_t nr = min(__hip_atomic_load(&ctr.n_roots, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), a.cap_roots);
+    for (uint32_t i = t; i < nr; i += T) {
+        const uint32_t s = __hip_atomic_load(&a.roots[(size_t)frame * a.cap_roots + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const size_t q = (size_t)frame * a.cap_roots + i;
-        a.clu_key[q] = a.minidx[base + s];
-        a.clu_cnt[q] = a.cnt[base + s];
-        a.clu_sx[q] = a.sumx[base + s];
-        a.clu_sy[q] = a.sumy[base + s];
+        a.clu_key[q] = __hip_atomic_load(&a.minidx[base + s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a.clu_cnt[q] = __hip_atomic_load(&a.cnt[base + s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a.clu_sx[q] = __hip_atomic_load(&a.sumx[base + s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a.clu_sy[q] = __hip_atomic_load(&a.sumy[base + s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) ctr.n_clusters = n;
+    if (t == 0) ctr.n_clusters = nr;
 }
 
 // Debug only (agx_debug_fetch AGX_DBG_RESP): the response plane K2 thresholds, materialised.
@@ -834,7 +824,7 @@ __global__ void k_debug_resp(const float *__restrict__ blur, float *__restrict__
 // K4: rochade_refine, detector.rs:265-359, one cluster per lane.
 // ------------------------------------------------------------------------------------------
 template <bool VEC>
-__global__ void __launch_bounds__(64) k_refine(ChainArgs a, RefineConsts rc)
+__global__ void __launch_bounds__(64, 4) k_refine(ChainArgs a, RefineConsts rc)
 {
     const int frame = blockIdx.y;
     if (a.ctr[frame].flags & (FLAG_CAND_OVERFLOW | FLAG_ROOT_OVERFLOW)) return;
@@ -1129,11 +1119,8 @@ int launch_kernel(int which, const ChainArgs &a, const RefineConsts &rc, void *s
         return hipGetLastError();
     }
     case K_GENERIC: {
-        dim3 grid(sparse_grid_x(a, 8), a.n_frames), block(256);
-        hipLaunchKernelGGL(k_g_compact, grid, block, 0, st, a);
-        hipLaunchKernelGGL(k_g_union, grid, block, 0, st, a);
-        hipLaunchKernelGGL(k_g_sums, grid, block, 0, st, a);
-        hipLaunchKernelGGL(k_g_emit, grid, block, 0, st, a);
+        dim3 grid(a.n_frames), block(1024);
+        hipLaunchKernelGGL(k_generic, grid, block, 0, st, a);
         return hipGetLastError();
     }
     case K_REFINE: {

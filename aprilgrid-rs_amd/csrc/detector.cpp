@@ -21,7 +21,7 @@ using namespace agx;
 namespace {
 
 const char *kKernelNames[K_COUNT] = {"k_blur_hessian", "k_threshold", "k_flood",
-                                     "k_generic_x4",   "k_refine",    "k_filter_sort"};
+                                     "k_generic",   "k_refine",    "k_filter_sort"};
 
 struct EventPair {
     hipEvent_t a, b;
