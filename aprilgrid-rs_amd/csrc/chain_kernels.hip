@@ -58,22 +58,23 @@ __device__ __forceinline__ float div_const(float v)
 }
 
 // Neighbour-lane exchange by DPP wave shifts (one VALU op, no LDS): lane l receives the value
-// of lane l-1 (from_left) or l+1 (from_right); lane 0 / lane 63 receive 0.
+// of lane l-1 (from_left) or l+1 (from_right); lane 0 / lane 63 receive 0 (bound_ctrl: no
+// destination to initialise).
 __device__ __forceinline__ float from_left(float v)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
 }
 __device__ __forceinline__ float from_right(float v)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
 }
 __device__ __forceinline__ uint32_t from_left_u(uint32_t v)
 {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true);
 }
 __device__ __forceinline__ uint32_t from_right_u(uint32_t v)
 {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true);
 }
 
 // Raw pixel words of 4 consecutive pixels: L8 1 dword, L16 2 dwords, RGB8 3 dwords.
@@ -200,23 +201,39 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
         for (int j = 0; j < 4; ++j) acc[s7][j] = 0.0f;
 #pragma unroll
     for (int j = 0; j < 6; ++j) up[j] = mid[j] = 0.0f;
-    float run_min = 0.0f;  // the frame always contains its zero border ring
+    // Running minimum per pixel column of the lane (a column either always or never takes part in
+    // the frame's minimum, so validity is applied when the columns are combined, not per row).
+    // A4: columns 1 and 2 share rmin[1].  The frame always contains its zero border ring -> 0.
+    float rmin[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     // Candidate superset: a pixel can only end up below the final threshold 0.05*min_frame if it
     // is below 0.05*m for every m >= min_frame; m = the smallest response this frame has shown so
     // far (own rows + what other waves published in ctr.min_key_inv).  thr_run only ever moves
     // down towards the final threshold, so nothing is lost; the list is filtered again in K2.
     FrameCounters &ctr = a.ctr[frame];
     uint32_t *mask_f = a.mask + (size_t)frame * (size_t)a.mask_plane;
-    float thr_run = 0.0f, published = 0.0f;
+    // wave-uniform; kept as bit patterns so that they live in scalar registers
+    int thr_run_bits = 0, published_bits = 0;  // 0.0f
     int rows_to_sync = 0, sync_gap = 1;
     uint32_t polled = 0u;  // ctr.min_key_inv as fetched at the previous sync point
     float cmax = -__builtin_inff();  // weakest candidate response of this lane in the current 32-row block
     uint32_t mw[4] = {0u, 0u, 0u, 0u};  // this lane's 4 mask words (4 columns x 32 rows) in progress
+    int y_pushed = 0;                    // last row whose bits were shifted into mw
 
     // per-pixel "takes part in the min" (interior column of this lane's strip)
     bool min_ok[4];
+    uint64_t ok_mask[4];  // the same as wave-wide lane masks
 #pragma unroll
-    for (int j = 0; j < 4; ++j) min_ok[j] = lane_valid && (c0 + j > 0) && (c0 + j < W - 1);
+    for (int j = 0; j < 4; ++j) {
+        min_ok[j] = lane_valid && (c0 + j > 0) && (c0 + j < W - 1);
+        ok_mask[j] = __ballot(min_ok[j]);
+    }
+    auto lane_min = [&]() {
+        float v = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (!(A4 && j == 2)) v = fminf(v, min_ok[j] ? rmin[j] : 0.0f);
+        return v;
+    };
     const bool store_ok = lane_valid && !(a.dbg & 1);
 
     const int r0 = ys - 4, r1 = ye + 3;
@@ -234,6 +251,8 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
     uint32_t ring[7];
     RawPx<FMT> raw_a, raw_b, raw_c, raw_d;
     const int cc = c0 < 0 ? 0 : (c0 > W - 4 ? W - 4 : c0);  // FAST: clamped column of this lane's dword
+    // byte selector of v_perm_b32: identity, or the first / last byte of the dword four times
+    const uint32_t edge_sel = c0 < 0 ? 0x00000000u : (c0 >= W ? 0x03030303u : 0x03020100u);
     auto issue_load = [&](int r) -> uint32_t { return *reinterpret_cast<const uint32_t *>(rowptr(r) + cc); };
     if (FAST) {
 #pragma unroll
@@ -260,10 +279,8 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
             if (r > r1) break;  // wave-uniform
             float m[4];
             if (FAST) {
-                const uint32_t d = cur[k];
                 // lanes left / right of the image replicate the edge pixel (clamp-to-edge)
-                const uint32_t first = (d & 0xffu) * 0x01010101u, last = (d >> 24) * 0x01010101u;
-                const uint32_t dd = c0 < 0 ? first : (c0 >= W ? last : d);
+                const uint32_t dd = __builtin_amdgcn_perm(cur[k], cur[k], edge_sel);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) m[j] = s_lut[(dd >> (8 * j)) & 0xffu];
             } else {
@@ -326,48 +343,91 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
                         const float lxx = (v21 - t22) + v23;
                         const float lyy = (v12 - t22) + v32;
                         const float lxy = (((v13 - v11) + v31) - v33) * 0.25f;
-                        // the 1-pixel border ring is exactly 0 (already in run_min's initial value)
-                        const float d = min_ok[j] ? (lxx * lyy - lxy * lxy) : 0.0f;
-                        run_min = fminf(run_min, d);
-                        dv[j] = d;
+                        // columns outside the lane's share (halo lanes, the image's border ring) hold a
+                        // meaningless value here; they are masked where the columns are combined
+                        dv[j] = lxx * lyy - lxy * lxy;
+                    }
+                    if (A4) {
+                        rmin[0] = fminf(rmin[0], dv[0]);
+                        rmin[1] = fminf(fminf(rmin[1], dv[1]), dv[2]);
+                        rmin[3] = fminf(rmin[3], dv[3]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) rmin[j] = fminf(rmin[j], dv[j]);
                     }
                     // refresh the running threshold with exponential back-off (rows 0,1,5,21,85,..).
                     // The poll of the frame's published minimum is asynchronous: a sync point uses
                     // the value fetched at the previous one and issues the next fetch without
                     // waiting for it (a staler threshold is only a slightly larger superset).
                     if (rows_to_sync <= 0 && !(a.dbg & 16)) {
-                        float wmin = run_min;
+                        float wmin = lane_min();
 #pragma unroll
                         for (int off = 32; off > 0; off >>= 1) wmin = fminf(wmin, __shfl_xor(wmin, off, 64));
+                        const int wmin_bits = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wmin));
+                        wmin = __builtin_bit_cast(float, wmin_bits);
+                        const float published = __builtin_bit_cast(float, published_bits);
                         if (wmin < published * 1.125f || (published == 0.0f && wmin < 0.0f)) {  // >12 % better
                             if (lane == 0) atomicMax(&ctr.min_key_inv, ~f32_order_key(wmin));
-                            published = wmin;
+                            published_bits = wmin_bits;
                         }
                         const float gmin = polled ? f32_from_order_key(~polled) : 0.0f;  // 0 = nothing seen yet
-                        thr_run = fminf(wmin, gmin) * 0.05f;
+                        // (asm: the builtin would be commuted with the multiply and leave a VGPR.  The
+                        // assembler inserts no wait states inside asm: on gfx950 a readlane needs one
+                        // after the VALU write of its source, a VALU read of the SGPR two after this)
+                        asm("s_nop 0\n\tv_readfirstlane_b32 %0, %1\n\ts_nop 1" : "=s"(thr_run_bits) : "v"(fminf(wmin, gmin) * 0.05f));
                         polled = __hip_atomic_load(&ctr.min_key_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         rows_to_sync = sync_gap;
                         sync_gap = min(sync_gap * 4, 128);
                     }
                     --rows_to_sync;
-                    const int sh = y & 31;
+                    // Candidate bit of this row: compare -> lane mask (SGPR pair), restricted to the
+                    // lane's own columns, shifted into the word by an add-with-carry (mw = 2*mw + bit:
+                    // rows enter at bit 0, the word is bit-reversed when it is stored).  One block with
+                    // the four columns interleaved: a VALU-written SGPR needs two wait states before
+                    // a VALU reads it on gfx950, which the assembler does not insert inside asm.
+                    uint64_t cj[4];
+                    asm("v_cmp_lt_f32_e64 %[c0], %[d0], %[thr]\n\t"
+                        "v_cmp_lt_f32_e64 %[c1], %[d1], %[thr]\n\t"
+                        "v_cmp_lt_f32_e64 %[c2], %[d2], %[thr]\n\t"
+                        "v_cmp_lt_f32_e64 %[c3], %[d3], %[thr]\n\t"
+                        "s_and_b64 %[c0], %[c0], %[k0]\n\t"
+                        "s_and_b64 %[c1], %[c1], %[k1]\n\t"
+                        "s_and_b64 %[c2], %[c2], %[k2]\n\t"
+                        "s_and_b64 %[c3], %[c3], %[k3]\n\t"
+                        "v_addc_co_u32_e64 %[m0], vcc, %[m0], %[m0], %[c0]\n\t"
+                        "v_addc_co_u32_e64 %[m1], vcc, %[m1], %[m1], %[c1]\n\t"
+                        "v_addc_co_u32_e64 %[m2], vcc, %[m2], %[m2], %[c2]\n\t"
+                        "v_addc_co_u32_e64 %[m3], vcc, %[m3], %[m3], %[c3]"
+                        : [m0] "+v"(mw[0]), [m1] "+v"(mw[1]), [m2] "+v"(mw[2]), [m3] "+v"(mw[3]),
+                          [c0] "=&s"(cj[0]), [c1] "=&s"(cj[1]), [c2] "=&s"(cj[2]), [c3] "=&s"(cj[3])
+                        : [d0] "v"(dv[0]), [d1] "v"(dv[1]), [d2] "v"(dv[2]), [d3] "v"(dv[3]), [thr] "s"(thr_run_bits),
+                          [k0] "s"(ok_mask[0]), [k1] "s"(ok_mask[1]), [k2] "s"(ok_mask[2]), [k3] "s"(ok_mask[3])
+                        : "vcc", "scc");  // s_and_b64 writes SCC
+                    if ((cj[0] | cj[1] | cj[2] | cj[3]) != 0ull) {  // wave-uniform; most rows have no candidate
+                        float sel[4];  // the candidate's response, or the current maximum itself
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const bool cj = dv[j] < thr_run;
-                        mw[j] |= cj ? (1u << sh) : 0u;
-                        cmax = fmaxf(cmax, cj ? dv[j] : -__builtin_inff());
+                        for (int j = 0; j < 4; ++j)
+                            asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(sel[j]) : "v"(cmax), "v"(dv[j]), "s"(cj[j]));
+                        cmax = fmaxf(fmaxf(cmax, sel[0]), sel[1]);
+                        cmax = fmaxf(fmaxf(cmax, sel[2]), sel[3]);
                     }
+                    y_pushed = y;
                 }
                 if ((y & 31) == 31 || y == ye - 1) {  // word row complete (segments are 32-row aligned)
                     if (lane_valid) {
                         a.cand_max[((size_t)frame * a.mask_yb + (y >> 5)) * (a.mask_wpr >> 2) + ((MASK_PAD_X + c0) >> 2)] = cmax;
                         uint32_t *dst = mask_f + (size_t)(y >> 5) * a.mask_wpr + MASK_PAD_X + c0;
+                        // the last row pushed sits at bit 0: reverse, then move it to bit (row & 31)
+                        const int fix = 31 - (y_pushed & 31);
+                        uint32_t o[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[j] = __brev(mw[j]) >> fix;
                         if (A4) {
-                            *reinterpret_cast<uint4 *>(dst) = make_uint4(mw[0], mw[1], mw[2], mw[3]);
+                            *reinterpret_cast<uint4 *>(dst) = make_uint4(o[0], o[1], o[2], o[3]);
                         } else {
 #pragma unroll
                             for (int j = 0; j < 4; ++j)
-                                if (c0 + j < W) dst[j] = mw[j];
+                                if (c0 + j < W) dst[j] = o[j];
                         }
                     }
                     mw[0] = mw[1] = mw[2] = mw[3] = 0u;
@@ -382,6 +442,7 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
         }
     }
     // per-frame min: wave reduction, one atomic per wave
+    float run_min = lane_min();
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) run_min = fminf(run_min, __shfl_xor(run_min, off, 64));
     if (lane == 0) atomicMax(&ctr.min_key_inv, ~f32_order_key(run_min));  // always: the word must end up valid
