@@ -253,7 +253,19 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
     const int cc = c0 < 0 ? 0 : (c0 > W - 4 ? W - 4 : c0);  // FAST: clamped column of this lane's dword
     // byte selector of v_perm_b32: identity, or the first / last byte of the dword four times
     const uint32_t edge_sel = c0 < 0 ? 0x00000000u : (c0 >= W ? 0x03030303u : 0x03020100u);
-    auto issue_load = [&](int r) -> uint32_t { return *reinterpret_cast<const uint32_t *>(rowptr(r) + cc); };
+    // A4 kernels address the frame and its blur plane through raw buffer resources: the base is
+    // wave-uniform (SGPRs), the lane's column offset is one constant VGPR and the row offset an
+    // SGPR, so a row's load / store costs no address arithmetic on the vector ALU.  Range rule
+    // (checked by tools/ubench/buffer_oob_test.hip): an access with voffset >= num_records - soffset
+    // is dropped -- a store with soffset == num_records goes nowhere.
+    constexpr uint32_t RSRC_WORD3 = 0x00020000u;  // raw 32-bit buffer, gfx9
+    const uint32_t blur_bytes = (uint32_t)a.plane * 4u;
+    __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void *)fbase, 0, (int)((uint32_t)H * (uint32_t)a.row_stride), RSRC_WORD3);
+    __amdgpu_buffer_rsrc_t rs_blur = __builtin_amdgcn_make_buffer_rsrc((void *)blur_f, 0, (int)blur_bytes, RSRC_WORD3);
+    auto issue_load = [&](int r) -> uint32_t {
+        const int rr = r < 0 ? 0 : (r > H - 1 ? H - 1 : r);
+        return __builtin_amdgcn_raw_buffer_load_b32(rs_in, cc, rr * a.row_stride, 0);
+    };
     if (FAST) {
 #pragma unroll
         for (int k = 0; k < 7; ++k) ring[k] = issue_load(r0 + k);
@@ -319,10 +331,13 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
             // that the number of memory operations per row is fixed and the compiler can wait
             // with a counted vmcnt(N) instead of draining the stores before every row
             if (store_ok) {
-                float *dst = (b >= ys && b < ye) ? blur_f + (size_t)((a.dbg & 8) ? (b & 7) : b) * W + c0 : a.dummy + c0;
-                if (A4) {  // valid lanes hold 4 in-image pixels
-                    *reinterpret_cast<float4 *>(dst) = make_float4(bc[0], bc[1], bc[2], bc[3]);
+                if (A4) {  // valid lanes hold 4 in-image pixels; rows outside the segment are dropped
+                    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                    const u32x4 v4 = {__float_as_uint(bc[0]), __float_as_uint(bc[1]), __float_as_uint(bc[2]), __float_as_uint(bc[3])};
+                    const uint32_t row_off = (b >= ys && b < ye) ? (uint32_t)((a.dbg & 8) ? (b & 7) : b) * (uint32_t)W * 4u : blur_bytes;
+                    __builtin_amdgcn_raw_buffer_store_b128(v4, rs_blur, c0 * 4, (int)row_off, 0);
                 } else {
+                    float *dst = (b >= ys && b < ye) ? blur_f + (size_t)((a.dbg & 8) ? (b & 7) : b) * W + c0 : a.dummy + c0;
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         if (c0 + j < W) dst[j] = bc[j];
@@ -355,7 +370,7 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) rmin[j] = fminf(rmin[j], dv[j]);
                     }
-                    // refresh the running threshold with exponential back-off (rows 0,1,5,21,85,..).
+                    // refresh the running threshold with exponential back-off (rows 0,1,3,7,15,31,63,..).
                     // The poll of the frame's published minimum is asynchronous: a sync point uses
                     // the value fetched at the previous one and issues the next fetch without
                     // waiting for it (a staler threshold is only a slightly larger superset).
@@ -375,9 +390,11 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
                         // assembler inserts no wait states inside asm: on gfx950 a readlane needs one
                         // after the VALU write of its source, a VALU read of the SGPR two after this)
                         asm("s_nop 0\n\tv_readfirstlane_b32 %0, %1\n\ts_nop 1" : "=s"(thr_run_bits) : "v"(fminf(wmin, gmin) * 0.05f));
-                        polled = __hip_atomic_load(&ctr.min_key_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        // scalar load past the scalar cache: its own counter (lgkmcnt), so the wave does
+                        // not have to drain its blur stores (vmcnt) to read one word
+                        asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(polled) : "s"(&ctr.min_key_inv) : "memory");
                         rows_to_sync = sync_gap;
-                        sync_gap = min(sync_gap * 4, 128);
+                        sync_gap = min(sync_gap * 2, 128);
                     }
                     --rows_to_sync;
                     // Candidate bit of this row: compare -> lane mask (SGPR pair), restricted to the
@@ -1140,7 +1157,9 @@ static hipError_t launch_k1(const ChainArgs &a, hipStream_t st)
 {
     const int units = a.n_strips * a.n_segs;
     dim3 grid((units + 3) / 4, a.n_frames), block(256);
-    if ((a.W & 3) == 0) hipLaunchKernelGGL((k_blur_hessian<FMT, true>), grid, block, 0, st, a);
+    // the aligned form addresses a frame and its blur plane with 32-bit buffer offsets
+    const bool small = a.plane * 4 < (1ll << 31) && (long long)a.H * a.row_stride < (1ll << 31);
+    if ((a.W & 3) == 0 && small) hipLaunchKernelGGL((k_blur_hessian<FMT, true>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((k_blur_hessian<FMT, false>), grid, block, 0, st, a);
     return hipGetLastError();
 }
