@@ -57,6 +57,8 @@ __device__ __forceinline__ float div_const(float v)
     return __builtin_fmaf(e, r, q);
 }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 // Neighbour-lane exchange by DPP wave shifts (one VALU op, no LDS): lane l receives the value
 // of lane l-1 (from_left) or l+1 (from_right); lane 0 / lane 63 receive 0 (bound_ctrl: no
 // destination to initialise).
@@ -194,13 +196,21 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
     // x = -3..3), so the 7 products per pixel are only 4 distinct ones.  The row loop is
     // unrolled by 7 so that the slot of every sum is a compile-time register.
     float acc[7][4];
-    float up[6], mid[6];  // blur rows b-2, b-1 with their edge columns
+    // blur rows b-2, b-1 (and b below) with their edge columns.  The lane's own four values are
+    // one vector value, so that the row store can take them from the register quad they live in.
+    struct Row6 {
+        float l;
+        f32x4 c;
+        float r;
+        __device__ __forceinline__ float operator[](int i) const { return i == 0 ? l : (i == 5 ? r : c[i - 1]); }
+    };
+    Row6 up, mid;
 #pragma unroll
     for (int s7 = 0; s7 < 7; ++s7)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[s7][j] = 0.0f;
-#pragma unroll
-    for (int j = 0; j < 6; ++j) up[j] = mid[j] = 0.0f;
+    up.l = up.r = mid.l = mid.r = 0.0f;
+    up.c = mid.c = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     // Running minimum per pixel column of the lane (a column either always or never takes part in
     // the frame's minimum, so validity is applied when the columns are combined, not per row).
     // A4: columns 1 and 2 share rmin[1].  The frame always contains its zero border ring -> 0.
@@ -306,7 +316,7 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
             // horizontal pass, image_util.rs:137-185: taps in index order, mul then add
             const float x[10] = {from_left(m[1]), from_left(m[2]), from_left(m[3]), m[0], m[1], m[2], m[3],
                                  from_right(m[0]), from_right(m[1]), from_right(m[2])};
-            float bc[4];
+            f32x4 bc;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float v = x[j] * w0;
@@ -333,7 +343,7 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
             if (store_ok) {
                 if (A4) {  // valid lanes hold 4 in-image pixels; rows outside the segment are dropped
                     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-                    const u32x4 v4 = {__float_as_uint(bc[0]), __float_as_uint(bc[1]), __float_as_uint(bc[2]), __float_as_uint(bc[3])};
+                    const u32x4 v4 = __builtin_bit_cast(u32x4, bc);
                     const uint32_t row_off = (b >= ys && b < ye) ? (uint32_t)((a.dbg & 8) ? (b & 7) : b) * (uint32_t)W * 4u : blur_bytes;
                     __builtin_amdgcn_raw_buffer_store_b128(v4, rs_blur, c0 * 4, (int)row_off, 0);
                 } else {
@@ -344,7 +354,10 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
                 }
             }
             // Hessian determinant of row y = b-1 (rows b-2, b-1, b), image_util.rs:88-106
-            const float dn[6] = {from_left(bc[3]), bc[0], bc[1], bc[2], bc[3], from_right(bc[0])};
+            Row6 dn;
+            dn.l = from_left(bc[3]);
+            dn.c = bc;
+            dn.r = from_right(bc[0]);
             const int y = b - 1;
             if (y >= ys && y < ye && !(a.dbg & 4)) {  // wave-uniform
                 if (y > 0 && y < H - 1) {
@@ -451,11 +464,8 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
                     cmax = -__builtin_inff();
                 }
             }
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                up[j] = mid[j];
-                mid[j] = dn[j];
-            }
+            up = mid;
+            mid = dn;
         }
     }
     // per-frame min: wave reduction, one atomic per wave
