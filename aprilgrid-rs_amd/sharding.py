@@ -56,12 +56,13 @@ class GatherPipeline:
         gathered = pipe.finish()             # on dst: (list_of_saddles, list_of_tables) of the LAST step
     """
 
-    def __init__(self, n_frames, device, dst=0, group=None, depth=2):
+    def __init__(self, n_frames, device, dst=0, group=None, depth=2, always_depth=False):
         self.dst, self.group = dst, group
         self.multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
         self.world = dist.get_world_size(group) if self.multi else 1
         self.rank = dist.get_rank(group) if self.multi else 0
-        self.bufs = [alloc_result_buffers(n_frames, device) for _ in range(depth if self.multi else 1)]
+        # one rank alone needs a single buffer pair unless several batches are in flight (ChainPipeline)
+        self.bufs = [alloc_result_buffers(n_frames, device) for _ in range(depth if (self.multi or always_depth) else 1)]
         self.recv = None
         if self.multi and self.rank == dst:
             self.recv = [([torch.empty_like(s) for _ in range(self.world)], [torch.empty_like(t) for _ in range(self.world)])
@@ -99,6 +100,65 @@ class GatherPipeline:
         if not self.multi:
             return [self.bufs[self.i][0]], [self.bufs[self.i][1]]
         return self.recv[self.i] if self.rank == self.dst else (None, None)
+
+
+class ChainPipeline:
+    """Several batches in flight on one GPU: `depth` detectors, each with its own workspace and HIP
+    stream, take the batches in turn, so that the dense kernel (K1) of batch i+1 runs while the
+    sparse kernels (verify .. filter) of batch i -- short, latency-bound launches that leave most
+    of the chip idle -- are still going.  Results go to `depth` device buffer pairs and, with
+    several ranks, through the asynchronous gather of GatherPipeline.
+
+        pipe = ChainPipeline(tag_family, n_frames, device, depth=2)
+        for frames in batches:            # [n_frames, H, W] uint8 device tensors
+            pipe.submit(frames)           # ordered behind the current stream's work on `frames`
+        saddles, tables = pipe.finish()   # results of the LAST batch (lists over ranks on dst)
+    """
+
+    def __init__(self, tag_family, n_frames, device, depth=2, params=None, dst=0, group=None):
+        from .detector import TagDetector
+        dev = torch.device(device)
+        index = dev.index if dev.index is not None else torch.cuda.current_device()
+        self.device = dev
+        # (more streams than the runtime's 4 hardware queues serialise badly: measured 10 ms/step at 4)
+        self.depth = min(max(1, int(depth)), 3)
+        self.dets = [TagDetector(tag_family, params, device=index) for _ in range(self.depth)]
+        # depth 1 stays on the caller's stream (no cross-stream events at all)
+        self.streams = [torch.cuda.Stream(dev) for _ in range(self.depth)] if self.depth > 1 else [None]
+        self.gather = GatherPipeline(n_frames, dev, dst=dst, group=group, depth=max(2, self.depth),
+                                     always_depth=self.depth > 1)
+        self.i = -1
+        self.last_table = None
+
+    def submit(self, frames):
+        """Enqueue one batch; returns the index of the detector that took it."""
+        self.i = (self.i + 1) % self.depth
+        det, st = self.dets[self.i], self.streams[self.i]
+        if st is None:
+            out, table = self.gather.acquire()
+            det.saddles_batch_enqueue_to(frames, out, table)
+            self.gather.submit()
+        else:
+            st.wait_stream(torch.cuda.current_stream(self.device))  # the frames' producer
+            with torch.cuda.stream(st):
+                out, table = self.gather.acquire()
+                det.saddles_batch_enqueue_to(frames, out, table)
+                self.gather.submit()
+        self.last_table = table
+        return self.i
+
+    def finish(self):
+        """Wait for everything in flight; results of the last submitted batch."""
+        res = self.gather.finish()
+        for st in self.streams:
+            if st is not None:
+                st.synchronize()
+        return res
+
+    def close(self):
+        for d in self.dets:
+            d.close()
+        self.dets = []
 
 
 def unpack_frames(saddles, table):

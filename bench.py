@@ -47,6 +47,11 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--noise", action="store_true", help="pure-noise frames (sensitivity row)")
+    ap.add_argument("--pipeline", type=int, default=1,
+                    help="batches in flight per GPU in the timed region (detectors on separate HIP streams; "
+                         "1 = strictly serial: value, ms_per_step and roofline then describe the same launches)")
+    ap.add_argument("--extra-pipeline", type=int, default=3,
+                    help="N = 1 only: a second, separately reported timed pass with this many batches in flight (0 = skip)")
     ap.add_argument("--pmc-traffic", type=float, default=None,
                     help="HBM bytes per K1 launch from a separate rocprofv3 --pmc run (profiles/)")
     return ap.parse_args()
@@ -120,20 +125,14 @@ def main():
     del base
     px_per_step_rank = F * W * H
 
-    det = A.TagDetector(A.TagFamily.T36H11, None, device=local_rank)
-    stream = torch.cuda.current_stream(dev)
-    det.set_stream(stream.cuda_stream)  # kernels, events and the RCCL gather share torch's stream order
-
-    # result buffers stay in HBM; for N > 1 they are double-buffered and gathered to rank 0
-    # asynchronously (RCCL over xGMI), so the gather of step i overlaps the chain of step i+1
-    pipe = sharding.GatherPipeline(F, dev, dst=0)
-    last = {}
+    # `--pipeline` detectors (own workspace + HIP stream each) take the steps in turn: K1 of step
+    # i+1 overlaps the short, latency-bound sparse kernels of step i.  Result buffers stay in
+    # HBM; for N > 1 they are gathered to rank 0 asynchronously (RCCL over xGMI) -- the one
+    # collective of the path -- so the gather of a step overlaps the chain of the next.
+    pipe = sharding.ChainPipeline(A.TagFamily.T36H11, F, dev, depth=args.pipeline, dst=0)
 
     def step():
-        out_saddles, table = pipe.acquire()
-        det.saddles_batch_enqueue_to(frames, out_saddles, table)
-        pipe.submit()  # the one collective of the path: result gather to rank 0
-        last["table"] = table
+        pipe.submit(frames)
 
     def fence():
         pipe.finish()
@@ -145,30 +144,57 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    tb = last["table"].cpu().numpy()
+    tb = pipe.last_table.cpu().numpy()
     assert (tb[:, 2] & 7 == 0).all(), "capacity overflow in the bench workload: %s" % tb[tb[:, 2] != 0][:4]
     generic_frames = int(((tb[:, 2] & 16) != 0).sum())
     saddles_per_frame = float(tb[:, 0].mean())
     clusters_per_frame = float(tb[:, 3].mean())
 
     # timed region: hipEvents (on the launch stream) around K1 only -- 2 records per step
-    det.profile_enable(1)
-    det.profile_reset()
+    for d in pipe.dets:
+        d.profile_enable(1)
+        d.profile_reset()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     dt = time.perf_counter() - t0
-    k1_prof = det.profile_read()["k_blur_hessian"]
-    # separate, untimed pass for the per-kernel breakdown (events around every launch)
+    k1_ms, k1_n = 0.0, 0
+    for d in pipe.dets:
+        ms, n = d.profile_read()["k_blur_hessian"]
+        k1_ms, k1_n = k1_ms + ms, k1_n + n
+        d.profile_enable(0)
+    # separate, untimed pass for the per-kernel breakdown: one detector, strictly serial, events
+    # around every launch (each kernel alone on the GPU)
+    det = pipe.dets[0]
+    out_s, out_t = sharding.alloc_result_buffers(F, dev)
     det.profile_enable(2)
     det.profile_reset()
     for _ in range(min(args.steps, 10)):
-        step()
+        det.saddles_batch_enqueue_to(frames, out_s, out_t)
     fence()
     prof = det.profile_read()
     det.profile_enable(0)
+
+    # N = 1: the same K steps again with several batches in flight (reported as "pipelined")
+    pipelined = None
+    if world == 1 and args.extra_pipeline > 1 and args.pipeline == 1:
+        pipe2 = sharding.ChainPipeline(A.TagFamily.T36H11, F, dev, depth=args.extra_pipeline, dst=0)
+        for _ in range(max(args.warmup, pipe2.depth)):
+            pipe2.submit(frames)
+        pipe2.finish()
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            pipe2.submit(frames)
+        pipe2.finish()
+        torch.cuda.synchronize(dev)
+        dt2 = time.perf_counter() - t1
+        pipelined = {"batches_in_flight": pipe2.depth, "ms_per_step": round(1e3 * dt2 / args.steps, 4),
+                     "value": round(px_per_step_rank * args.steps / dt2 / 1e6, 1), "unit": "Mpix/s",
+                     "note": "K1 of one batch overlaps the sparse kernels of the previous one (sharding.ChainPipeline)"}
+        pipe2.close()
 
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -181,8 +207,8 @@ def main():
         ms_per_step = 1e3 * dt / args.steps
         mpix = total_px / dt / 1e6
         in_b = IN_BYTES[args.format]
-        k1_ms, k1_n = k1_prof
         k1_avg_ms = k1_ms / max(k1_n, 1)
+        k1_alone_ms = prof["k_blur_hessian"][0] / max(prof["k_blur_hessian"][1], 1)
         # K1 reads the input once, writes the blur plane (f32) and 1 bit / px of candidate mask
         k1_bytes = px_per_step_rank * (in_b + 4 + 0.125)
         k1_gbps = k1_bytes / (k1_avg_ms * 1e-3) / 1e9
@@ -224,6 +250,7 @@ def main():
                 "saddles_per_frame": round(saddles_per_frame, 1),
                 "clusters_per_frame": round(clusters_per_frame, 1),
                 "parallelism": "frame-sharded x%d, RCCL gather of result slabs" % world if world > 1 else "1 GPU",
+                "batches_in_flight": pipe.depth,
             },
             "roofline": {
                 "kernel": "k_blur_hessian (K1)",
@@ -238,6 +265,10 @@ def main():
                 "bytes_per_launch": k1_bytes,
                 "avg_launch_ms": round(k1_avg_ms, 5),
                 "launches_timed": k1_n,
+                # the same kernel alone on the GPU (serial pass below the timed region): with
+                # --pipeline > 1 the timed launches share the chip with another step's sparse kernels
+                "alone_avg_launch_ms": round(k1_alone_ms, 5),
+                "alone_frac": round(k1_bytes / (k1_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
             },
             "chain": {
                 "a_mat_bytes_per_px": a_mat,
@@ -250,6 +281,8 @@ def main():
                 "frames_on_generic_path": generic_frames,
             },
         }
+        if pipelined:
+            result["pipelined"] = pipelined
         if world == 1 and not args.no_cpu_baseline:
             sample = frames[:uniq].cpu().numpy()
             if args.format == "L16":
@@ -257,7 +290,7 @@ def main():
             result["cpu_baseline"] = cpu_baseline(sample, args.format, args.cpu_seconds)
             result["cpu_baseline"]["host_cores_available"] = os.cpu_count()
         print(json.dumps(result), flush=True)
-    det.close()
+    pipe.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -176,6 +176,47 @@ def test_batch_matches_oracle_and_is_deterministic(det, oracle):
             assert np.min(np.hypot(*(g - p).T)) < 0.5
 
 
+@pytest.mark.parametrize("depth", [1, 2, 3])
+def test_chain_pipeline_batches_in_flight(det, oracle, depth):
+    """Several batches in flight on separate streams (sharding.ChainPipeline): every batch's
+    device-resident result must equal what one detector gives for that batch alone."""
+    import torch
+    import aprilgrid_rs_amd as A
+    from aprilgrid_rs_amd import sharding
+    synth = synth_module()
+    batches = [synth.render_batch(100 + 10 * b, 4, 480, 320, device="cuda")[0] for b in range(5)]
+    want = []
+    for fr in batches:
+        det.saddles_batch_enqueue(fr)
+        res, status = det.saddles_batch_fetch()
+        assert (status == 0).all()
+        want.append(res)
+    ref0 = oracle.refined_saddle_points(batches[0][0].cpu().numpy())
+    check_saddles(want[0][0], ref0, "pipeline reference frame")
+    pipe = sharding.ChainPipeline(A.TagFamily.T36H11, 4, torch.device("cuda", 0), depth=depth)
+    try:
+        kept = []
+        for b, fr in enumerate(batches):
+            pipe.submit(fr)
+            slot = pipe.gather.i
+            kept.append((b, pipe.gather.bufs[slot]))
+            # a slot is reused `len(bufs)` submissions later: collect the batch that is about to be overwritten
+            if len(kept) == len(pipe.gather.bufs):
+                pipe.finish()
+                for bb, (s_buf, t_buf) in kept:
+                    got = sharding.unpack_frames(s_buf, t_buf)
+                    for i in range(4):
+                        assert got[i] is not None
+                        g = np.zeros(len(got[i]), want[bb][i].dtype)
+                        for j, f in enumerate(("x", "y", "k", "theta", "phi")):
+                            g[f] = got[i][:, j]
+                        assert g.tobytes() == want[bb][i].tobytes(), "batch %d frame %d" % (bb, i)
+                kept = []
+        pipe.finish()
+    finally:
+        pipe.close()
+
+
 @pytest.mark.parametrize("fmt", ["L16", "RGB8"])
 def test_batch_other_formats(det, oracle, fmt):
     synth = synth_module()
