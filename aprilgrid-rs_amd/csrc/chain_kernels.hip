@@ -483,7 +483,7 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_verify(ChainArgs a)
 {
-    const int frame = blockIdx.y;
+    const int frame = (int)(gridDim.y - 1 - blockIdx.y);  // latest-written blur planes first (cache)
     const FrameCounters &ctr = a.ctr[frame];
     const float thr = f32_from_order_key(~ctr.min_key_inv) * 0.05f;
     uint32_t *mask = a.mask + (size_t)frame * (size_t)a.mask_plane;
@@ -914,7 +914,7 @@ __global__ void k_debug_resp(const float *__restrict__ blur, float *__restrict__
 template <bool VEC>
 __global__ void __launch_bounds__(64, 4) k_refine(ChainArgs a, RefineConsts rc)
 {
-    const int frame = blockIdx.y;
+    const int frame = (int)(gridDim.y - 1 - blockIdx.y);  // latest-written blur planes first (cache)
     if (a.ctr[frame].flags & (FLAG_CAND_OVERFLOW | FLAG_ROOT_OVERFLOW)) return;
     const uint32_t n = min(a.ctr[frame].n_clusters, a.cap_roots);
     const size_t cbase = (size_t)frame * a.cap_roots;
