@@ -17,10 +17,10 @@ for k, v in agg.items(): print("%-12s %-10s mean %.1f KB per launch of 1048576 K
 PY
 done
 cat $OUT/calibration.txt
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/stats_$TAG -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/stats_$TAG -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --extra-pipeline 0 > $OUT/bench_under_rocprof.json 2> /dev/null
 S=$(find /tmp/stats_$TAG -name "*kernel_stats.csv" | head -1); (head -1 $S; grep "agx::" $S) > $OUT/kernel_stats.csv; cat $OUT/kernel_stats.csv | cut -c1-120
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/pmc_$TAG_$C -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/pmc_$TAG_$C -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --extra-pipeline 0 --settle-ms 0 > /dev/null 2>&1
   python3 - /tmp/pmc_$TAG_$C $C >> $OUT/traffic.txt <<'PY'
 import csv, glob, sys, collections
 f = glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)[0]
