@@ -289,7 +289,7 @@ def test_oversized_components_take_second_tier_and_generic_path(det, oracle):
 def test_capacity_overflow_is_reported_not_truncated(oracle):
     import aprilgrid_rs_amd as A
     d = A.TagDetector("T36H11", None, device=0)
-    d.set_limits(max_candidates=4096, max_clusters=1024, max_saddles=256)
+    d.set_limits(max_candidates=4096, max_clusters=256, max_saddles=64)
     img = load_image("EuRoC.png")
     with pytest.raises(A.AgxError) as e:
         d.refined_saddle_points(img)
