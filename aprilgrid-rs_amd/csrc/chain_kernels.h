@@ -11,7 +11,7 @@ enum Kernel : int {
     K_THRESHOLD = 1,     // K2: verify K1's candidate superset mask against the final threshold
                          //     (exact response recomputed from the blur plane at set bits only),
                          //     then mask scan -> flood seeds
-    K_FLOOD = 2,         // K3: bit-parallel flood fill per seed -> cluster records
+    K_FLOOD = 2,         // K3: bit-parallel flood fill per seed (32x32 per lane, 128x64 per wave) -> cluster records
     K_GENERIC = 3,       // K3g: guarded fallback (4 launches) for frames with oversized clusters
     K_REFINE = 4,        // K4: rochade_refine per cluster
     K_FILTER_SORT = 5,   // K5: k/phi filter, reference-order emission
@@ -38,7 +38,7 @@ struct FrameCounters {
     uint32_t out_offset;   // start of this frame's saddles in the compact output array
     uint32_t n_cand;       // generic path: candidate pixels
     uint32_t n_roots;      // generic path: union-find roots
-    uint32_t n_big;        // seeds handed to the block-wide flood
+    uint32_t n_big;        // seeds handed to the wave-wide second flood tier
     uint32_t pad1[22];
 };
 enum : uint32_t {
@@ -95,7 +95,6 @@ struct ChainArgs {
     uint32_t *total_out;  // single counter: compact output allocation
     uint32_t cap_cand, cap_roots, cap_out;
     uint32_t *seeds;      // [n_frames][cap_roots] pixel index of each flood seed
-    uint32_t *big_seeds;  // [n_frames][cap_roots] seeds whose component left the 32x32 window
     // cluster records [n_frames][cap_roots]
     uint32_t *clu_key;    // smallest pixel index of the cluster
     uint32_t *clu_cnt;

@@ -575,7 +575,7 @@ __global__ void __launch_bounds__(256) k_seeds(ChainArgs a)
 // the mask that contain a set bit with a carry-propagation add (fill_runs).  The seed is the
 // canonical one iff its component contains no pixel with a smaller raster index: then the lane
 // emits the cluster with exact integer sums.  A component that touches the window's left /
-// right / bottom edge may continue outside: its seed goes to the second tier (k_flood_block,
+// right / bottom edge may continue outside: it goes to the second tier (wave_flood_128x64,
 // 128 x 64 window); a component that leaves that window too sets FLAG_BIG_CLUSTER and the
 // whole frame is redone by the generic kernels.
 // ------------------------------------------------------------------------------------------
@@ -597,91 +597,11 @@ __device__ __forceinline__ uint32_t bitpos_sum(uint32_t c)
 
 constexpr int FLOOD_COLS = 32;
 
-__global__ void __launch_bounds__(64) k_flood(ChainArgs a)
-{
-    const int frame = blockIdx.y;
-    FrameCounters &ctr = a.ctr[frame];
-    if (ctr.flags & FLAG_CAND_OVERFLOW) return;
-    const uint32_t n = min(ctr.n_seeds, a.cap_roots);
-    const uint32_t *mask = a.mask + (size_t)frame * (size_t)a.mask_plane;
-    const uint32_t W = (uint32_t)a.W;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint32_t p = a.seeds[(size_t)frame * a.cap_roots + i];
-        const uint32_t sx = p % W, sy = p / W;
-        const int sh = (int)((sy - 1u) & 31u);
-        const uint32_t *wp = mask + (size_t)((sy - 1u) >> 5) * a.mask_wpr + MASK_PAD_X + ((int)sx - 16);
-        uint32_t cand[FLOOD_COLS], comp[FLOOD_COLS];
-#pragma unroll
-        for (int c = 0; c < FLOOD_COLS; ++c) {
-            const unsigned long long two = (unsigned long long)wp[c] | ((unsigned long long)wp[a.mask_wpr + c] << 32);
-            cand[c] = (uint32_t)(two >> sh);  // bit r = row sy-1+r of column sx-16+c
-            comp[c] = 0u;
-        }
-        comp[16] = 2u;  // the seed: column sx, row sy
-        uint32_t changed;
-        do {
-            changed = 0u;
-#pragma unroll
-            for (int c = 0; c < FLOOD_COLS; ++c) {  // left-to-right sweep
-                uint32_t s = comp[c];
-                if (c > 0) s |= comp[c - 1];
-                if (c < FLOOD_COLS - 1) s |= comp[c + 1];
-                const uint32_t f = fill_runs(s & cand[c], cand[c]);
-                changed |= f ^ comp[c];
-                comp[c] = f;
-            }
-#pragma unroll
-            for (int c = FLOOD_COLS - 1; c >= 0; --c) {  // right-to-left sweep
-                uint32_t s = comp[c];
-                if (c > 0) s |= comp[c - 1];
-                if (c < FLOOD_COLS - 1) s |= comp[c + 1];
-                const uint32_t f = fill_runs(s & cand[c], cand[c]);
-                changed |= f ^ comp[c];
-                comp[c] = f;
-            }
-        } while (changed);
-        uint32_t all = 0u, left_of_seed = 0u;
-#pragma unroll
-        for (int c = 0; c < FLOOD_COLS; ++c) {
-            all |= comp[c];
-            if (c < 16) left_of_seed |= comp[c];
-        }
-        // a pixel of the component precedes the seed in raster order -> not the canonical seed
-        if ((all & 1u) || (left_of_seed & 2u)) continue;
-        if ((all >> 31) || comp[0] || comp[FLOOD_COLS - 1]) {  // may continue outside the window
-            const uint32_t o = atomicAdd(&ctr.n_big, 1u);
-            if (o < a.cap_roots) a.big_seeds[(size_t)frame * a.cap_roots + o] = p;
-            else atomicOr(&ctr.flags, FLAG_BIG_CLUSTER);
-            continue;
-        }
-        uint32_t cnt = 0, sumx = 0, sumy = 0;
-#pragma unroll
-        for (int c = 0; c < FLOOD_COLS; ++c) {
-            const uint32_t w = comp[c];
-            const uint32_t nc = (uint32_t)__popc(w);
-            cnt += nc;
-            sumy += bitpos_sum(w);
-            sumx += nc * (uint32_t)c;
-        }
-        sumx += cnt * (sx - 16u);  // window column 0 is image column sx-16 (mod 2^32 arithmetic)
-        sumy += cnt * (sy - 1u);   // window row 0 is image row sy-1
-        const uint32_t o = atomicAdd(&ctr.n_clusters, 1u);
-        if (o < a.cap_roots) {
-            const size_t q = (size_t)frame * a.cap_roots + o;
-            a.clu_key[q] = p;
-            a.clu_cnt[q] = cnt;
-            a.clu_sx[q] = sumx;
-            a.clu_sy[q] = sumy;
-        } else {
-            atomicOr(&ctr.flags, FLAG_ROOT_OVERFLOW);
-        }
-    }
-}
-
-// K3 second tier: one 128-thread workgroup per oversized component.  Thread t holds column
-// sx-64+t of a 128-column x 64-row window [sy-1, sy+62] as a 64-bit word (bit = row); each round
-// ORs the two neighbouring columns (through LDS) and fills vertical runs; rounds repeat until
-// no column changes.
+// Second tier, wave-wide: lane t holds columns sx-64+2t and sx-63+2t of a 128-column x 64-row
+// window [sy-1, sy+62] as two 64-bit words (bit = row); each round ORs the neighbouring columns
+// (own pair + DPP from the adjacent lanes) and fills vertical runs; rounds repeat until no column
+// changes.  All 64 lanes of the wave take part.  Returns nothing: emits the cluster, or flags the
+// frame for the generic path when the component leaves this window too.
 __device__ __forceinline__ unsigned long long brev64(unsigned long long v)
 {
     return ((unsigned long long)__brev((uint32_t)v) << 32) | (unsigned long long)__brev((uint32_t)(v >> 32));
@@ -699,76 +619,166 @@ __device__ __forceinline__ uint32_t bitpos_sum64(unsigned long long c)
            4u * (uint32_t)__popcll(c & 0xF0F0F0F0F0F0F0F0ull) + 8u * (uint32_t)__popcll(c & 0xFF00FF00FF00FF00ull) +
            16u * (uint32_t)__popcll(c & 0xFFFF0000FFFF0000ull) + 32u * (uint32_t)__popcll(c & 0xFFFFFFFF00000000ull);
 }
-
-__global__ void __launch_bounds__(128) k_flood_block(ChainArgs a)
+__device__ __forceinline__ unsigned long long from_left_u64(unsigned long long v)
 {
-    __shared__ unsigned long long s_comp[130];
-    __shared__ int s_changed[2];
-    __shared__ uint32_t s_sum[3];
+    return (unsigned long long)from_left_u((uint32_t)v) | ((unsigned long long)from_left_u((uint32_t)(v >> 32)) << 32);
+}
+__device__ __forceinline__ unsigned long long from_right_u64(unsigned long long v)
+{
+    return (unsigned long long)from_right_u((uint32_t)v) | ((unsigned long long)from_right_u((uint32_t)(v >> 32)) << 32);
+}
+
+__device__ __forceinline__ void wave_flood_128x64(const ChainArgs &a, int frame, FrameCounters &ctr, const uint32_t *mask,
+                                                  uint32_t p, int lane)
+{
+    const uint32_t W = (uint32_t)a.W;
+    const uint32_t sx = p % W, sy = p / W;
+    const int sh = (int)((sy - 1u) & 31u);
+    const uint32_t *wp = mask + (size_t)((sy - 1u) >> 5) * a.mask_wpr + MASK_PAD_X + ((int)sx - 64) + 2 * lane;
+    unsigned long long cand[2], comp[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const unsigned long long w01 = (unsigned long long)wp[c] | ((unsigned long long)wp[a.mask_wpr + c] << 32);
+        const unsigned long long w2 = wp[2 * a.mask_wpr + c];
+        cand[c] = sh ? ((w01 >> sh) | (w2 << (64 - sh))) : w01;  // bit r = row sy-1+r
+        comp[c] = 0ull;
+    }
+    if (lane == 32) comp[0] = 2ull;  // the seed: column sx (window column 64), row sy
+    for (;;) {
+        const unsigned long long from_l = from_left_u64(comp[1]);   // column left of this lane's pair
+        const unsigned long long from_r = from_right_u64(comp[0]);  // column right of it
+        const unsigned long long f0 = fill_runs64((comp[0] | from_l | comp[1]) & cand[0], cand[0]);
+        const unsigned long long f1 = fill_runs64((comp[1] | comp[0] | from_r) & cand[1], cand[1]);
+        const bool ch = f0 != comp[0] || f1 != comp[1];
+        comp[0] = f0;
+        comp[1] = f1;
+        if (!__any(ch)) break;
+    }
+    const unsigned long long both = comp[0] | comp[1];
+    // not the canonical seed: a pixel of the component precedes it in raster order
+    const bool earlier = (both & 1ull) != 0ull || (lane < 32 && (both & 2ull) != 0ull);
+    const bool edge = (lane == 0 && comp[0] != 0ull) || (lane == 63 && comp[1] != 0ull) || (both >> 63) != 0ull;
+    if (__any(earlier)) return;
+    if (__any(edge)) {
+        if (lane == 0) atomicOr(&ctr.flags, FLAG_BIG_CLUSTER);
+        return;
+    }
+    const uint32_t n0 = (uint32_t)__popcll(comp[0]), n1 = (uint32_t)__popcll(comp[1]);
+    const uint32_t x0 = sx - 64u + 2u * (uint32_t)lane;
+    uint32_t s_n = n0 + n1, s_x = n0 * x0 + n1 * (x0 + 1u), s_y = bitpos_sum64(comp[0]) + bitpos_sum64(comp[1]) + (n0 + n1) * (sy - 1u);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s_n += __shfl_xor(s_n, off, 64);
+        s_x += __shfl_xor(s_x, off, 64);
+        s_y += __shfl_xor(s_y, off, 64);
+    }
+    if (lane == 0) {
+        const uint32_t o = atomicAdd(&ctr.n_clusters, 1u);
+        if (o < a.cap_roots) {
+            const size_t q = (size_t)frame * a.cap_roots + o;
+            a.clu_key[q] = p;
+            a.clu_cnt[q] = s_n;
+            a.clu_sx[q] = s_x;
+            a.clu_sy[q] = s_y;
+        } else {
+            atomicOr(&ctr.flags, FLAG_ROOT_OVERFLOW);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(64) k_flood(ChainArgs a)
+{
     const int frame = blockIdx.y;
     FrameCounters &ctr = a.ctr[frame];
-    const uint32_t n = min(ctr.n_big, a.cap_roots);
-    if (n == 0) return;
-    const int t = threadIdx.x;
+    if (ctr.flags & FLAG_CAND_OVERFLOW) return;
+    const uint32_t n = min(ctr.n_seeds, a.cap_roots);
     const uint32_t *mask = a.mask + (size_t)frame * (size_t)a.mask_plane;
     const uint32_t W = (uint32_t)a.W;
-    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
-        const uint32_t p = a.big_seeds[(size_t)frame * a.cap_roots + i];
-        const uint32_t sx = p % W, sy = p / W;
-        const int sh = (int)((sy - 1u) & 31u);
-        const uint32_t *wp = mask + (size_t)((sy - 1u) >> 5) * a.mask_wpr + MASK_PAD_X + ((int)sx - 64) + t;
-        const unsigned long long w01 = (unsigned long long)wp[0] | ((unsigned long long)wp[a.mask_wpr] << 32);
-        const unsigned long long w2 = wp[2 * a.mask_wpr];
-        const unsigned long long cand = sh ? ((w01 >> sh) | (w2 << (64 - sh))) : w01;  // bit r = row sy-1+r
-        unsigned long long comp = (t == 64) ? 2ull : 0ull;  // the seed: column sx, row sy
-        if (t == 0) {
-            s_comp[0] = 0ull;
-            s_comp[129] = 0ull;
-            s_changed[0] = s_changed[1] = 0;
-            s_sum[0] = s_sum[1] = s_sum[2] = 0u;
-        }
-        __syncthreads();
-        for (int it = 0;; ++it) {
-            s_comp[t + 1] = comp;
-            if (t == 0) s_changed[(it + 1) & 1] = 0;
-            __syncthreads();
-            const unsigned long long f = fill_runs64((comp | s_comp[t] | s_comp[t + 2]) & cand, cand);
-            if (f != comp) s_changed[it & 1] = 1;
-            comp = f;
-            __syncthreads();
-            if (!s_changed[it & 1]) break;
-        }
-        // not the canonical seed: a pixel of the component precedes it in raster order
-        const int earlier = ((comp & 1ull) != 0ull) || (t < 64 && (comp & 2ull) != 0ull);
-        const int edge = ((t == 0 || t == 127) && comp != 0ull) || ((comp >> 63) != 0ull);
-        const int any_earlier = __syncthreads_or(earlier);
-        const int any_edge = __syncthreads_or(edge);
-        if (!any_earlier) {
-            if (any_edge) {
-                if (t == 0) atomicOr(&ctr.flags, FLAG_BIG_CLUSTER);
-            } else {
-                const uint32_t nc = (uint32_t)__popcll(comp);
-                if (nc) {
-                    atomicAdd(&s_sum[0], nc);
-                    atomicAdd(&s_sum[1], nc * (sx - 64u + (uint32_t)t));
-                    atomicAdd(&s_sum[2], bitpos_sum64(comp) + nc * (sy - 1u));
+    const int lane = threadIdx.x;
+    for (uint32_t base = blockIdx.x * 64u; base < n; base += gridDim.x * 64u) {  // wave-uniform trip count
+        const uint32_t i = base + (uint32_t)lane;
+        uint32_t p = 0u;
+        bool big = false;
+        if (i < n) {
+            p = a.seeds[(size_t)frame * a.cap_roots + i];
+            const uint32_t sx = p % W, sy = p / W;
+            const int sh = (int)((sy - 1u) & 31u);
+            const uint32_t *wp = mask + (size_t)((sy - 1u) >> 5) * a.mask_wpr + MASK_PAD_X + ((int)sx - 16);
+            uint32_t cand[FLOOD_COLS], comp[FLOOD_COLS];
+#pragma unroll
+            for (int c = 0; c < FLOOD_COLS; ++c) {
+                const unsigned long long two = (unsigned long long)wp[c] | ((unsigned long long)wp[a.mask_wpr + c] << 32);
+                cand[c] = (uint32_t)(two >> sh);  // bit r = row sy-1+r of column sx-16+c
+                comp[c] = 0u;
+            }
+            comp[16] = 2u;  // the seed: column sx, row sy
+            uint32_t changed;
+            do {
+                changed = 0u;
+#pragma unroll
+                for (int c = 0; c < FLOOD_COLS; ++c) {  // left-to-right sweep
+                    uint32_t s = comp[c];
+                    if (c > 0) s |= comp[c - 1];
+                    if (c < FLOOD_COLS - 1) s |= comp[c + 1];
+                    const uint32_t f = fill_runs(s & cand[c], cand[c]);
+                    changed |= f ^ comp[c];
+                    comp[c] = f;
                 }
-                __syncthreads();
-                if (t == 0) {
+#pragma unroll
+                for (int c = FLOOD_COLS - 1; c >= 0; --c) {  // right-to-left sweep
+                    uint32_t s = comp[c];
+                    if (c > 0) s |= comp[c - 1];
+                    if (c < FLOOD_COLS - 1) s |= comp[c + 1];
+                    const uint32_t f = fill_runs(s & cand[c], cand[c]);
+                    changed |= f ^ comp[c];
+                    comp[c] = f;
+                }
+            } while (changed);
+            uint32_t all = 0u, left_of_seed = 0u;
+#pragma unroll
+            for (int c = 0; c < FLOOD_COLS; ++c) {
+                all |= comp[c];
+                if (c < 16) left_of_seed |= comp[c];
+            }
+            // a pixel of the component precedes the seed in raster order -> not the canonical seed
+            const bool canonical = !((all & 1u) || (left_of_seed & 2u));
+            if (canonical) {
+                if ((all >> 31) || comp[0] || comp[FLOOD_COLS - 1]) {
+                    big = true;  // may continue outside the window: second tier below
+                } else {
+                    uint32_t cnt = 0, sumx = 0, sumy = 0;
+#pragma unroll
+                    for (int c = 0; c < FLOOD_COLS; ++c) {
+                        const uint32_t w = comp[c];
+                        const uint32_t nc = (uint32_t)__popc(w);
+                        cnt += nc;
+                        sumy += bitpos_sum(w);
+                        sumx += nc * (uint32_t)c;
+                    }
+                    sumx += cnt * (sx - 16u);  // window column 0 is image column sx-16 (mod 2^32 arithmetic)
+                    sumy += cnt * (sy - 1u);   // window row 0 is image row sy-1
                     const uint32_t o = atomicAdd(&ctr.n_clusters, 1u);
                     if (o < a.cap_roots) {
                         const size_t q = (size_t)frame * a.cap_roots + o;
                         a.clu_key[q] = p;
-                        a.clu_cnt[q] = s_sum[0];
-                        a.clu_sx[q] = s_sum[1];
-                        a.clu_sy[q] = s_sum[2];
+                        a.clu_cnt[q] = cnt;
+                        a.clu_sx[q] = sumx;
+                        a.clu_sy[q] = sumy;
                     } else {
                         atomicOr(&ctr.flags, FLAG_ROOT_OVERFLOW);
                     }
                 }
             }
         }
-        __syncthreads();
+        // oversized components (about 0.5 % of the seeds on real frames): the whole wave floods a
+        // 128 x 64 window for each of them in turn
+        unsigned long long bigm = __ballot(big);
+        if (bigm && lane == 0) atomicAdd(&ctr.n_big, (uint32_t)__popcll(bigm));
+        while (bigm) {
+            const int src = __ffsll((long long)bigm) - 1;
+            bigm &= bigm - 1ull;
+            wave_flood_128x64(a, frame, ctr, mask, __shfl(p, src, 64), lane);
+        }
     }
 }
 
@@ -1220,8 +1230,6 @@ int launch_kernel(int which, const ChainArgs &a, const RefineConsts &rc, void *s
     case K_FLOOD: {
         dim3 grid(sparse_grid_x(a, 48, "AGX_G_FLOOD"), a.n_frames), block(64);
         hipLaunchKernelGGL(k_flood, grid, block, 0, st, a);
-        dim3 grid2(sparse_grid_x(a, 4), a.n_frames), block2(128);
-        hipLaunchKernelGGL(k_flood_block, grid2, block2, 0, st, a);
         return hipGetLastError();
     }
     case K_GENERIC: {

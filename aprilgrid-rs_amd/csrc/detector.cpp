@@ -246,7 +246,6 @@ int ensure_workspace(agx_detector *d, int n_frames, int W, int H)
     if ((rc = dev_alloc(d, a.ctr, F + 1))) return rc;  // + one extra record: its first word is total_out
     a.total_out = &a.ctr[F].min_key_inv;
     if ((rc = dev_alloc(d, a.seeds, F * cap_roots))) return rc;
-    if ((rc = dev_alloc(d, a.big_seeds, F * cap_roots))) return rc;
     if ((rc = dev_alloc(d, a.clu_key, F * cap_roots))) return rc;
     if ((rc = dev_alloc(d, a.clu_cnt, F * cap_roots))) return rc;
     if ((rc = dev_alloc(d, a.clu_sx, F * cap_roots))) return rc;
@@ -314,7 +313,6 @@ int enqueue_chunk(agx_detector *d, int f0, int nf, hipStream_t st)
     a.mask += F0 * (size_t)a.mask_plane;
     a.ctr += F0;
     a.seeds += F0 * a.cap_roots;
-    a.big_seeds += F0 * a.cap_roots;
     a.clu_key += F0 * a.cap_roots;
     a.clu_cnt += F0 * a.cap_roots;
     a.clu_sx += F0 * a.cap_roots;
