@@ -154,6 +154,101 @@ public:
         return m;
     }
 
+    // The board search asks the same questions over and over: every query point of
+    // find_closest_potential_saddle_idxs (board.rs:177-233) is a function of an ordered pair of
+    // saddles, and a board is built for every candidate quad of up to 30 seeds.  The candidates of
+    // both query points of a pair -- 3 nearest neighbours, filtered by the radius and the saddle
+    // angle, which do not depend on the board -- are memoised per (i0, i1) in an open-addressing
+    // table; only the board's own "still unused" test is applied per call.
+    struct PairCands {
+        uint64_t key = 0;  // 0 = empty slot
+        int idx[2][3];
+        int n[2];
+    };
+    const PairCands &pair_candidates(int i0, int i1, float spacing_ratio)
+    {
+        const uint64_t key = 1ull + ((uint64_t)(uint32_t)i0 << 32 | (uint64_t)(uint32_t)i1);
+        if (pair_tab_.empty()) pair_tab_.resize(1u << 12);
+        for (;;) {
+            const size_t mask = pair_tab_.size() - 1;
+            size_t h = (size_t)((key * 0x9E3779B97F4A7C15ull) >> 32) & mask;
+            while (pair_tab_[h].key != 0ull && pair_tab_[h].key != key) h = (h + 1) & mask;
+            if (pair_tab_[h].key == key) return pair_tab_[h];
+            if (pair_used_ * 2 >= pair_tab_.size()) {  // grow and re-insert, then look the slot up again
+                std::vector<PairCands> bigger(pair_tab_.size() * 2);
+                for (const PairCands &e : pair_tab_)
+                    if (e.key) {
+                        size_t g = (size_t)((e.key * 0x9E3779B97F4A7C15ull) >> 32) & (bigger.size() - 1);
+                        while (bigger[g].key) g = (g + 1) & (bigger.size() - 1);
+                        bigger[g] = e;
+                    }
+                pair_tab_.swap(bigger);
+                continue;
+            }
+            PairCands e;
+            e.key = key;
+            const agx_saddle &s0 = pts_[i0], &s1 = pts_[i1];
+            const float ratio0 = 1.0f + spacing_ratio;
+            const float ex = s0.x - s1.x, ey = s0.y - s1.y;
+            const float radius_sq = 0.5f * (ex * ex + ey * ey);
+            const float v10x = s1.x - s0.x, v10y = s1.y - s0.y;
+            for (int side = 0; side < 2; ++side) {
+                const agx_saddle &anchor = side ? s1 : s0;
+                Hit hits[3];
+                const int m = nearest(anchor.x + v10x * ratio0, anchor.y + v10y * ratio0, 3, hits);
+                e.n[side] = 0;
+                for (int i = 0; i < m; ++i)
+                    if (hits[i].d2 <= radius_sq && theta_distance_degree(anchor.theta, pts_[hits[i].idx].theta) < 5.0f)
+                        e.idx[side][e.n[side]++] = hits[i].idx;
+            }
+            pair_tab_[h] = e;
+            ++pair_used_;
+            return pair_tab_[h];
+        }
+    }
+
+    // is_valid_quad is a pure function of four saddles (five atan2f, a sincos): boards grown from
+    // different seed quads test the same index quadruples again and again.  Open-addressing table
+    // keyed by the four indices (16 bits each; larger sets are evaluated directly).
+    bool valid_quad(int i0, int i1, int i2, int i3)
+    {
+        if (pts_.size() >= 65535u) return is_valid_quad(pts_[i0], pts_[i1], pts_[i2], pts_[i3]);
+        const uint64_t key = 1ull + ((uint64_t)i0 | ((uint64_t)i1 << 16) | ((uint64_t)i2 << 32) | ((uint64_t)i3 << 48));  // != 0
+        if (quad_keys_.empty()) {
+            quad_keys_.assign(1u << 14, 0ull);
+            quad_vals_.assign(1u << 14, 0);
+        }
+        for (;;) {
+            const size_t mask = quad_keys_.size() - 1;
+            size_t h = (size_t)((key * 0x9E3779B97F4A7C15ull) >> 32) & mask;
+            for (;;) {
+                const uint64_t k = quad_keys_[h];
+                if (k == key) return quad_vals_[h] != 0;
+                if (k == 0ull) break;
+                h = (h + 1) & mask;
+            }
+            if (quad_used_ * 2 >= quad_keys_.size()) {  // grow, re-insert, look the slot up again
+                std::vector<uint64_t> ok(quad_keys_.size() * 2, 0ull);
+                std::vector<uint8_t> ov(ok.size(), 0);
+                for (size_t i = 0; i < quad_keys_.size(); ++i)
+                    if (quad_keys_[i]) {
+                        size_t g = (size_t)((quad_keys_[i] * 0x9E3779B97F4A7C15ull) >> 32) & (ok.size() - 1);
+                        while (ok[g]) g = (g + 1) & (ok.size() - 1);
+                        ok[g] = quad_keys_[i];
+                        ov[g] = quad_vals_[i];
+                    }
+                quad_keys_.swap(ok);
+                quad_vals_.swap(ov);
+                continue;
+            }
+            const bool v = is_valid_quad(pts_[i0], pts_[i1], pts_[i2], pts_[i3]);
+            quad_keys_[h] = key;
+            quad_vals_[h] = v ? 1 : 0;
+            ++quad_used_;
+            return v;
+        }
+    }
+
 private:
     int cell_x(float x) const { return std::min(nx_ - 1, std::max(0, (int)std::floor(((double)x - ox_) / cell_))); }
     int cell_y(float y) const { return std::min(ny_ - 1, std::max(0, (int)std::floor(((double)y - oy_) / cell_))); }
@@ -175,6 +270,11 @@ private:
     int nx_ = 1, ny_ = 1;
     std::vector<int> start_, items_;
     std::vector<Hit> cand_;
+    std::vector<PairCands> pair_tab_;
+    size_t pair_used_ = 0;
+    std::vector<uint64_t> quad_keys_;
+    std::vector<uint8_t> quad_vals_;
+    size_t quad_used_ = 0;
 };
 
 struct CellKey {
@@ -233,7 +333,7 @@ public:
                 index_.nearest(x, y, 1, &h);
                 mid[i] = h.idx;
             }
-            if (is_valid_quad(refined_[mid[0]], refined_[mid[1]], refined_[mid[2]], refined_[mid[3]]))
+            if (index_.valid_quad(mid[0], mid[1], mid[2], mid[3]))
                 put({(f.a.x + f.b.x) / 2, (f.a.y + f.b.y) / 2}, true, mid);
         }
     }
@@ -245,58 +345,56 @@ private:
         Quad quad;
     };
 
+    // cell coordinates near the seed live in a direct-mapped grid, anything farther in the map
+    static constexpr int kGridR = 24, kGridN = 2 * kGridR + 1;
+    int find_cell(const CellKey &k) const
+    {
+        if (k.x >= -kGridR && k.x <= kGridR && k.y >= -kGridR && k.y <= kGridR)
+            return grid_[(k.y + kGridR) * kGridN + (k.x + kGridR)];
+        auto it = lookup_.find(k);
+        return it == lookup_.end() ? -1 : (int)it->second;
+    }
     const Cell *get(const CellKey &k) const
     {
-        auto it = lookup_.find(k);
-        return it == lookup_.end() ? nullptr : &cells_[it->second];
+        const int i = find_cell(k);
+        return i < 0 ? nullptr : &cells_[i];
     }
     void put(const CellKey &k, bool found, const Quad &q)
     {
-        auto it = lookup_.find(k);
-        if (it == lookup_.end()) {
-            lookup_.emplace(k, cells_.size());
+        const int i = find_cell(k);
+        if (i < 0) {
+            if (k.x >= -kGridR && k.x <= kGridR && k.y >= -kGridR && k.y <= kGridR)
+                grid_[(k.y + kGridR) * kGridN + (k.x + kGridR)] = (int16_t)cells_.size();
+            else lookup_.emplace(k, cells_.size());
             cells_.push_back({k, found, q});
         } else {
-            cells_[it->second].found = found;
-            cells_[it->second].quad = q;
+            cells_[i].found = found;
+            cells_[i].quad = q;
         }
     }
 
-    // find_closest_potential_saddle_idxs, board.rs:177-233 (one side)
-    int candidates_near(float qx, float qy, float radius_sq, float theta, int out[3])
+    // find_closest_potential_saddle_idxs, board.rs:177-233: the memoised candidates of the pair,
+    // minus the saddles this board has already used
+    void closest_pair(int i0, int i1, int o0[3], int &n0, int o1[3], int &n1)
     {
-        SaddleIndex::Hit hits[3];
-        const int m = index_.nearest(qx, qy, 3, hits);
-        int n = 0;
-        for (int i = 0; i < m; ++i) {
-            if (hits[i].d2 <= radius_sq && active_[hits[i].idx] &&
-                theta_distance_degree(theta, refined_[hits[i].idx].theta) < 5.0f) {
-                out[n++] = hits[i].idx;
-                if (n == 3) break;
-            }
-        }
-        return n;
-    }
-    void closest_pair(const agx_saddle &s0, const agx_saddle &s1, int o0[3], int &n0, int o1[3], int &n1)
-    {
-        const float ratio0 = 1.0f + spacing_ratio_;
-        const float ex = s0.x - s1.x, ey = s0.y - s1.y;
-        const float radius_sq = 0.5f * (ex * ex + ey * ey);
-        const float v10x = s1.x - s0.x, v10y = s1.y - s0.y;
-        n0 = candidates_near(s0.x + v10x * ratio0, s0.y + v10y * ratio0, radius_sq, s0.theta, o0);
-        n1 = candidates_near(s1.x + v10x * ratio0, s1.y + v10y * ratio0, radius_sq, s1.theta, o1);
+        const SaddleIndex::PairCands &pc = index_.pair_candidates(i0, i1, spacing_ratio_);
+        n0 = n1 = 0;
+        for (int i = 0; i < pc.n[0]; ++i)
+            if (active_[pc.idx[0][i]]) o0[n0++] = pc.idx[0][i];
+        for (int i = 0; i < pc.n[1]; ++i)
+            if (active_[pc.idx[1][i]]) o1[n1++] = pc.idx[1][i];
     }
 
     bool expand_one(const Quad &q, Quad &out)  // try_expand_one, board.rs:153-176
     {
         int c0[3], c1[3], c2[3], c3[3], n0, n1, n2, n3;
-        closest_pair(refined_[q[0]], refined_[q[1]], c0, n0, c1, n1);
-        closest_pair(refined_[q[3]], refined_[q[2]], c3, n3, c2, n2);
+        closest_pair(q[0], q[1], c0, n0, c1, n1);
+        closest_pair(q[3], q[2], c3, n3, c2, n2);
         for (int i0 = 0; i0 < n0; ++i0)
             for (int i1 = 0; i1 < n1; ++i1)
                 for (int i2 = 0; i2 < n2; ++i2)
                     for (int i3 = 0; i3 < n3; ++i3)
-                        if (is_valid_quad(refined_[c0[i0]], refined_[c1[i1]], refined_[c2[i2]], refined_[c3[i3]])) {
+                        if (index_.valid_quad(c0[i0], c1[i1], c2[i2], c3[i3])) {
                             out = {c0[i0], c1[i1], c2[i2], c3[i3]};
                             return true;
                         }
@@ -336,6 +434,7 @@ private:
     unsigned score_ = 1;
     std::vector<Cell> cells_;
     std::unordered_map<CellKey, size_t, CellKeyHash> lookup_;
+    std::vector<int16_t> grid_ = std::vector<int16_t>((size_t)kGridN * kGridN, (int16_t)-1);
 };
 
 // init_quads, src/detector.rs:543-586
