@@ -90,7 +90,8 @@ def lib():
             import torch  # noqa: F401
         except ImportError:
             pass
-        l = C.CDLL(LIB_PATH)
+        # AGX_LIBRARY: another build of the same library (kernel A/B measurements on one GPU box)
+        l = C.CDLL(os.environ.get("AGX_LIBRARY") or LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             f = getattr(l, name)  # AttributeError if the library does not export it
             f.restype = res

@@ -163,11 +163,16 @@ template <int FMT, bool A4>
 __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
 {
     const int lane = threadIdx.x & 63;
-    // u8 -> luma table (v / 255, true division once per entry): the per-pixel lookups run on the
-    // LDS pipe, which this kernel otherwise leaves idle, instead of 3 VALU ops per pixel
-    __shared__ float s_lut[256];
+    // u8 -> the pixel's four distinct tap products of the horizontal pass: entry v holds
+    // (v/255)*w0 .. (v/255)*w3 (true division and the same multiplications the pass would do, once
+    // per entry; w4..w6 equal w2..w0 bit for bit).  One 16-byte LDS read per pixel replaces the
+    // conversion AND the pass's 7 multiplications per output pixel; the LDS pipe is otherwise idle.
+    __shared__ float4 s_lut4[256];
     if (FMT == 0) {
-        if (threadIdx.x < 256) s_lut[threadIdx.x] = (float)threadIdx.x / 255.0f;
+        for (int i = threadIdx.x; i < 256; i += blockDim.x) {
+            const float f = (float)i / 255.0f;
+            s_lut4[i] = make_float4(f * a.w[0], f * a.w[1], f * a.w[2], f * a.w[3]);
+        }
         __syncthreads();
     }
     // wave-uniform quantities are made scalar explicitly (the compiler cannot prove it)
@@ -198,18 +203,21 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
     float acc[7][4];
     // blur rows b-2, b-1 (and b below) with their edge columns.  The lane's own four values are
     // one vector value, so that the row store can take them from the register quad they live in.
+    // The two values beyond the lane's four columns are not kept: they are fetched from the
+    // neighbouring lane where they are used (each is used once, so the DPP shift folds into the
+    // consuming subtraction / addition).
     struct Row6 {
-        float l;
         f32x4 c;
-        float r;
-        __device__ __forceinline__ float operator[](int i) const { return i == 0 ? l : (i == 5 ? r : c[i - 1]); }
+        __device__ __forceinline__ float operator[](int i) const
+        {
+            return i == 0 ? from_left(c[3]) : (i == 5 ? from_right(c[0]) : c[i - 1]);
+        }
     };
     Row6 up, mid;
 #pragma unroll
     for (int s7 = 0; s7 < 7; ++s7)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[s7][j] = 0.0f;
-    up.l = up.r = mid.l = mid.r = 0.0f;
     up.c = mid.c = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     // Running minimum per pixel column of the lane (a column either always or never takes part in
     // the frame's minimum, so validity is applied when the columns are combined, not per row).
@@ -300,11 +308,12 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
             const int r = rbase + k;
             if (r > r1) break;  // wave-uniform
             float m[4];
+            float4 P[4];  // FAST: tap products of the lane's own four pixels
             if (FAST) {
                 // lanes left / right of the image replicate the edge pixel (clamp-to-edge)
                 const uint32_t dd = __builtin_amdgcn_perm(cur[k], cur[k], edge_sel);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) m[j] = s_lut[(dd >> (8 * j)) & 0xffu];
+                for (int j = 0; j < 4; ++j) P[j] = s_lut4[(dd >> (8 * j)) & 0xffu];
             } else {
                 convert_px<FMT>(raw_a, m);
                 raw_a = raw_b;
@@ -314,18 +323,41 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
             }
 
             // horizontal pass, image_util.rs:137-185: taps in index order, mul then add
-            const float x[10] = {from_left(m[1]), from_left(m[2]), from_left(m[3]), m[0], m[1], m[2], m[3],
-                                 from_right(m[0]), from_right(m[1]), from_right(m[2])};
+            float x[10];
+            if (!FAST) {
+                x[0] = from_left(m[1]); x[1] = from_left(m[2]); x[2] = from_left(m[3]);
+                x[3] = m[0]; x[4] = m[1]; x[5] = m[2]; x[6] = m[3];
+                x[7] = from_right(m[0]); x[8] = from_right(m[1]); x[9] = from_right(m[2]);
+            }
+            // FAST: x[n] * w_i comes out of the table -- of the own pixels directly, of the three
+            // pixels on either side through the neighbouring lane (the DPP shift folds into the add)
+            auto prod = [&](int n, int i) -> float {
+                const int t = i <= 3 ? i : 6 - i;
+                const float4 &q = P[n < 3 ? n + 1 : (n > 6 ? n - 7 : n - 3)];
+                const float e = t == 0 ? q.x : (t == 1 ? q.y : (t == 2 ? q.z : q.w));
+                return n < 3 ? from_left(e) : (n > 6 ? from_right(e) : e);
+            };
             f32x4 bc;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float v = x[j] * w0;
-                v = v + x[j + 1] * w1;
-                v = v + x[j + 2] * w2;
-                v = v + x[j + 3] * w3;
-                v = v + x[j + 4] * w4;
-                v = v + x[j + 5] * w5;
-                v = v + x[j + 6] * w6;
+                float v;
+                if (FAST) {
+                    v = prod(j, 0);
+                    v = v + prod(j + 1, 1);
+                    v = v + prod(j + 2, 2);
+                    v = v + prod(j + 3, 3);
+                    v = v + prod(j + 4, 4);
+                    v = v + prod(j + 5, 5);
+                    v = v + prod(j + 6, 6);
+                } else {
+                    v = x[j] * w0;
+                    v = v + x[j + 1] * w1;
+                    v = v + x[j + 2] * w2;
+                    v = v + x[j + 3] * w3;
+                    v = v + x[j + 4] * w4;
+                    v = v + x[j + 5] * w5;
+                    v = v + x[j + 6] * w6;
+                }
                 // vertical pass: blur row b = r-3 completes, rows r-2 .. r+3 advance
                 const float p0 = v * w0, p1 = v * w1, p2 = v * w2, p3 = v * w3;
                 bc[j] = acc[k][j] + p0;                              // tap 6 of row r-3
@@ -355,9 +387,7 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
             }
             // Hessian determinant of row y = b-1 (rows b-2, b-1, b), image_util.rs:88-106
             Row6 dn;
-            dn.l = from_left(bc[3]);
             dn.c = bc;
-            dn.r = from_right(bc[0]);
             const int y = b - 1;
             if (y >= ys && y < ye && !(a.dbg & 4)) {  // wave-uniform
                 if (y > 0 && y < H - 1) {
