@@ -159,6 +159,8 @@ __device__ __forceinline__ void convert_px(const RawPx<FMT> &r, float m[4])
 // stores the blur row, and evaluates the Hessian determinant of the previous row (its left /
 // right blur neighbours again by DPP) for the per-frame minimum.  No LDS, no barriers.
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int H_full_segs(const ChainArgs &a) { return a.H / a.rows_per_seg; }
+
 template <int FMT, bool A4>
 __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
 {
@@ -176,11 +178,27 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
         __syncthreads();
     }
     // wave-uniform quantities are made scalar explicitly (the compiler cannot prove it)
-    const int unit = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-    if (unit >= a.n_strips * a.n_segs) return;  // whole wave
-    const int strip = unit % a.n_strips;
-    const int seg = unit / a.n_strips;
-    const int frame = blockIdx.y;
+    // Work units (frame, strip, segment) in dispatch order: first every full-height segment of
+    // every frame, then the short last segments (H not a multiple of the segment height) -- the
+    // short ones fill the slots that free up while the last full ones are still running, instead
+    // of leaving a thin extra round at the end.
+    const int u = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    const int n_full = H_full_segs(a);  // segments of full height per frame
+    const int per_frame_full = a.n_strips * n_full;
+    const int total_full = per_frame_full * a.n_frames;
+    int frame, strip, seg;
+    if (u < total_full) {
+        frame = u / per_frame_full;
+        const int r = u - frame * per_frame_full;
+        seg = r / a.n_strips;
+        strip = r - seg * a.n_strips;
+    } else {
+        const int v = u - total_full;
+        if (n_full == a.n_segs || v >= a.n_strips * a.n_frames) return;  // whole wave: padding of the last workgroup
+        frame = v / a.n_strips;
+        strip = v - frame * a.n_strips;
+        seg = n_full;
+    }
     const int W = a.W, H = a.H;
     const int xs = strip * a.strip_cols;
     const int xe = min(W, xs + a.strip_cols);
@@ -1221,8 +1239,8 @@ size_t k5_lds_bytes(const ChainArgs &a)
 template <int FMT>
 static hipError_t launch_k1(const ChainArgs &a, hipStream_t st)
 {
-    const int units = a.n_strips * a.n_segs;
-    dim3 grid((units + 3) / 4, a.n_frames), block(256);
+    const long long units = (long long)a.n_strips * a.n_segs * a.n_frames;
+    dim3 grid((unsigned)((units + 3) / 4)), block(256);
     // the aligned form addresses a frame and its blur plane with 32-bit buffer offsets
     const bool small = a.plane * 4 < (1ll << 31) && (long long)a.H * a.row_stride < (1ll << 31);
     if ((a.W & 3) == 0 && small) hipLaunchKernelGGL((k_blur_hessian<FMT, true>), grid, block, 0, st, a);
