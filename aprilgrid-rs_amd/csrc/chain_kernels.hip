@@ -150,6 +150,20 @@ __device__ __forceinline__ void convert_px(const RawPx<FMT> &r, float m[4])
     }
 }
 
+// 8-bit luma of pixel j of the raw words (L8: the byte; RGB8: the integer luma of the image crate)
+template <int FMT>
+__device__ __forceinline__ uint32_t luma_byte(const RawPx<FMT> &r, int j)
+{
+    if (FMT != 2) return (r.d[0] >> (8 * j)) & 0xffu;
+    uint32_t c[3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        const int pos = j * 3 + b;
+        c[b] = (r.d[pos >> 2] >> ((pos & 3) * 8)) & 0xffu;
+    }
+    return (2126u * c[0] + 7152u * c[1] + 722u * c[2]) / 10000u;
+}
+
 // ------------------------------------------------------------------------------------------
 // K1: every wave is autonomous.  A wave owns a strip of up to 248 columns: lane l holds the 4
 // pixels of columns xs-4+4l .. xs-1+4l of the current row, lanes 0 and n+1 are halo lanes that
@@ -170,7 +184,7 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
     // per entry; w4..w6 equal w2..w0 bit for bit).  One 16-byte LDS read per pixel replaces the
     // conversion AND the pass's 7 multiplications per output pixel; the LDS pipe is otherwise idle.
     __shared__ float4 s_lut4[256];
-    if (FMT == 0) {
+    if (FMT == 0 || FMT == 2) {
         for (int i = threadIdx.x; i < 256; i += blockDim.x) {
             const float f = (float)i / 255.0f;
             s_lut4[i] = make_float4(f * a.w[0], f * a.w[1], f * a.w[2], f * a.w[3]);
@@ -283,8 +297,13 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
     // issued at once.  gfx9 counts loads and stores in one in-order vmcnt and the compiler waits
     // with vmcnt(0) here, i.e. it also drains the blur stores issued so far; batching makes that
     // happen once per 7 rows, on loads that are a whole body old, instead of before every row.
-    constexpr bool FAST = (FMT == 0) && A4;
-    uint32_t ring[7];
+    // FAST: 8-bit luma (L8, RGB8) and W % 4 == 0.  RGB8 rows arrive as 3 dwords per lane and are
+    // reduced to the packed luma dword of the image crate's integer formula when the group starts;
+    // from there on the two formats share everything.
+    constexpr bool FAST = (FMT == 0 || FMT == 2) && A4;
+    constexpr int RW = FMT == 2 ? 3 : 1;  // input dwords per lane and row
+    typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+    uint32_t ring[7][RW];
     RawPx<FMT> raw_a, raw_b, raw_c, raw_d;
     const int cc = c0 < 0 ? 0 : (c0 > W - 4 ? W - 4 : c0);  // FAST: clamped column of this lane's dword
     // byte selector of v_perm_b32: identity, or the first / last byte of the dword four times
@@ -298,13 +317,20 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
     const uint32_t blur_bytes = (uint32_t)a.plane * 4u;
     __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void *)fbase, 0, (int)((uint32_t)H * (uint32_t)a.row_stride), RSRC_WORD3);
     __amdgpu_buffer_rsrc_t rs_blur = __builtin_amdgcn_make_buffer_rsrc((void *)blur_f, 0, (int)blur_bytes, RSRC_WORD3);
-    auto issue_load = [&](int r) -> uint32_t {
+    auto issue_load = [&](int r, uint32_t (&dst)[RW]) {
         const int rr = r < 0 ? 0 : (r > H - 1 ? H - 1 : r);
-        return __builtin_amdgcn_raw_buffer_load_b32(rs_in, cc, rr * a.row_stride, 0);
+        if (FMT == 2) {
+            const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(rs_in, cc * 3, rr * a.row_stride, 0);
+            dst[0] = v.x;
+            dst[RW > 1 ? 1 : 0] = v.y;
+            dst[RW > 2 ? 2 : 0] = v.z;
+        } else {
+            dst[0] = __builtin_amdgcn_raw_buffer_load_b32(rs_in, cc, rr * a.row_stride, 0);
+        }
     };
     if (FAST) {
 #pragma unroll
-        for (int k = 0; k < 7; ++k) ring[k] = issue_load(r0 + k);
+        for (int k = 0; k < 7; ++k) issue_load(r0 + k, ring[k]);
     } else {
         raw_a = load_raw<FMT, A4>(rowptr(r0), c0, W);
         raw_b = load_raw<FMT, A4>(rowptr(r0 + 1), c0, W);
@@ -314,12 +340,27 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
 
 #pragma unroll 1
     for (int rbase = r0; rbase <= r1; rbase += 7) {
-        uint32_t cur[7];
+        uint32_t cur[7];  // packed 8-bit luma of the lane's four pixels, per row of the group
         if (FAST) {
+            uint32_t got[7][RW];
 #pragma unroll
-            for (int k = 0; k < 7; ++k) cur[k] = ring[k];
+            for (int k = 0; k < 7; ++k)
 #pragma unroll
-            for (int k = 0; k < 7; ++k) ring[k] = issue_load(rbase + 7 + k);  // rows past the end clamp to H-1
+                for (int q = 0; q < RW; ++q) got[k][q] = ring[k][q];
+#pragma unroll
+            for (int k = 0; k < 7; ++k) issue_load(rbase + 7 + k, ring[k]);  // rows past the end clamp to H-1
+#pragma unroll
+            for (int k = 0; k < 7; ++k) {
+                if (FMT == 2) {
+                    RawPx<FMT> px;
+#pragma unroll
+                    for (int q = 0; q < RW; ++q) px.d[q] = got[k][q];
+                    cur[k] = luma_byte<FMT>(px, 0) | (luma_byte<FMT>(px, 1) << 8) | (luma_byte<FMT>(px, 2) << 16) |
+                             (luma_byte<FMT>(px, 3) << 24);
+                } else {
+                    cur[k] = got[k][0];
+                }
+            }
         }
 #pragma unroll
         for (int k = 0; k < 7; ++k) {
