@@ -301,7 +301,11 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
     // reduced to the packed luma dword of the image crate's integer formula when the group starts;
     // from there on the two formats share everything.
     constexpr bool FAST = (FMT == 0 || FMT == 2) && A4;
-    constexpr int RW = FMT == 2 ? 3 : 1;  // input dwords per lane and row
+    // BUF: W % 4 == 0, any format -- the rows of a group are fetched together through the buffer
+    // resource one group ahead (L16 keeps its raw 2 dwords per row and converts row by row).
+    constexpr bool BUF = A4;
+    constexpr int RW = FMT == 2 ? 3 : (FMT == 1 ? 2 : 1);  // input dwords per lane and row
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
     uint32_t ring[7][RW];
     RawPx<FMT> raw_a, raw_b, raw_c, raw_d;
@@ -324,11 +328,19 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
             dst[0] = v.x;
             dst[RW > 1 ? 1 : 0] = v.y;
             dst[RW > 2 ? 2 : 0] = v.z;
+        } else if (FMT == 1) {
+            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs_in, cc * 2, rr * a.row_stride, 0);
+            dst[0] = v.x;
+            dst[RW > 1 ? 1 : 0] = v.y;
         } else {
             dst[0] = __builtin_amdgcn_raw_buffer_load_b32(rs_in, cc, rr * a.row_stride, 0);
         }
     };
-    if (FAST) {
+    // L16 edge lanes: 16-bit selectors of v_perm_b32 over (dword1:dword0) -- identity, or the first /
+    // last pixel of the 8 bytes in both halves
+    const uint32_t sel16_lo = c0 < 0 ? 0x01000100u : (c0 >= W ? 0x07060706u : 0x03020100u);
+    const uint32_t sel16_hi = c0 < 0 ? 0x01000100u : (c0 >= W ? 0x07060706u : 0x07060504u);
+    if (BUF) {
 #pragma unroll
         for (int k = 0; k < 7; ++k) issue_load(r0 + k, ring[k]);
     } else {
@@ -341,8 +353,8 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
 #pragma unroll 1
     for (int rbase = r0; rbase <= r1; rbase += 7) {
         uint32_t cur[7];  // packed 8-bit luma of the lane's four pixels, per row of the group
-        if (FAST) {
-            uint32_t got[7][RW];
+        uint32_t got[7][RW];
+        if (BUF) {
 #pragma unroll
             for (int k = 0; k < 7; ++k)
 #pragma unroll
@@ -357,7 +369,7 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
                     for (int q = 0; q < RW; ++q) px.d[q] = got[k][q];
                     cur[k] = luma_byte<FMT>(px, 0) | (luma_byte<FMT>(px, 1) << 8) | (luma_byte<FMT>(px, 2) << 16) |
                              (luma_byte<FMT>(px, 3) << 24);
-                } else {
+                } else if (FMT == 0) {
                     cur[k] = got[k][0];
                 }
             }
@@ -373,6 +385,13 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
                 const uint32_t dd = __builtin_amdgcn_perm(cur[k], cur[k], edge_sel);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) P[j] = s_lut4[(dd >> (8 * j)) & 0xffu];
+            } else if (BUF) {  // L16, aligned: 4 x u16 in two dwords, edge lanes replicate by permute
+                const uint32_t d0 = got[k][0], d1 = got[k][RW > 1 ? 1 : 0];
+                const uint32_t e0 = __builtin_amdgcn_perm(d1, d0, sel16_lo), e1 = __builtin_amdgcn_perm(d1, d0, sel16_hi);
+                m[0] = div_const<65535>((float)(e0 & 0xffffu));
+                m[1] = div_const<65535>((float)(e0 >> 16));
+                m[2] = div_const<65535>((float)(e1 & 0xffffu));
+                m[3] = div_const<65535>((float)(e1 >> 16));
             } else {
                 convert_px<FMT>(raw_a, m);
                 raw_a = raw_b;
