@@ -589,7 +589,7 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
 // the blur plane -- same expression, same operands as K1 -- and keep the bit only if
 // resp < 0.05*min_frame (detector.rs:418, :177).  Each thread owns its word: no atomics.
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_verify(ChainArgs a)
+__global__ void __launch_bounds__(64) k_verify(ChainArgs a)
 {
     const int frame = (int)(gridDim.y - 1 - blockIdx.y);  // latest-written blur planes first (cache)
     const FrameCounters &ctr = a.ctr[frame];
@@ -1330,8 +1330,8 @@ int launch_kernel(int which, const ChainArgs &a, const RefineConsts &rc, void *s
         if (a.fmt == 1) return launch_k1<1>(a, st);
         return launch_k1<2>(a, st);
     case K_THRESHOLD: {
-        dim3 grid(sparse_grid_x(a, 32, "AGX_G_VERIFY"), a.n_frames), grid4(sparse_grid_x(a, 16, "AGX_G_SEEDS"), a.n_frames), block(256);
-        hipLaunchKernelGGL(k_verify, grid, block, 0, st, a);
+        dim3 grid(sparse_grid_x(a, 128, "AGX_G_VERIFY"), a.n_frames), grid4(sparse_grid_x(a, 16, "AGX_G_SEEDS"), a.n_frames), block(256);
+        hipLaunchKernelGGL(k_verify, grid, dim3(64), 0, st, a);  // single-wave workgroups: a slot frees when its wave is done
         hipLaunchKernelGGL(k_seeds, grid4, block, 0, st, a);
         return hipGetLastError();
     }
