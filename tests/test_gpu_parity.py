@@ -286,6 +286,39 @@ def test_oversized_components_take_second_tier_and_generic_path(det, oracle):
     assert c[2]["big_seeds"] > 0, c[2]                                 # second tier exercised
 
 
+def test_randomised_sizes_formats_batches(det, oracle):
+    """Seeded random sweep: widths (aligned and not), heights, formats, batch sizes, board and
+    noise frames -- every frame against the oracle (tools/stress_parity.py is the long version)."""
+    import torch
+    synth = synth_module()
+    rng = np.random.default_rng(5)
+    for case in range(36):
+        fmt = ["L8", "L16", "RGB8"][int(rng.integers(0, 3))]
+        w = int(rng.choice([rng.integers(8, 80) * 4, rng.integers(200, 420) * 4, rng.integers(33, 700)]))
+        h = int(rng.choice([rng.integers(9, 70), rng.integers(64, 300), rng.integers(300, 700)]))
+        noise = bool(rng.integers(0, 3) == 0)
+        first = int(rng.integers(0, 1000))
+        if w % 4 == 0:
+            n = int(rng.integers(1, 5))
+            frames, _ = synth.render_batch(first, n, w, h, device="cuda", fmt=fmt, pure_noise=noise)
+            host = frames.cpu().numpy()
+            if fmt == "L16":
+                host = host.view(np.uint16)
+            det.saddles_batch_enqueue(frames)
+            res, status = det.saddles_batch_fetch()
+            assert (status == 0).all()
+        else:  # device batches need 4-byte aligned rows: unaligned widths go through the host API
+            n = 1
+            fr, _ = synth.render_batch(first, 1, (w + 3) // 4 * 4, h, device="cpu", fmt=fmt, pure_noise=noise)
+            host = fr.numpy()
+            if fmt == "L16":
+                host = host.view(np.uint16)
+            host = np.ascontiguousarray(host[:, :, :w])
+            res = [det.refined_saddle_points(host[0], as_array=True)]
+        for i in range(n):
+            check_saddles(res[i], oracle.refined_saddle_points(host[i]), "case %d %s %dx%d frame %d" % (case, fmt, w, h, i))
+
+
 def test_capacity_overflow_is_reported_not_truncated(oracle):
     import aprilgrid_rs_amd as A
     d = A.TagDetector("T36H11", None, device=0)
