@@ -820,6 +820,9 @@ __global__ void __launch_bounds__(64) k_flood(ChainArgs a)
                 comp[c] = 0u;
             }
             comp[16] = 2u;  // the seed: column sx, row sy
+            // A right-to-left sweep applies the full update rule to every column with its current
+            // neighbours, so "that sweep changed nothing" IS the fixed point: the left-to-right
+            // sweep before it need not be watched (convex blobs finish after one pair of sweeps).
             uint32_t changed;
             do {
                 changed = 0u;
@@ -828,9 +831,7 @@ __global__ void __launch_bounds__(64) k_flood(ChainArgs a)
                     uint32_t s = comp[c];
                     if (c > 0) s |= comp[c - 1];
                     if (c < FLOOD_COLS - 1) s |= comp[c + 1];
-                    const uint32_t f = fill_runs(s & cand[c], cand[c]);
-                    changed |= f ^ comp[c];
-                    comp[c] = f;
+                    comp[c] = fill_runs(s & cand[c], cand[c]);
                 }
 #pragma unroll
                 for (int c = FLOOD_COLS - 1; c >= 0; --c) {  // right-to-left sweep
