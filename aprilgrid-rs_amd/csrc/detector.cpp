@@ -37,14 +37,6 @@ struct agx_detector {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
-    // chunk pipeline: the frames of a batch are split into chunks that run the chain on
-    // different streams, so that the ALU-bound and the HBM-bound kernels of different chunks
-    // overlap; fork/join events order them behind / in front of `stream`
-    static constexpr int kMaxStreams = 8;
-    hipStream_t aux[kMaxStreams] = {};
-    hipEvent_t ev_fork = nullptr, ev_join[kMaxStreams] = {};
-    int n_streams = 1;     // option "streams" (1 = everything on `stream`)
-    int chunk_frames = 1 << 20;  // option "chunk_frames"
     RefineConsts rc{};
     float blur_w[7]{};
     uint32_t lim_cand = 0, lim_roots = 0, lim_out = 0;
@@ -351,24 +343,9 @@ int enqueue_chain(agx_detector *d)
     // counters of the batch's frames and the compact-output cursor in one clear
     a.total_out = &a.ctr[a.n_frames].min_key_inv;
     HIP_TRY(d, hipMemsetAsync(a.ctr, 0, ((size_t)a.n_frames + 1) * sizeof(FrameCounters), d->stream));
-    const int F = a.n_frames;
-    const int chunk = std::max(1, d->chunk_frames);
-    const int n_chunks = (F + chunk - 1) / chunk;
-    const int S = std::min(d->n_streams, n_chunks);
-    int rc = AGX_OK;
-    if (S <= 1) {
-        for (int c = 0; c < n_chunks && rc == AGX_OK; ++c)
-            rc = enqueue_chunk(d, c * chunk, std::min(chunk, F - c * chunk), d->stream);
-    } else {
-        HIP_TRY(d, hipEventRecord(d->ev_fork, d->stream));
-        for (int i = 0; i < S; ++i) HIP_TRY(d, hipStreamWaitEvent(d->aux[i], d->ev_fork, 0));
-        for (int c = 0; c < n_chunks && rc == AGX_OK; ++c)
-            rc = enqueue_chunk(d, c * chunk, std::min(chunk, F - c * chunk), d->aux[c % S]);
-        for (int i = 0; i < S; ++i) {
-            HIP_TRY(d, hipEventRecord(d->ev_join[i], d->aux[i]));
-            HIP_TRY(d, hipStreamWaitEvent(d->stream, d->ev_join[i], 0));
-        }
-    }
+    // (splitting a batch over several streams -- whole chain or sparse kernels only -- was measured
+    // and lost every time: see DESIGN.md; batches in flight are separate detectors)
+    const int rc = enqueue_chunk(d, 0, a.n_frames, d->stream);
     if (rc) return rc;
     d->enqueued = true;
     return AGX_OK;
@@ -472,14 +449,6 @@ int agx_detector_create(int family, const agx_params *params, int device, agx_de
         return AGX_ERR_HIP;
     }
     d->stream = d->own_stream;
-    for (int i = 0; i < agx_detector::kMaxStreams; ++i) {
-        if (hipStreamCreateWithFlags(&d->aux[i], hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&d->ev_join[i], hipEventDisableTiming) != hipSuccess) {
-            g_create_error = "creating pipeline streams failed";
-            return AGX_ERR_HIP;
-        }
-    }
-    if (hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming) != hipSuccess) return AGX_ERR_HIP;
     make_blur_weights(1.5f, d->blur_w);
     make_refine_consts(d->rc);
     *out = d.release();
@@ -496,12 +465,6 @@ void agx_detector_destroy(agx_detector *det)
     free_workspace(det);
     if (det->d_stage) (void)hipFree(det->d_stage);
     if (det->d_dbg_resp) (void)hipFree(det->d_dbg_resp);
-    for (int i = 0; i < agx_detector::kMaxStreams; ++i) {
-        if (det->aux[i]) (void)hipStreamSynchronize(det->aux[i]);
-        if (det->aux[i]) (void)hipStreamDestroy(det->aux[i]);
-        if (det->ev_join[i]) (void)hipEventDestroy(det->ev_join[i]);
-    }
-    if (det->ev_fork) (void)hipEventDestroy(det->ev_fork);
     if (det->own_stream) (void)hipStreamDestroy(det->own_stream);
     delete det;
 }
@@ -544,8 +507,6 @@ int agx_detector_set_option(agx_detector *det, const char *name, int value)
     if (!std::strcmp(name, "force_generic")) det->force_generic = value != 0;
     else if (!std::strcmp(name, "k1_rows_per_segment")) det->k1_rows = value > 0 ? value : 0;
     else if (!std::strcmp(name, "debug_ablation")) det->dbg = value;  // timing only, results invalid
-    else if (!std::strcmp(name, "streams")) det->n_streams = std::min(std::max(value, 1), (int)agx_detector::kMaxStreams);
-    else if (!std::strcmp(name, "chunk_frames")) det->chunk_frames = std::max(value, 1);
     else return fail(det, AGX_ERR_ARG, std::string("unknown option ") + name);
     return AGX_OK;
 }

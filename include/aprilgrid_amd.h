@@ -107,9 +107,6 @@ int agx_detector_set_limits(agx_detector *det, uint32_t max_candidates, uint32_t
  *   "force_generic"        1 = cluster every frame with the generic union-find kernels instead
  *                          of the windowed flood fill (results are identical; test hook)
  *   "k1_rows_per_segment"  rows one wave of the blur kernel walks (0 = automatic)
- *   "streams"              HIP streams the chunks of a batch are pipelined over (default 1 =
- *                          the whole chain in order on the detector's stream)
- *   "chunk_frames"         frames per chunk (default: the whole batch)
  *   "debug_ablation"       timing experiments only -- results are INVALID when non-zero */
 int agx_detector_set_option(agx_detector *det, const char *name, int value);
 

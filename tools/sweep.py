@@ -9,8 +9,6 @@ rows = [int(x) for x in (sys.argv[1:] or ["0"])]
 base, _ = synth.render_batch(0, 32, 1280, 800, device="cuda")
 frames = base.repeat((F // 32 + 1, 1, 1))[:F].contiguous()
 det = A.TagDetector("t36h11")
-det.set_option("streams", int(os.environ.get("STREAMS", "1")))
-det.set_option("chunk_frames", int(os.environ.get("CHUNK", "256")))
 import time
 DBG = [int(x) for x in os.environ.get("DBG", "0").split(",")]
 for r, dbg in [(r, d) for r in rows for d in DBG]:
