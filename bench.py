@@ -89,7 +89,32 @@ def cpu_baseline(frames_host, fmt, budget_s):
         t_used += time.perf_counter() - t0
         n_done += 1
     mpix = n_done * w * h / t_used / 1e6
+    # SURVEY.md 8(d) baseline #2: the same code, frame-parallel over the host cores this process may
+    # use (ctypes releases the GIL; every thread has its own output buffer) -- a short extra sample
+    import threading
+    n_thr = max(1, min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 64))
+    counts = [0] * n_thr
+    t_end = time.perf_counter() + min(5.0, budget_s)
+
+    def worker(t):
+        o = np.zeros(1 << 16, O.SADDLE_DTYPE)
+        i = t
+        while time.perf_counter() < t_end:
+            f = frames_host[i % len(frames_host)]
+            lib.orc_refined_saddle_points(f.ctypes.data, w, h, stride, ofmt, C.addressof(prm), o.ctypes.data, len(o), None)
+            counts[t] += 1
+            i += n_thr
+
+    t_mt = time.perf_counter()
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(n_thr)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    t_mt = time.perf_counter() - t_mt
     return {"value": round(mpix, 3), "unit": "Mpix/s", "cores": 1, "kind": "port",
+            "all_cores": {"value": round(sum(counts) * w * h / t_mt / 1e6, 1), "unit": "Mpix/s", "cores": n_thr,
+                          "sample": "%d frames in %.1f s on %d threads" % (sum(counts), t_mt, n_thr)},
             "sample": "%d frames %dx%d %s, chain only (refined_saddle_points), oracle/agx_oracle.c -O3 "
                       "-march=native -ffp-contract=off, %.1f s" % (n_done, w, h, fmt, t_used),
             "ms_per_frame": round(1e3 * t_used / n_done, 3)}
