@@ -59,6 +59,15 @@ __device__ __forceinline__ float div_const(float v)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Workgroups go to the 8 XCDs round-robin by their linear id.  In a (blocks per frame, frames)
+// grid whose x extent is a multiple of 8, block x of every frame lands on the same XCD -- and the
+// sparse kernels use only the first few x slots of a frame (as many as it has work for), so the
+// idle slots would always hit the same XCDs.  Rotating the slot by the frame index spreads them.
+__device__ __forceinline__ uint32_t rotated_block_x(int frame)
+{
+    return (blockIdx.x + 3u * (uint32_t)frame) % gridDim.x;
+}
+
 // Neighbour-lane exchange by DPP wave shifts (one VALU op, no LDS): lane l receives the value
 // of lane l-1 (from_left) or l+1 (from_right); lane 0 / lane 63 receive 0 (bound_ctrl: no
 // destination to initialise).
@@ -803,7 +812,7 @@ __global__ void __launch_bounds__(64) k_flood(ChainArgs a)
     const uint32_t *mask = a.mask + (size_t)frame * (size_t)a.mask_plane;
     const uint32_t W = (uint32_t)a.W;
     const int lane = threadIdx.x;
-    for (uint32_t base = blockIdx.x * 64u; base < n; base += gridDim.x * 64u) {  // wave-uniform trip count
+    for (uint32_t base = rotated_block_x(frame) * 64u; base < n; base += gridDim.x * 64u) {  // wave-uniform trip count
         const uint32_t i = base + (uint32_t)lane;
         uint32_t p = 0u;
         bool big = false;
@@ -1055,7 +1064,7 @@ __global__ void __launch_bounds__(64, 4) k_refine(ChainArgs a, RefineConsts rc)
     const size_t cbase = (size_t)frame * a.cap_roots;
     const float *img = a.blur + (size_t)frame * (size_t)a.plane;
     const int W = a.W, H = a.H;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    for (uint32_t i = rotated_block_x(frame) * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t s = i;
         const uint32_t sx = a.clu_sx[cbase + s], sy = a.clu_sy[cbase + s], cn = a.clu_cnt[cbase + s];
         if (sx >= (1u << 24) || sy >= (1u << 24)) atomicOr(&a.ctr[frame].flags, FLAG_CENTROID_INEXACT);
