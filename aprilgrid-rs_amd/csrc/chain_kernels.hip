@@ -59,13 +59,25 @@ __device__ __forceinline__ float div_const(float v)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// Workgroups go to the 8 XCDs round-robin by their linear id.  In a (blocks per frame, frames)
-// grid whose x extent is a multiple of 8, block x of every frame lands on the same XCD -- and the
-// sparse kernels use only the first few x slots of a frame (as many as it has work for), so the
-// idle slots would always hit the same XCDs.  Rotating the slot by the frame index spreads them.
-__device__ __forceinline__ uint32_t rotated_block_x(int frame)
+// Workgroups go to the 8 XCDs round-robin by their linear id, and the sparse kernels use only the
+// first few slots of a frame (as many as it has work for).  A (slots, frames) grid with an x
+// extent that is a multiple of 8 would park the idle slots on the same XCDs for every frame
+// (refine: 0.096 ms at 16 slots per frame, 0.072 ms at 15).  These kernels therefore take a 1-D
+// grid in slot-major order: linear id -> (slot = id / n_frames, frame = id % n_frames).  Slot s of
+// all frames is dispatched before slot s+1, a frame stays on one XCD, and the slots without work
+// come last and exit at once.
+struct FrameSlot {
+    int frame;
+    uint32_t slot, n_slots;
+};
+__device__ __forceinline__ FrameSlot frame_slot(int n_frames, bool newest_first)
 {
-    return (blockIdx.x + 3u * (uint32_t)frame) % gridDim.x;
+    FrameSlot fs;
+    fs.slot = blockIdx.x / (uint32_t)n_frames;
+    const int f = (int)(blockIdx.x - fs.slot * (uint32_t)n_frames);
+    fs.frame = newest_first ? n_frames - 1 - f : f;
+    fs.n_slots = gridDim.x / (uint32_t)n_frames;
+    return fs;
 }
 
 // Neighbour-lane exchange by DPP wave shifts (one VALU op, no LDS): lane l receives the value
@@ -805,14 +817,15 @@ __device__ __forceinline__ void wave_flood_128x64(const ChainArgs &a, int frame,
 
 __global__ void __launch_bounds__(64) k_flood(ChainArgs a)
 {
-    const int frame = blockIdx.y;
+    const FrameSlot fs = frame_slot(a.n_frames, false);
+    const int frame = fs.frame;
     FrameCounters &ctr = a.ctr[frame];
     if (ctr.flags & FLAG_CAND_OVERFLOW) return;
     const uint32_t n = min(ctr.n_seeds, a.cap_roots);
     const uint32_t *mask = a.mask + (size_t)frame * (size_t)a.mask_plane;
     const uint32_t W = (uint32_t)a.W;
     const int lane = threadIdx.x;
-    for (uint32_t base = rotated_block_x(frame) * 64u; base < n; base += gridDim.x * 64u) {  // wave-uniform trip count
+    for (uint32_t base = fs.slot * 64u; base < n; base += fs.n_slots * 64u) {  // wave-uniform trip count
         const uint32_t i = base + (uint32_t)lane;
         uint32_t p = 0u;
         bool big = false;
@@ -1058,13 +1071,14 @@ __global__ void k_debug_resp(const float *__restrict__ blur, float *__restrict__
 template <bool VEC>
 __global__ void __launch_bounds__(64, 4) k_refine(ChainArgs a, RefineConsts rc)
 {
-    const int frame = (int)(gridDim.y - 1 - blockIdx.y);  // latest-written blur planes first (cache)
+    const FrameSlot fs = frame_slot(a.n_frames, true);  // latest-written blur planes first (cache)
+    const int frame = fs.frame;
     if (a.ctr[frame].flags & (FLAG_CAND_OVERFLOW | FLAG_ROOT_OVERFLOW)) return;
     const uint32_t n = min(a.ctr[frame].n_clusters, a.cap_roots);
     const size_t cbase = (size_t)frame * a.cap_roots;
     const float *img = a.blur + (size_t)frame * (size_t)a.plane;
     const int W = a.W, H = a.H;
-    for (uint32_t i = rotated_block_x(frame) * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    for (uint32_t i = fs.slot * blockDim.x + threadIdx.x; i < n; i += fs.n_slots * blockDim.x) {
         const uint32_t s = i;
         const uint32_t sx = a.clu_sx[cbase + s], sy = a.clu_sy[cbase + s], cn = a.clu_cnt[cbase + s];
         if (sx >= (1u << 24) || sy >= (1u << 24)) atomicOr(&a.ctr[frame].flags, FLAG_CENTROID_INEXACT);
@@ -1346,7 +1360,7 @@ int launch_kernel(int which, const ChainArgs &a, const RefineConsts &rc, void *s
         return hipGetLastError();
     }
     case K_FLOOD: {
-        dim3 grid(sparse_grid_x(a, 48, "AGX_G_FLOOD"), a.n_frames), block(64);
+        dim3 grid((unsigned)sparse_grid_x(a, 48, "AGX_G_FLOOD") * (unsigned)a.n_frames), block(64);  // slot-major, see frame_slot
         hipLaunchKernelGGL(k_flood, grid, block, 0, st, a);
         return hipGetLastError();
     }
@@ -1356,7 +1370,7 @@ int launch_kernel(int which, const ChainArgs &a, const RefineConsts &rc, void *s
         return hipGetLastError();
     }
     case K_REFINE: {
-        dim3 grid(sparse_grid_x(a, 24, "AGX_G_REFINE"), a.n_frames), block(64);
+        dim3 grid((unsigned)sparse_grid_x(a, 24, "AGX_G_REFINE") * (unsigned)a.n_frames), block(64);  // slot-major
         if ((a.W & 3) == 0) hipLaunchKernelGGL(k_refine<true>, grid, block, 0, st, a, rc);
         else hipLaunchKernelGGL(k_refine<false>, grid, block, 0, st, a, rc);
         return hipGetLastError();
