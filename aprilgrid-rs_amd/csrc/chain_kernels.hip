@@ -523,7 +523,7 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
                         const int wmin_bits = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wmin));
                         wmin = __builtin_bit_cast(float, wmin_bits);
                         const float published = __builtin_bit_cast(float, published_bits);
-                        if (wmin < published * 1.125f || (published == 0.0f && wmin < 0.0f)) {  // >12 % better
+                        if (wmin < published) {  // any improvement: at most one atomic per sync point and wave
                             if (lane == 0) atomicMax(&ctr.min_key_inv, ~f32_order_key(wmin));
                             published_bits = wmin_bits;
                         }
