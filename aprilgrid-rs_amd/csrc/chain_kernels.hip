@@ -9,20 +9,22 @@
 //
 //   K1 k_blur_hessian   luma->f32 (image crate to_luma32f), 7-tap separable Gaussian
 //                       (image_util.rs:110-206), Hessian determinant (image_util.rs:72-109),
-//                       per-frame min (detector.rs:414-417).  Row-marching workgroups: a
-//                       workgroup owns a column strip and walks down a segment of rows,
-//                       keeping the 7-row vertical window and the 3-row Hessian window in
-//                       registers; LDS carries only the +-4 column neighbour exchange.
-//                       The response is NOT stored.  K1 also writes a candidate SUPERSET as a
-//                       1 bit / pixel mask: resp < 0.05*m for a running minimum m >= min_frame.
+//                       per-frame min (detector.rs:414-417).  Every WAVE is autonomous: it owns a
+//                       strip of <= 248 columns (4 pixels per lane, neighbours by DPP) and
+//                       marches down a segment of rows with the 7-row vertical window and the
+//                       3-row Hessian window in registers.  No LDS exchange, no barriers in the
+//                       row loop.  The response is NOT stored.  K1 also writes a candidate
+//                       SUPERSET as a transposed 1 bit / pixel mask: resp < 0.05*m for a running
+//                       minimum m >= min_frame.
 //   K2 k_verify         the exact threshold resp < 0.05*min_frame (detector.rs:418,177) at the set
-//                       bits only (response recomputed from the blur plane); k_seeds: flood seeds
-//                       (candidates with no left / upper candidate) from the mask
+//                       bits that can still fail (response recomputed from the blur plane);
+//                       k_seeds: flood seeds from the mask
 //   K3 k_flood          4-connected components (image_util.rs:208-236) + centroid sums
 //                       (detector.rs:421-429): one component per lane, bit-parallel flood fill
-//                       of a 32x32 window of the mask held in registers
+//                       of a 32x32 window of the mask held in registers; oversized components
+//                       by the whole wave in a 128x64 window
 //   K3g k_generic       guarded generic fallback (mask -> candidate list -> lock-free
-//                       union-find -> sums) for frames where a component leaves the window
+//                       union-find -> sums) for frames where a component leaves that window too
 //   K4 k_refine         rochade_refine (detector.rs:194-361), one cluster per lane
 //   K5 k_filter_sort    k/phi filter (detector.rs:436-445), emission in reference order
 #include <hip/hip_runtime.h>
@@ -192,7 +194,8 @@ __device__ __forceinline__ uint32_t luma_byte(const RawPx<FMT> &r, int j)
 // pixels, pulls the 3+3 neighbouring pixels from the adjacent lanes by DPP, does the 7-tap
 // horizontal pass, pushes the result into a 7-row register window for the vertical pass,
 // stores the blur row, and evaluates the Hessian determinant of the previous row (its left /
-// right blur neighbours again by DPP) for the per-frame minimum.  No LDS, no barriers.
+// right blur neighbours again by DPP) for the per-frame minimum.  No LDS exchange and no barriers in
+// the row loop; 8-bit formats read their tap products from an LDS table built once per workgroup.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ int H_full_segs(const ChainArgs &a) { return a.H / a.rows_per_seg; }
 
