@@ -135,3 +135,34 @@ def test_host_tail_library_entry_points_via_cpu_handle(lib):
     assert lib.agx_family_from_str(b"t25h9", C.byref(fam)) == 0 and fam.value == 2
     assert lib.agx_family_from_str(b"nope", C.byref(fam)) == -6
     assert lib.agx_status_string(-3) == b"capacity exceeded"
+
+
+def _build_c_client(tmp_path):
+    """examples/c_client.c: a plain-C99 program against include/aprilgrid_amd.h, linked with the
+    library -- no Python, no torch in that process."""
+    import subprocess
+    exe = str(tmp_path / "c_client")
+    pkg = os.path.join(ROOT, "aprilgrid-rs_amd")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "examples", "c_client.c"), "-L", pkg, "-laprilgrid_amd",
+                    "-Wl,-rpath," + pkg, "-o", exe], check=True)
+    return exe
+
+
+def test_c_client_builds_and_fails_loudly_without_a_device(tmp_path):
+    import subprocess
+    import numpy as np
+    exe = _build_c_client(tmp_path)
+    raw = tmp_path / "flat.raw"
+    np.full((64, 64), 128, np.uint8).tofile(raw)
+    r = subprocess.run([exe, str(raw), "64", "64"], capture_output=True, text=True)
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    if has_gpu:
+        assert r.returncode == 0 and "0 saddles, 0 tags" in r.stdout, (r.stdout, r.stderr)
+    else:  # the product path has no CPU fallback
+        assert r.returncode == 1 and "no usable gfx950 device" in r.stderr, (r.stdout, r.stderr)
+

@@ -319,6 +319,23 @@ def test_randomised_sizes_formats_batches(det, oracle):
             check_saddles(res[i], oracle.refined_saddle_points(host[i]), "case %d %s %dx%d frame %d" % (case, fmt, w, h, i))
 
 
+def test_plain_c_client_of_the_abi(oracle, tmp_path):
+    """examples/c_client.c (C99, no Python / torch in the process) on a synthetic board frame:
+    the same counts and first saddle as the oracle."""
+    import subprocess
+    from tests.test_abi_cpu import _build_c_client
+    synth = synth_module()
+    img = np.asarray(synth.render_frame(4, 640, 480)[0])
+    raw = tmp_path / "frame.raw"
+    img.tofile(raw)
+    r = subprocess.run([_build_c_client(tmp_path), str(raw), "640", "480"], capture_output=True, text=True)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    ref = oracle.refined_saddle_points(img)
+    tags = oracle.detect(img)
+    assert "%d saddles, %d tags" % (len(ref), len(tags)) in r.stdout, (r.stdout, len(ref), len(tags))
+    assert "first saddle (%.3f, %.3f) k=%.5f" % (ref["x"][0], ref["y"][0], ref["k"][0]) in r.stdout, r.stdout
+
+
 def test_capacity_overflow_is_reported_not_truncated(oracle):
     import aprilgrid_rs_amd as A
     d = A.TagDetector("T36H11", None, device=0)
