@@ -760,8 +760,8 @@ __device__ __forceinline__ unsigned long long from_right_u64(unsigned long long 
     return (unsigned long long)from_right_u((uint32_t)v) | ((unsigned long long)from_right_u((uint32_t)(v >> 32)) << 32);
 }
 
-__device__ __forceinline__ void wave_flood_128x64(const ChainArgs &a, int frame, FrameCounters &ctr, const uint32_t *mask,
-                                                  uint32_t p, int lane)
+__device__ __forceinline__ void wave_flood_128x64(const ChainArgs &a, int frame, uint32_t *flags, uint32_t *n_clusters,
+                                                  const uint32_t *mask, uint32_t p, int lane)
 {
     const uint32_t W = (uint32_t)a.W;
     const uint32_t sx = p % W, sy = p / W;
@@ -792,7 +792,7 @@ __device__ __forceinline__ void wave_flood_128x64(const ChainArgs &a, int frame,
     const bool edge = (lane == 0 && comp[0] != 0ull) || (lane == 63 && comp[1] != 0ull) || (both >> 63) != 0ull;
     if (__any(earlier)) return;
     if (__any(edge)) {
-        if (lane == 0) atomicOr(&ctr.flags, FLAG_BIG_CLUSTER);
+        if (lane == 0) atomicOr(flags, FLAG_BIG_CLUSTER);
         return;
     }
     const uint32_t n0 = (uint32_t)__popcll(comp[0]), n1 = (uint32_t)__popcll(comp[1]);
@@ -805,7 +805,7 @@ __device__ __forceinline__ void wave_flood_128x64(const ChainArgs &a, int frame,
         s_y += __shfl_xor(s_y, off, 64);
     }
     if (lane == 0) {
-        const uint32_t o = atomicAdd(&ctr.n_clusters, 1u);
+        const uint32_t o = atomicAdd(n_clusters, 1u);
         if (o < a.cap_roots) {
             const size_t q = (size_t)frame * a.cap_roots + o;
             a.clu_key[q] = p;
@@ -813,9 +813,87 @@ __device__ __forceinline__ void wave_flood_128x64(const ChainArgs &a, int frame,
             a.clu_sx[q] = s_x;
             a.clu_sy[q] = s_y;
         } else {
-            atomicOr(&ctr.flags, FLAG_ROOT_OVERFLOW);
+            atomicOr(flags, FLAG_ROOT_OVERFLOW);
         }
     }
+}
+
+// First flood tier for one seed (one lane): 32 x 32 window.  Emits the cluster if the seed is the
+// canonical one and the component stays inside the window; returns true if the component may
+// continue outside (second tier).
+__device__ __forceinline__ bool flood_lane(const ChainArgs &a, int frame, const uint32_t *mask, uint32_t W, uint32_t p,
+                                           uint32_t *flags, uint32_t *n_clusters)
+{
+    const uint32_t sx = p % W, sy = p / W;
+    const int sh = (int)((sy - 1u) & 31u);
+    const uint32_t *wp = mask + (size_t)((sy - 1u) >> 5) * a.mask_wpr + MASK_PAD_X + ((int)sx - 16);
+    uint32_t cand[FLOOD_COLS], comp[FLOOD_COLS];
+#pragma unroll
+    for (int c = 0; c < FLOOD_COLS; ++c) {
+        const unsigned long long two = (unsigned long long)wp[c] | ((unsigned long long)wp[a.mask_wpr + c] << 32);
+        cand[c] = (uint32_t)(two >> sh);  // bit r = row sy-1+r of column sx-16+c
+        comp[c] = 0u;
+    }
+    comp[16] = 2u;  // the seed: column sx, row sy
+    // A right-to-left sweep applies the full update rule to every column with its current
+    // neighbours, so "that sweep changed nothing" IS the fixed point: the left-to-right
+    // sweep before it need not be watched (convex blobs finish after one pair of sweeps).
+    uint32_t changed;
+    do {
+        changed = 0u;
+#pragma unroll
+        for (int c = 0; c < FLOOD_COLS; ++c) {  // left-to-right sweep
+            uint32_t s = comp[c];
+            if (c > 0) s |= comp[c - 1];
+            if (c < FLOOD_COLS - 1) s |= comp[c + 1];
+            comp[c] = fill_runs(s & cand[c], cand[c]);
+        }
+#pragma unroll
+        for (int c = FLOOD_COLS - 1; c >= 0; --c) {  // right-to-left sweep
+            uint32_t s = comp[c];
+            if (c > 0) s |= comp[c - 1];
+            if (c < FLOOD_COLS - 1) s |= comp[c + 1];
+            const uint32_t f = fill_runs(s & cand[c], cand[c]);
+            changed |= f ^ comp[c];
+            comp[c] = f;
+        }
+    } while (changed);
+    uint32_t all = 0u, left_of_seed = 0u;
+#pragma unroll
+    for (int c = 0; c < FLOOD_COLS; ++c) {
+        all |= comp[c];
+        if (c < 16) left_of_seed |= comp[c];
+    }
+    // a pixel of the component precedes the seed in raster order -> not the canonical seed
+    const bool canonical = !((all & 1u) || (left_of_seed & 2u));
+    if (canonical) {
+        if ((all >> 31) || comp[0] || comp[FLOOD_COLS - 1]) {
+            return true;  // may continue outside the window: second tier below
+        } else {
+            uint32_t cnt = 0, sumx = 0, sumy = 0;
+#pragma unroll
+            for (int c = 0; c < FLOOD_COLS; ++c) {
+                const uint32_t w = comp[c];
+                const uint32_t nc = (uint32_t)__popc(w);
+                cnt += nc;
+                sumy += bitpos_sum(w);
+                sumx += nc * (uint32_t)c;
+            }
+            sumx += cnt * (sx - 16u);  // window column 0 is image column sx-16 (mod 2^32 arithmetic)
+            sumy += cnt * (sy - 1u);   // window row 0 is image row sy-1
+            const uint32_t o = atomicAdd(n_clusters, 1u);
+            if (o < a.cap_roots) {
+                const size_t q = (size_t)frame * a.cap_roots + o;
+                a.clu_key[q] = p;
+                a.clu_cnt[q] = cnt;
+                a.clu_sx[q] = sumx;
+                a.clu_sy[q] = sumy;
+            } else {
+                atomicOr(flags, FLAG_ROOT_OVERFLOW);
+            }
+        }
+    }
+    return false;
 }
 
 __global__ void __launch_bounds__(64) k_flood(ChainArgs a)
@@ -834,75 +912,7 @@ __global__ void __launch_bounds__(64) k_flood(ChainArgs a)
         bool big = false;
         if (i < n) {
             p = a.seeds[(size_t)frame * a.cap_roots + i];
-            const uint32_t sx = p % W, sy = p / W;
-            const int sh = (int)((sy - 1u) & 31u);
-            const uint32_t *wp = mask + (size_t)((sy - 1u) >> 5) * a.mask_wpr + MASK_PAD_X + ((int)sx - 16);
-            uint32_t cand[FLOOD_COLS], comp[FLOOD_COLS];
-#pragma unroll
-            for (int c = 0; c < FLOOD_COLS; ++c) {
-                const unsigned long long two = (unsigned long long)wp[c] | ((unsigned long long)wp[a.mask_wpr + c] << 32);
-                cand[c] = (uint32_t)(two >> sh);  // bit r = row sy-1+r of column sx-16+c
-                comp[c] = 0u;
-            }
-            comp[16] = 2u;  // the seed: column sx, row sy
-            // A right-to-left sweep applies the full update rule to every column with its current
-            // neighbours, so "that sweep changed nothing" IS the fixed point: the left-to-right
-            // sweep before it need not be watched (convex blobs finish after one pair of sweeps).
-            uint32_t changed;
-            do {
-                changed = 0u;
-#pragma unroll
-                for (int c = 0; c < FLOOD_COLS; ++c) {  // left-to-right sweep
-                    uint32_t s = comp[c];
-                    if (c > 0) s |= comp[c - 1];
-                    if (c < FLOOD_COLS - 1) s |= comp[c + 1];
-                    comp[c] = fill_runs(s & cand[c], cand[c]);
-                }
-#pragma unroll
-                for (int c = FLOOD_COLS - 1; c >= 0; --c) {  // right-to-left sweep
-                    uint32_t s = comp[c];
-                    if (c > 0) s |= comp[c - 1];
-                    if (c < FLOOD_COLS - 1) s |= comp[c + 1];
-                    const uint32_t f = fill_runs(s & cand[c], cand[c]);
-                    changed |= f ^ comp[c];
-                    comp[c] = f;
-                }
-            } while (changed);
-            uint32_t all = 0u, left_of_seed = 0u;
-#pragma unroll
-            for (int c = 0; c < FLOOD_COLS; ++c) {
-                all |= comp[c];
-                if (c < 16) left_of_seed |= comp[c];
-            }
-            // a pixel of the component precedes the seed in raster order -> not the canonical seed
-            const bool canonical = !((all & 1u) || (left_of_seed & 2u));
-            if (canonical) {
-                if ((all >> 31) || comp[0] || comp[FLOOD_COLS - 1]) {
-                    big = true;  // may continue outside the window: second tier below
-                } else {
-                    uint32_t cnt = 0, sumx = 0, sumy = 0;
-#pragma unroll
-                    for (int c = 0; c < FLOOD_COLS; ++c) {
-                        const uint32_t w = comp[c];
-                        const uint32_t nc = (uint32_t)__popc(w);
-                        cnt += nc;
-                        sumy += bitpos_sum(w);
-                        sumx += nc * (uint32_t)c;
-                    }
-                    sumx += cnt * (sx - 16u);  // window column 0 is image column sx-16 (mod 2^32 arithmetic)
-                    sumy += cnt * (sy - 1u);   // window row 0 is image row sy-1
-                    const uint32_t o = atomicAdd(&ctr.n_clusters, 1u);
-                    if (o < a.cap_roots) {
-                        const size_t q = (size_t)frame * a.cap_roots + o;
-                        a.clu_key[q] = p;
-                        a.clu_cnt[q] = cnt;
-                        a.clu_sx[q] = sumx;
-                        a.clu_sy[q] = sumy;
-                    } else {
-                        atomicOr(&ctr.flags, FLAG_ROOT_OVERFLOW);
-                    }
-                }
-            }
+            big = flood_lane(a, frame, mask, W, p, &ctr.flags, &ctr.n_clusters);
         }
         // oversized components (about 0.5 % of the seeds on real frames): the whole wave floods a
         // 128 x 64 window for each of them in turn
@@ -911,7 +921,7 @@ __global__ void __launch_bounds__(64) k_flood(ChainArgs a)
         while (bigm) {
             const int src = __ffsll((long long)bigm) - 1;
             bigm &= bigm - 1ull;
-            wave_flood_128x64(a, frame, ctr, mask, __shfl(p, src, 64), lane);
+            wave_flood_128x64(a, frame, &ctr.flags, &ctr.n_clusters, mask, __shfl(p, src, 64), lane);
         }
     }
 }
@@ -1071,6 +1081,113 @@ __global__ void k_debug_resp(const float *__restrict__ blur, float *__restrict__
 // ------------------------------------------------------------------------------------------
 // K4: rochade_refine, detector.rs:265-359, one cluster per lane.
 // ------------------------------------------------------------------------------------------
+// rochade_refine of cluster s of `frame` (detector.rs:265-359).  Appends a RefinedRec through the
+// counters given (the global per-frame counters, or a workgroup's LDS copies).
+template <bool VEC>
+__device__ __forceinline__ void refine_cluster(const ChainArgs &a, const RefineConsts &rc, int frame, size_t cbase,
+                                               const float *img, int W, int H, uint32_t s, uint32_t *n_refined,
+                                               uint32_t *max_k_bits)
+{
+    const uint32_t sx = a.clu_sx[cbase + s], sy = a.clu_sy[cbase + s], cn = a.clu_cnt[cbase + s];
+    if (sx >= (1u << 24) || sy >= (1u << 24)) atomicOr(&a.ctr[frame].flags, FLAG_CENTROID_INEXACT);
+    const float fn = (float)cn;
+    const float initial_x = (float)sx / fn;  // detector.rs:427
+    const float initial_y = (float)sy / fn;
+    a.clu_sx[cbase + s] = __float_as_uint(initial_x);  // kept for agx_debug_fetch
+    a.clu_sy[cbase + s] = __float_as_uint(initial_y);
+    const float rxf = roundf(initial_x), ryf = roundf(initial_y);
+    const int round_x = (int)rxf, round_y = (int)ryf;
+    if (round_y - 4 < 0 || round_y + 4 >= H || round_x - 4 < 0 || round_x + 4 >= W) return;
+    // The 9x9 window is streamed row by row through 25 running sums.  Patch value (r,c)
+    // receives its 25 taps in the reference's order (:283-297): window rows r..r+4 arrive in
+    // ascending order and the 5 taps of a row are added left to right.  Patch row r is
+    // complete after window row r+4 and is then folded into the 6 parameter sums (:321-328,
+    // i = r*5+c ascending).
+    const int wx0 = round_x - 4;
+    const int al = VEC ? (wx0 & 3) : 0;
+    const float *win = img + (size_t)(round_y - 4) * W + (wx0 - al);
+    float conv[25];
+#pragma unroll
+    for (int q = 0; q < 25; ++q) conv[q] = 0.0f;
+    float prm[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int wr = 0; wr < 9; ++wr) {
+        float v[9];
+        if (VEC) {
+            // three aligned 16-byte loads cover the 9 floats; shift by the misalignment
+            const float4 q0 = *reinterpret_cast<const float4 *>(win + (size_t)wr * W);
+            const float4 q1 = *reinterpret_cast<const float4 *>(win + (size_t)wr * W + 4);
+            const float4 q2 = *reinterpret_cast<const float4 *>(win + (size_t)wr * W + 8);
+            const bool s1 = (al & 1) != 0, s2 = (al & 2) != 0;
+            // shift left by 1 if s1, then by 2 if s2 (all indices compile-time)
+            const float u0 = s1 ? q0.y : q0.x, u1 = s1 ? q0.z : q0.y, u2 = s1 ? q0.w : q0.z, u3 = s1 ? q1.x : q0.w;
+            const float u4 = s1 ? q1.y : q1.x, u5 = s1 ? q1.z : q1.y, u6 = s1 ? q1.w : q1.z, u7 = s1 ? q2.x : q1.w;
+            const float u8 = s1 ? q2.y : q2.x, u9 = s1 ? q2.z : q2.y, u10 = s1 ? q2.w : q2.z;
+            v[0] = s2 ? u2 : u0; v[1] = s2 ? u3 : u1; v[2] = s2 ? u4 : u2; v[3] = s2 ? u5 : u3; v[4] = s2 ? u6 : u4;
+            v[5] = s2 ? u7 : u5; v[6] = s2 ? u8 : u6; v[7] = s2 ? u9 : u7; v[8] = s2 ? u10 : u8;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 9; ++e) v[e] = win[(size_t)wr * W + e];
+        }
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            const int pr = wr - r;
+            if (pr < 0 || pr > 4) continue;
+#pragma unroll
+            for (int c = 0; c < 5; ++c)
+#pragma unroll
+                for (int pc = 0; pc < 5; ++pc) conv[r * 5 + c] = conv[r * 5 + c] + v[c + pc] * rc.cone[pr * 5 + pc];
+        }
+        if (wr >= 4) {
+            const int r = wr - 4;
+#pragma unroll
+            for (int c = 0; c < 5; ++c)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) prm[j] = prm[j] + rc.pmat[(r * 5 + c) * 6 + j] * conv[r * 5 + c];
+        }
+    }
+    const float a1 = prm[0], a2 = prm[1], a3 = prm[2], a4 = prm[3], a5 = prm[4];
+    const float fxx = 2.0f * a1, fyy = 2.0f * a3, fxy = a2;
+    const float d = fxx * fyy - fxy * fxy;
+    if (!(d < 0.0f)) return;
+    // find_xy(2a1, a2, a4, a2, 2a3, a5), math_util.rs:5-12: 2x2 LU with row pivoting
+    float x0, y0;
+    {
+        const float A0 = 2.0f * a1, B0 = a2, R0 = -a4;
+        const float A1 = a2, B1 = 2.0f * a3, R1 = -a5;
+        float pa, pb, pr_, qa, qb, qr;
+        if (fabsf(A1) > fabsf(A0)) {
+            pa = A1; pb = B1; pr_ = R1; qa = A0; qb = B0; qr = R0;
+        } else {
+            pa = A0; pb = B0; pr_ = R0; qa = A1; qb = B1; qr = R1;
+        }
+        const float l = qa / pa;
+        const float u22 = qb - l * pb;
+        const float y2 = qr - l * pr_;
+        y0 = y2 / u22;
+        x0 = (pr_ - pb * y0) / pa;
+    }
+    if (!(fabsf(x0) <= 1.0f && fabsf(y0) <= 1.0f)) return;
+    const float c5 = (a1 + a3) / 2.0f;
+    const float c4 = (a1 - a3) / 2.0f;
+    const float c3 = a2 / 2.0f;
+    const float k = sqrtf(c4 * c4 + c3 * c3);
+    if (!(fabsf(c5) < k)) return;
+    const float PI_F = 3.14159274101257324219f;
+    const float phi = acosf(-c5 / k) / 2.0f / PI_F * 180.0f;
+    const float theta = atan2f(c3, c4) / 2.0f / PI_F * 180.0f;
+    uint32_t o = atomicAdd(n_refined, 1u);  // o < n_clusters <= cap_roots
+    RefinedRec rec;
+    rec.key = a.clu_key[cbase + s];
+    rec.x = rxf + x0;
+    rec.y = ryf + y0;
+    rec.k = k;
+    rec.theta = theta;
+    rec.phi = phi;
+    a.refined[(size_t)frame * a.cap_roots + o] = rec;
+    atomicMax(max_k_bits, __float_as_uint(k));
+}
+
 template <bool VEC>
 __global__ void __launch_bounds__(64, 4) k_refine(ChainArgs a, RefineConsts rc)
 {
@@ -1082,105 +1199,7 @@ __global__ void __launch_bounds__(64, 4) k_refine(ChainArgs a, RefineConsts rc)
     const float *img = a.blur + (size_t)frame * (size_t)a.plane;
     const int W = a.W, H = a.H;
     for (uint32_t i = fs.slot * blockDim.x + threadIdx.x; i < n; i += fs.n_slots * blockDim.x) {
-        const uint32_t s = i;
-        const uint32_t sx = a.clu_sx[cbase + s], sy = a.clu_sy[cbase + s], cn = a.clu_cnt[cbase + s];
-        if (sx >= (1u << 24) || sy >= (1u << 24)) atomicOr(&a.ctr[frame].flags, FLAG_CENTROID_INEXACT);
-        const float fn = (float)cn;
-        const float initial_x = (float)sx / fn;  // detector.rs:427
-        const float initial_y = (float)sy / fn;
-        a.clu_sx[cbase + s] = __float_as_uint(initial_x);  // kept for agx_debug_fetch
-        a.clu_sy[cbase + s] = __float_as_uint(initial_y);
-        const float rxf = roundf(initial_x), ryf = roundf(initial_y);
-        const int round_x = (int)rxf, round_y = (int)ryf;
-        if (round_y - 4 < 0 || round_y + 4 >= H || round_x - 4 < 0 || round_x + 4 >= W) continue;
-        // The 9x9 window is streamed row by row through 25 running sums.  Patch value (r,c)
-        // receives its 25 taps in the reference's order (:283-297): window rows r..r+4 arrive in
-        // ascending order and the 5 taps of a row are added left to right.  Patch row r is
-        // complete after window row r+4 and is then folded into the 6 parameter sums (:321-328,
-        // i = r*5+c ascending).
-        const int wx0 = round_x - 4;
-        const int al = VEC ? (wx0 & 3) : 0;
-        const float *win = img + (size_t)(round_y - 4) * W + (wx0 - al);
-        float conv[25];
-#pragma unroll
-        for (int q = 0; q < 25; ++q) conv[q] = 0.0f;
-        float prm[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int wr = 0; wr < 9; ++wr) {
-            float v[9];
-            if (VEC) {
-                // three aligned 16-byte loads cover the 9 floats; shift by the misalignment
-                const float4 q0 = *reinterpret_cast<const float4 *>(win + (size_t)wr * W);
-                const float4 q1 = *reinterpret_cast<const float4 *>(win + (size_t)wr * W + 4);
-                const float4 q2 = *reinterpret_cast<const float4 *>(win + (size_t)wr * W + 8);
-                const bool s1 = (al & 1) != 0, s2 = (al & 2) != 0;
-                // shift left by 1 if s1, then by 2 if s2 (all indices compile-time)
-                const float u0 = s1 ? q0.y : q0.x, u1 = s1 ? q0.z : q0.y, u2 = s1 ? q0.w : q0.z, u3 = s1 ? q1.x : q0.w;
-                const float u4 = s1 ? q1.y : q1.x, u5 = s1 ? q1.z : q1.y, u6 = s1 ? q1.w : q1.z, u7 = s1 ? q2.x : q1.w;
-                const float u8 = s1 ? q2.y : q2.x, u9 = s1 ? q2.z : q2.y, u10 = s1 ? q2.w : q2.z;
-                v[0] = s2 ? u2 : u0; v[1] = s2 ? u3 : u1; v[2] = s2 ? u4 : u2; v[3] = s2 ? u5 : u3; v[4] = s2 ? u6 : u4;
-                v[5] = s2 ? u7 : u5; v[6] = s2 ? u8 : u6; v[7] = s2 ? u9 : u7; v[8] = s2 ? u10 : u8;
-            } else {
-#pragma unroll
-                for (int e = 0; e < 9; ++e) v[e] = win[(size_t)wr * W + e];
-            }
-#pragma unroll
-            for (int r = 0; r < 5; ++r) {
-                const int pr = wr - r;
-                if (pr < 0 || pr > 4) continue;
-#pragma unroll
-                for (int c = 0; c < 5; ++c)
-#pragma unroll
-                    for (int pc = 0; pc < 5; ++pc) conv[r * 5 + c] = conv[r * 5 + c] + v[c + pc] * rc.cone[pr * 5 + pc];
-            }
-            if (wr >= 4) {
-                const int r = wr - 4;
-#pragma unroll
-                for (int c = 0; c < 5; ++c)
-#pragma unroll
-                    for (int j = 0; j < 6; ++j) prm[j] = prm[j] + rc.pmat[(r * 5 + c) * 6 + j] * conv[r * 5 + c];
-            }
-        }
-        const float a1 = prm[0], a2 = prm[1], a3 = prm[2], a4 = prm[3], a5 = prm[4];
-        const float fxx = 2.0f * a1, fyy = 2.0f * a3, fxy = a2;
-        const float d = fxx * fyy - fxy * fxy;
-        if (!(d < 0.0f)) continue;
-        // find_xy(2a1, a2, a4, a2, 2a3, a5), math_util.rs:5-12: 2x2 LU with row pivoting
-        float x0, y0;
-        {
-            const float A0 = 2.0f * a1, B0 = a2, R0 = -a4;
-            const float A1 = a2, B1 = 2.0f * a3, R1 = -a5;
-            float pa, pb, pr_, qa, qb, qr;
-            if (fabsf(A1) > fabsf(A0)) {
-                pa = A1; pb = B1; pr_ = R1; qa = A0; qb = B0; qr = R0;
-            } else {
-                pa = A0; pb = B0; pr_ = R0; qa = A1; qb = B1; qr = R1;
-            }
-            const float l = qa / pa;
-            const float u22 = qb - l * pb;
-            const float y2 = qr - l * pr_;
-            y0 = y2 / u22;
-            x0 = (pr_ - pb * y0) / pa;
-        }
-        if (!(fabsf(x0) <= 1.0f && fabsf(y0) <= 1.0f)) continue;
-        const float c5 = (a1 + a3) / 2.0f;
-        const float c4 = (a1 - a3) / 2.0f;
-        const float c3 = a2 / 2.0f;
-        const float k = sqrtf(c4 * c4 + c3 * c3);
-        if (!(fabsf(c5) < k)) continue;
-        const float PI_F = 3.14159274101257324219f;
-        const float phi = acosf(-c5 / k) / 2.0f / PI_F * 180.0f;
-        const float theta = atan2f(c3, c4) / 2.0f / PI_F * 180.0f;
-        uint32_t o = atomicAdd(&a.ctr[frame].n_refined, 1u);  // o < n_clusters <= cap_roots
-        RefinedRec rec;
-        rec.key = a.clu_key[cbase + s];
-        rec.x = rxf + x0;
-        rec.y = ryf + y0;
-        rec.k = k;
-        rec.theta = theta;
-        rec.phi = phi;
-        a.refined[(size_t)frame * a.cap_roots + o] = rec;
-        atomicMax(&a.ctr[frame].max_k_bits, __float_as_uint(k));
+        refine_cluster<VEC>(a, rc, frame, cbase, img, W, H, i, &a.ctr[frame].n_refined, &a.ctr[frame].max_k_bits);
     }
 }
 
@@ -1188,27 +1207,25 @@ __global__ void __launch_bounds__(64, 4) k_refine(ChainArgs a, RefineConsts rc)
 // K5: filter (detector.rs:436-445) and emission in the reference's order = ascending first
 // (smallest) pixel index of the cluster.  One workgroup per frame; bitonic sort in LDS.
 // ------------------------------------------------------------------------------------------
-__global__ void k_filter_sort(ChainArgs a, uint32_t lds_entries)
+// The k / phi filter (detector.rs:436-445) and the ordered emission of one frame by one workgroup:
+// n refined records, largest k as raw bits; keys / idxs are LDS arrays of lds_entries words each.
+__device__ __forceinline__ void filter_sort_emit(const ChainArgs &a, int frame, uint32_t n, uint32_t max_k_bits,
+                                                 uint32_t *keys, uint32_t *idxs, uint32_t lds_entries, uint32_t *s_count,
+                                                 uint32_t *s_offset, uint32_t *s_fits)
 {
-    extern __shared__ uint32_t lds_u[];
-    uint32_t *keys = lds_u;
-    uint32_t *idxs = lds_u + lds_entries;
-    __shared__ uint32_t s_count, s_offset, s_fits;
-    const int frame = blockIdx.x;
     const uint32_t t = threadIdx.x, T = blockDim.x;
     FrameCounters &ctr = a.ctr[frame];
-    const uint32_t n = ctr.n_refined;
     const RefinedRec *rec = a.refined + (size_t)frame * a.cap_roots;
-    if (t == 0) s_count = 0;
+    if (t == 0) *s_count = 0;
     __syncthreads();
     uint32_t nf = 0;
     bool ok = true;
     if (n != 0) {  // detector.rs:432-434: nothing refined -> empty result
-        const float s_max_k = __uint_as_float(ctr.max_k_bits) / 10.0f;
+        const float s_max_k = __uint_as_float(max_k_bits) / 10.0f;
         for (uint32_t i = t; i < n; i += T) {
             const float k = rec[i].k, phi = rec[i].phi;
             if (k >= s_max_k && phi >= a.min_angle && phi <= a.max_angle) {
-                uint32_t o = atomicAdd(&s_count, 1u);
+                uint32_t o = atomicAdd(s_count, 1u);
                 if (o < lds_entries) {
                     keys[o] = rec[i].key;
                     idxs[o] = i;
@@ -1216,7 +1233,7 @@ __global__ void k_filter_sort(ChainArgs a, uint32_t lds_entries)
             }
         }
         __syncthreads();
-        nf = s_count;
+        nf = *s_count;
         ok = nf <= a.cap_out && nf <= lds_entries;
     }
     if (ok && nf) {
@@ -1251,8 +1268,8 @@ __global__ void k_filter_sort(ChainArgs a, uint32_t lds_entries)
             if (off + nf > a.out_total_cap) fits = 0;  // caller's buffer is full
         }
         if (!ok || !fits) atomicOr(&ctr.flags, FLAG_OUT_OVERFLOW);
-        s_offset = off;
-        s_fits = fits;
+        *s_offset = off;
+        *s_fits = fits;
         ctr.n_out = nf;
         ctr.out_offset = off;
         if (a.frame_table) {
@@ -1266,8 +1283,8 @@ __global__ void k_filter_sort(ChainArgs a, uint32_t lds_entries)
         }
     }
     __syncthreads();
-    if (!ok || !nf || !s_fits) return;
-    float *out = a.out + (size_t)s_offset * 5;
+    if (!ok || !nf || !*s_fits) return;
+    float *out = a.out + (size_t)*s_offset * 5;
     for (uint32_t i = t; i < nf; i += T) {
         const RefinedRec r = rec[idxs[i]];
         out[i * 5 + 0] = r.x;
@@ -1276,6 +1293,16 @@ __global__ void k_filter_sort(ChainArgs a, uint32_t lds_entries)
         out[i * 5 + 3] = r.theta;
         out[i * 5 + 4] = r.phi;
     }
+}
+
+__global__ void k_filter_sort(ChainArgs a, uint32_t lds_entries)
+{
+    extern __shared__ uint32_t lds_u[];
+    __shared__ uint32_t s_count, s_offset, s_fits;
+    const int frame = blockIdx.x;
+    const FrameCounters &ctr = a.ctr[frame];
+    filter_sort_emit(a, frame, ctr.n_refined, ctr.max_k_bits, lds_u, lds_u + lds_entries, lds_entries, &s_count, &s_offset,
+                     &s_fits);
 }
 
 // ------------------------------------------------------------------------------------------
