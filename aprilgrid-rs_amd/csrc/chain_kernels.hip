@@ -607,6 +607,28 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
     if (lane == 0) atomicMax(&ctr.min_key_inv, ~f32_order_key(run_min));  // always: the word must end up valid
 }
 
+// Re-test the set bits of one mask word against the final threshold (exact response from the blur
+// plane, same expression and operands as K1); returns the bits that stay.
+__device__ __forceinline__ uint32_t retest_word(const float *blur, int W, int yb, int x, uint32_t m0, float thr)
+{
+    uint32_t m = m0, keep = m0;
+    while (m) {
+        const int b = __ffs(m) - 1;
+        m &= m - 1;
+        const float *c = blur + (size_t)(yb * 32 + b) * W + x;  // interior pixel (K1 sets no border bits)
+        const float v11 = c[-W - 1], v12 = c[-W], v13 = c[-W + 1];
+        const float v21 = c[-1], v22 = c[0], v23 = c[1];
+        const float v31 = c[W - 1], v32 = c[W], v33 = c[W + 1];
+        const float t22 = v22 * 2.0f;
+        const float lxx = (v21 - t22) + v23;
+        const float lyy = (v12 - t22) + v32;
+        const float lxy = (((v13 - v11) + v31) - v33) * 0.25f;
+        const float d = lxx * lyy - lxy * lxy;
+        if (!(d < thr)) keep &= ~(1u << b);
+    }
+    return keep;
+}
+
 // ------------------------------------------------------------------------------------------
 // K2: verify.  K1 left a superset of the candidates in the mask (threshold from a running
 // minimum).  One thread per mask word: at every set bit recompute the Hessian determinant from
@@ -630,21 +652,7 @@ __global__ void __launch_bounds__(64) k_verify(ChainArgs a)
         // every candidate K1 admitted in this word's 4-column x 32-row block is <= cand_max: if that
         // is below the final threshold they all pass and nothing needs recomputing
         if (a.cand_max[((size_t)frame * a.mask_yb + yb) * (a.mask_wpr >> 2) + ((MASK_PAD_X + x) >> 2)] < thr) continue;
-        uint32_t m = m0, keep = m0;
-        while (m) {
-            const int b = __ffs(m) - 1;
-            m &= m - 1;
-            const float *c = blur + (size_t)(yb * 32 + b) * W + x;  // interior pixel (K1 sets no border bits)
-            const float v11 = c[-W - 1], v12 = c[-W], v13 = c[-W + 1];
-            const float v21 = c[-1], v22 = c[0], v23 = c[1];
-            const float v31 = c[W - 1], v32 = c[W], v33 = c[W + 1];
-            const float t22 = v22 * 2.0f;
-            const float lxx = (v21 - t22) + v23;
-            const float lyy = (v12 - t22) + v32;
-            const float lxy = (((v13 - v11) + v31) - v33) * 0.25f;
-            const float d = lxx * lyy - lxy * lxy;
-            if (!(d < thr)) keep &= ~(1u << b);
-        }
+        const uint32_t keep = retest_word(blur, W, yb, x, m0, thr);
         if (keep != m0) *wp = keep;
     }
 }
@@ -974,11 +982,11 @@ __device__ __forceinline__ void uf_unite(uint32_t *parent, uint32_t x, uint32_t 
     }
 }
 
-__global__ void __launch_bounds__(1024) k_generic(ChainArgs a)
+// The generic clustering of one frame by one workgroup (any size): four phases separated by
+// workgroup barriers + agent-scope fences.  Replaces the frame's cluster records.
+__device__ __forceinline__ void generic_frame(const ChainArgs &a, int frame)
 {
-    const int frame = blockIdx.x;
     FrameCounters &ctr = a.ctr[frame];
-    if (!frame_is_generic(a, ctr)) return;  // whole workgroup
     const uint32_t T = blockDim.x, t = threadIdx.x;
     const uint32_t *mask = a.mask + (size_t)frame * (size_t)a.mask_plane;
     const int wpr = a.mask_wpr, W = a.W;
@@ -1055,6 +1063,14 @@ __global__ void __launch_bounds__(1024) k_generic(ChainArgs a)
     }
     if (t == 0) ctr.n_clusters = nr;
 }
+
+__global__ void __launch_bounds__(1024) k_generic(ChainArgs a)
+{
+    const int frame = blockIdx.x;
+    if (!frame_is_generic(a, a.ctr[frame])) return;  // whole workgroup
+    generic_frame(a, frame);
+}
+
 
 // Debug only (agx_debug_fetch AGX_DBG_RESP): the response plane K2 thresholds, materialised.
 __global__ void k_debug_resp(const float *__restrict__ blur, float *__restrict__ resp, int W, int H)
