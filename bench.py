@@ -15,8 +15,10 @@ slabs to rank 0.
 Rank 0 prints ONE JSON line.  value = pixels of all ranks through the chain per second
 (Mpix/s), inputs resident in HBM.  roofline = K1 (the dominant kernel): algorithmic bytes per
 launch / average launch duration from hipEvents recorded on the launch stream inside the
-timed region.  cpu_baseline = the C oracle (port of the reference CPU path, 1 thread) on a
-bounded sample of the same frames, rank 0, N = 1 only.
+timed region.  cpu_baseline = the C oracle (port of the reference CPU path, 1 thread; all_cores =
+the same frame-parallel on the host cores) on a bounded sample of the same frames, rank 0, N = 1
+only.  The timed region is strictly serial (one batch at a time); at N = 1 a second pass with
+--extra-pipeline batches in flight (sharding.ChainPipeline) is reported as "pipelined".
 """
 import argparse
 import json
