@@ -213,7 +213,7 @@ int ensure_workspace(agx_detector *d, int n_frames, int W, int H)
     const long long plane = (long long)W * H;
     const uint32_t cap_cand = d->lim_cand ? d->lim_cand : clamp_u32((unsigned long long)plane / 2, 4096, 1u << 28);
     const uint32_t cap_roots = d->lim_roots ? d->lim_roots : clamp_u32((unsigned long long)plane / 8, 1024, 1u << 26);
-    const uint32_t cap_out = d->lim_out ? d->lim_out : clamp_u32((unsigned long long)plane / 64, 256, 8192);
+    const uint32_t cap_out = d->lim_out ? d->lim_out : clamp_u32((unsigned long long)plane / 64, 256, 16384);
     ChainArgs &a = d->args;
     const bool fits = (size_t)n_frames <= d->cap_frames && plane <= d->cap_plane && cap_cand <= d->alloc_cand &&
                       cap_roots <= d->alloc_roots && cap_out <= d->alloc_out &&

@@ -259,7 +259,7 @@ class TagDetector:
                                                         fmt))
         self._batch = (n, None)
 
-    def saddles_batch_fetch(self, cap_per_frame=8192, raise_on_overflow=True):
+    def saddles_batch_fetch(self, cap_per_frame=16384, raise_on_overflow=True):
         """-> (list of SADDLE_DTYPE arrays, one per frame; per-frame status array)."""
         if self._batch is None:
             raise AgxError(_ffi.AGX_ERR_STATE, "no batch enqueued")

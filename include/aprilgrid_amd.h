@@ -98,7 +98,8 @@ int agx_detector_family_info(const agx_detector *det, int *edge_bits, int *borde
                              int *hamming_distance, const uint64_t **codes, int *n_codes);
 
 /* Internal list capacities per frame (0 = keep default).  Defaults scale with the frame:
- * candidates W*H/2, clusters W*H/8, saddles min(W*H/64, 16384).  Overflow of any of them
+ * candidates W*H/2, clusters W*H/8, saddles min(W*H/64, 16384) (also the largest max_saddles).
+ * Overflow of any of them
  * is reported as AGX_ERR_CAPACITY for that frame, never truncated. */
 int agx_detector_set_limits(agx_detector *det, uint32_t max_candidates, uint32_t max_clusters,
                             uint32_t max_saddles);
