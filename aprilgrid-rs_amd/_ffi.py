@@ -44,6 +44,7 @@ SYMBOLS = {
     "agx_detector_set_stream": (C.c_int, [_P, _P, C.c_int]),
     "agx_detector_sync": (C.c_int, [_P]),
     "agx_detector_set_option": (C.c_int, [_P, C.c_char_p, C.c_int]),
+    "agx_detector_get_option": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_int)]),
     "agx_refined_saddle_points": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_size_t, C.c_int, _P, C.c_uint32,
                                             C.POINTER(C.c_uint32)]),
     "agx_detect": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_size_t, C.c_int, _P, C.c_uint32,

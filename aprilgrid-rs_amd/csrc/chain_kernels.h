@@ -73,6 +73,7 @@ struct ChainArgs {
     float w[7];  // blur taps
     // dense planes [n_frames][H][W]
     float *blur;
+    float *resp_dbg;       // parity tests only ("store_response"): K1's in-register response, [n_frames][H][W]; else null
     float *dummy;          // one row (W + 8 floats): target of K1's out-of-segment stores
     // weakest (largest) response among the candidates K1 admitted, per 4 columns x 32 rows:
     // [n_frames][mask_yb][mask_wpr / 4] (same indexing as the mask, x/4); -inf where none

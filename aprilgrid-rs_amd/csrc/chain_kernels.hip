@@ -199,7 +199,9 @@ __device__ __forceinline__ uint32_t luma_byte(const RawPx<FMT> &r, int j)
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ int H_full_segs(const ChainArgs &a) { return a.H / a.rows_per_seg; }
 
-template <int FMT, bool A4>
+// RESP: debug instantiation (agx_detector_set_option "store_response") that also stores the
+// determinant this kernel evaluates in registers, for the parity tests (AGX_DBG_RESP).
+template <int FMT, bool A4, bool RESP = false>
 __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
 {
     const int lane = threadIdx.x & 63;
@@ -506,6 +508,12 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
                         // columns outside the lane's share (halo lanes, the image's border ring) hold a
                         // meaningless value here; they are masked where the columns are combined
                         dv[j] = lxx * lyy - lxy * lxy;
+                    }
+                    if (RESP) {  // the in-register response itself (border ring stays zero)
+                        float *rrow = a.resp_dbg + (size_t)frame * (size_t)a.plane + (size_t)y * W + c0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (min_ok[j]) rrow[j] = dv[j];
                     }
                     if (A4) {
                         rmin[0] = fminf(rmin[0], dv[0]);
@@ -1373,7 +1381,11 @@ static hipError_t launch_k1(const ChainArgs &a, hipStream_t st)
     dim3 grid((unsigned)((units + 3) / 4)), block(256);
     // the aligned form addresses a frame and its blur plane with 32-bit buffer offsets
     const bool small = a.plane * 4 < (1ll << 31) && (long long)a.H * a.row_stride < (1ll << 31);
-    if ((a.W & 3) == 0 && small) hipLaunchKernelGGL((k_blur_hessian<FMT, true>), grid, block, 0, st, a);
+    const bool a4 = (a.W & 3) == 0 && small;
+    if (a.resp_dbg) {  // parity-test instantiation: also stores the response it evaluates
+        if (a4) hipLaunchKernelGGL((k_blur_hessian<FMT, true, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((k_blur_hessian<FMT, false, true>), grid, block, 0, st, a);
+    } else if (a4) hipLaunchKernelGGL((k_blur_hessian<FMT, true>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((k_blur_hessian<FMT, false>), grid, block, 0, st, a);
     return hipGetLastError();
 }

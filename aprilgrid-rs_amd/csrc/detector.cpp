@@ -43,8 +43,12 @@ struct agx_detector {
     int force_generic = 0;
     int k1_rows = 0;
     int dbg = 0;
-    float *d_dbg_resp = nullptr;  // lazily allocated plane for agx_debug_fetch(AGX_DBG_RESP)
+    float *d_dbg_resp = nullptr;  // lazily allocated plane for agx_debug_fetch(AGX_DBG_RESP_RECOMPUTED)
     long long dbg_resp_plane = 0;
+    int store_resp = 0;           // option "store_response": K1's parity-test instantiation
+    float *d_resp_store = nullptr;  // [n_frames][H][W] planes it writes
+    size_t resp_store_floats = 0;
+    bool resp_stored = false;     // the last batch ran with store_response
     int ws_W = 0, ws_H = 0;       // geometry the mask plane was last zeroed for
 
     // workspace (device)
@@ -301,6 +305,7 @@ int enqueue_chunk(agx_detector *d, int f0, int nf, hipStream_t st)
     a.frames += F0 * (size_t)a.frame_stride;
     a.blur += F0 * (size_t)a.plane;
     a.slot_plane += F0 * (size_t)a.plane;
+    if (a.resp_dbg) a.resp_dbg += F0 * (size_t)a.plane;
     a.cand_max += F0 * (size_t)(a.mask_plane / 4);
     a.mask += F0 * (size_t)a.mask_plane;
     a.ctr += F0;
@@ -465,6 +470,7 @@ void agx_detector_destroy(agx_detector *det)
     free_workspace(det);
     if (det->d_stage) (void)hipFree(det->d_stage);
     if (det->d_dbg_resp) (void)hipFree(det->d_dbg_resp);
+    if (det->d_resp_store) (void)hipFree(det->d_resp_store);
     if (det->own_stream) (void)hipStreamDestroy(det->own_stream);
     delete det;
 }
@@ -507,7 +513,24 @@ int agx_detector_set_option(agx_detector *det, const char *name, int value)
     if (!std::strcmp(name, "force_generic")) det->force_generic = value != 0;
     else if (!std::strcmp(name, "k1_rows_per_segment")) det->k1_rows = value > 0 ? value : 0;
     else if (!std::strcmp(name, "debug_ablation")) det->dbg = value;  // timing only, results invalid
+    else if (!std::strcmp(name, "store_response")) det->store_resp = value != 0;
     else return fail(det, AGX_ERR_ARG, std::string("unknown option ") + name);
+    return AGX_OK;
+}
+
+int agx_detector_get_option(const agx_detector *det, const char *name, int *value)
+{
+    if (!det || !name || !value) return AGX_ERR_ARG;
+    const ChainArgs &a = det->args;
+    if (!std::strcmp(name, "force_generic")) *value = det->force_generic;
+    else if (!std::strcmp(name, "store_response")) *value = det->store_resp;
+    else if (!std::strcmp(name, "debug_ablation")) *value = det->dbg;
+    // the blur kernel's tiling of the last enqueued batch (0 before the first one)
+    else if (!std::strcmp(name, "k1_rows_per_segment")) *value = a.rows_per_seg;
+    else if (!std::strcmp(name, "k1_segments")) *value = a.n_segs;
+    else if (!std::strcmp(name, "k1_strips")) *value = a.n_strips;
+    else if (!std::strcmp(name, "k1_strip_columns")) *value = a.strip_cols;
+    else return AGX_ERR_ARG;
     return AGX_OK;
 }
 
@@ -560,6 +583,22 @@ static int batch_enqueue_impl(agx_detector *det, const void *d_frames, int n_fra
     }
     a.force_generic = det->force_generic;
     a.dbg = det->dbg;
+    a.resp_dbg = nullptr;
+    det->resp_stored = false;
+    if (det->store_resp) {  // parity tests: K1 also stores the response it evaluates in registers
+        const size_t need = (size_t)n_frames * (size_t)a.plane;
+        if (need > det->resp_store_floats) {
+            HIP_TRY(det, hipStreamSynchronize(det->stream));
+            if (det->d_resp_store) (void)hipFree(det->d_resp_store);
+            det->d_resp_store = nullptr;
+            det->resp_store_floats = 0;
+            HIP_TRY(det, hipMalloc((void **)&det->d_resp_store, need * sizeof(float)));
+            det->resp_store_floats = need;
+        }
+        HIP_TRY(det, hipMemsetAsync(det->d_resp_store, 0, need * sizeof(float), det->stream));  // the border ring is 0
+        a.resp_dbg = det->d_resp_store;
+        det->resp_stored = true;
+    }
     if (!plan_k1(a, det->k1_rows)) return fail(det, AGX_ERR_ARG, "unsupported frame geometry");
     return enqueue_chain(det);
 }
@@ -789,7 +828,16 @@ int agx_debug_fetch(agx_detector *det, int frame, int what, void *host_out, size
         return AGX_OK;
     }
     case AGX_DBG_RESP: {
-        // the chain never stores the response; materialise it from the blur plane on demand
+        // the response K1 evaluated in registers, stored by its "store_response" instantiation
+        *n_items = plane;
+        if (cap_bytes < plane * sizeof(float)) return AGX_ERR_CAPACITY;
+        if (!det->resp_stored)
+            return fail(det, AGX_ERR_STATE, "AGX_DBG_RESP needs option store_response=1 before the batch is enqueued");
+        HIP_TRY(det, hipMemcpy(host_out, det->d_resp_store + (size_t)frame * plane, plane * sizeof(float), hipMemcpyDeviceToHost));
+        return AGX_OK;
+    }
+    case AGX_DBG_RESP_RECOMPUTED: {
+        // cross-check: the response recomputed from the stored blur plane by a separate kernel
         *n_items = plane;
         if (cap_bytes < plane * sizeof(float)) return AGX_ERR_CAPACITY;
         if (det->dbg_resp_plane < (long long)plane) {

@@ -206,6 +206,11 @@ class TagDetector:
     def set_option(self, name, value):
         self._check(self._lib.agx_detector_set_option(self._h, name.encode(), int(value)))
 
+    def get_option(self, name):
+        v = C.c_int(0)
+        self._check(self._lib.agx_detector_get_option(self._h, name.encode(), C.byref(v)))
+        return v.value
+
     def sync(self):
         self._check(self._lib.agx_detector_sync(self._h))
 
@@ -298,11 +303,12 @@ class TagDetector:
         return w, cone, pmat
 
     def debug_fetch(self, frame, what, shape=None):
-        """Intermediate product of the last batch: 'blur', 'resp' (HxW f32), 'min' (f32),
+        """Intermediate product of the last batch: 'blur', 'resp' (HxW f32; K1's in-register response,
+        needs set_option("store_response", 1) before the batch), 'resp_recomputed', 'min' (f32),
         'centers' (cluster table sorted by first pixel), 'refined' (unfiltered saddles)."""
-        code = {"blur": 0, "resp": 1, "min": 2, "centers": 3, "refined": 4, "counters": 5}[what]
+        code = {"blur": 0, "resp": 1, "min": 2, "centers": 3, "refined": 4, "counters": 5, "resp_recomputed": 6}[what]
         n = C.c_size_t(0)
-        if code in (0, 1):
+        if code in (0, 1, 6):
             assert shape is not None
             buf = np.empty(shape, np.float32)
         elif code == 2:

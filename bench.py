@@ -44,8 +44,9 @@ def parse_args():
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--format", default="L8", choices=["L8", "L16", "RGB8"])
-    ap.add_argument("--unique", type=int, default=32,
-                    help="distinct rendered frames per GPU (tiled to --frames; rendering is not timed)")
+    ap.add_argument("--unique", type=int, default=0,
+                    help="distinct rendered frames per GPU, tiled to --frames (0 = every frame distinct: frame "
+                         "indices rank*F .. rank*F+F-1 of the seeded generator; rendering is not timed)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--noise", action="store_true", help="pure-noise frames (sensitivity row)")
@@ -60,6 +61,18 @@ def parse_args():
     ap.add_argument("--pmc-traffic", type=float, default=None,
                     help="HBM bytes per K1 launch from a separate rocprofv3 --pmc run (profiles/)")
     return ap.parse_args()
+
+
+def make_workload(first_frame, n_frames, width, height, fmt, unique, noise, device):
+    """The bench's frames: `unique` distinct frames [first_frame, first_frame + unique) of the seeded
+    renderer (per-frame seed = splitmix64(0xA9121D ^ frame_index)), rendered
+    straight into HBM and tiled to n_frames.  Returns (frames tensor, number of distinct frames)."""
+    from aprilgrid_rs_amd import synth
+    uniq = max(1, min(unique if unique > 0 else n_frames, n_frames))
+    base, _ = synth.render_batch(first_frame, uniq, width, height, device=device, fmt=fmt, pure_noise=noise)
+    reps = (n_frames + uniq - 1) // uniq
+    frames = base.repeat((reps,) + (1,) * (base.dim() - 1))[:n_frames].contiguous()
+    return frames, uniq
 
 
 def cpu_baseline(frames_host, fmt, budget_s):
@@ -147,12 +160,8 @@ def main():
     W, H, F = args.width, args.height, args.frames
     # ---- synthetic workload: frames [rank*F, rank*F + F) of the seeded generator, rendered
     # straight into HBM; `unique` distinct frames tiled (rendering is outside the timed region)
-    uniq = max(1, min(args.unique, F))
     first_frame, _ = sharding.shard_range(rank, world, F)
-    base, gts = synth.render_batch(first_frame, uniq, W, H, device=dev, fmt=args.format, pure_noise=args.noise)
-    reps = (F + uniq - 1) // uniq
-    frames = base.repeat((reps,) + (1,) * (base.dim() - 1))[:F].contiguous()
-    del base
+    frames, uniq = make_workload(first_frame, F, W, H, args.format, args.unique, args.noise, dev)
     px_per_step_rank = F * W * H
 
     # `--pipeline` detectors (own workspace + HIP stream each) take the steps in turn: K1 of step

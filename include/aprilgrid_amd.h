@@ -108,8 +108,13 @@ int agx_detector_set_limits(agx_detector *det, uint32_t max_candidates, uint32_t
  *   "force_generic"        1 = cluster every frame with the generic union-find kernels instead
  *                          of the windowed flood fill (results are identical; test hook)
  *   "k1_rows_per_segment"  rows one wave of the blur kernel walks (0 = automatic)
+ *   "store_response"       1 = the blur kernel also stores the Hessian response it evaluates in
+ *                          registers (parity tests: agx_debug_fetch AGX_DBG_RESP); slower
  *   "debug_ablation"       timing experiments only -- results are INVALID when non-zero */
 int agx_detector_set_option(agx_detector *det, const char *name, int value);
+/* Read an option back; additionally the tiling the blur kernel used for the last enqueued batch:
+ * "k1_rows_per_segment" (effective value), "k1_segments", "k1_strips", "k1_strip_columns". */
+int agx_detector_get_option(const agx_detector *det, const char *name, int *value);
 
 /* Stream selection.  external != 0: launch on the caller's stream `hip_stream` (hipStream_t as
  * void*; NULL is HIP's legacy default stream) so that the chain is stream-ordered behind the
@@ -209,14 +214,18 @@ int agx_profile_reset(agx_detector *det);
 int agx_profile_read(agx_detector *det, const char **names, double *ms_total, uint64_t *launches);
 
 /* Copy an intermediate product of frame `frame` of the last batch to host memory.
- * what: AGX_DBG_BLUR / AGX_DBG_RESP (width*height floats), AGX_DBG_MIN (1 float),
+ * what: AGX_DBG_BLUR / AGX_DBG_RESP (width*height floats; AGX_DBG_RESP is the Hessian response
+ * the blur kernel evaluated in its registers and needs option "store_response" = 1 set before
+ * the batch was enqueued -- the chain itself never stores it), AGX_DBG_MIN (1 float),
  * AGX_DBG_CENTERS (n clusters * {u32 first_index, u32 size, f32 cx, f32 cy} sorted by
  * first_index), AGX_DBG_REFINED (unfiltered rochade_refine output, agx_saddle each, in
  * cluster order).  *n_items receives the element count; returns AGX_ERR_CAPACITY if
  * cap_bytes is too small. */
 enum { AGX_DBG_BLUR = 0, AGX_DBG_RESP = 1, AGX_DBG_MIN = 2, AGX_DBG_CENTERS = 3, AGX_DBG_REFINED = 4,
-       AGX_DBG_COUNTERS = 5 /* 8 x uint32: status flags (AGX_FRAME_*), flood seeds, second-tier seeds,
-                               clusters, generic-path candidates, generic-path roots, refined, saddles */ };
+       AGX_DBG_COUNTERS = 5, /* 8 x uint32: status flags (AGX_FRAME_*), flood seeds, second-tier seeds,
+                                clusters, generic-path candidates, generic-path roots, refined, saddles */
+       AGX_DBG_RESP_RECOMPUTED = 6 /* width*height floats: the response recomputed from the stored blur
+                                      plane by a separate kernel (cross-check of AGX_DBG_RESP) */ };
 typedef struct agx_cluster_info {
     uint32_t first_index, size;
     float cx, cy;

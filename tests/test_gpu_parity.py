@@ -9,11 +9,11 @@ bit-identical (they are saddle coordinates).
 import numpy as np
 import pytest
 
-from tests.util import ALL_IMAGES, REFERENCE_TAG_COUNTS, bits_equal, load_image, synth_module
+from tests.util import (ALL_IMAGES, ANGLE_TOL_DEG, REFERENCE_TAG_COUNTS, bits_equal, check_frame, check_saddles, load_image,
+                        synth_module)
 
 pytestmark = pytest.mark.gpu
 
-ANGLE_TOL_DEG = 1e-3  # |theta|, |phi| difference allowed, degrees (observed ~1e-5)
 
 
 @pytest.fixture(scope="module")
@@ -31,29 +31,30 @@ def oracle():
     return O
 
 
-def check_saddles(gpu, ref, what=""):
-    assert len(gpu) == len(ref), "%s: %d saddles vs oracle %d" % (what, len(gpu), len(ref))
-    for f in ("x", "y", "k"):
-        assert bits_equal(gpu[f], ref[f]), "%s: field %s differs" % (what, f)
-    for f in ("theta", "phi"):
-        if len(ref):
-            assert np.max(np.abs(gpu[f] - ref[f])) <= ANGLE_TOL_DEG, (what, f)
+@pytest.fixture(scope="module")
+def det_resp():
+    """Detector whose blur kernel also stores the response it evaluates in registers."""
+    import aprilgrid_rs_amd as A
+    d = A.TagDetector(A.TagFamily.T36H11, None, device=0)
+    d.set_option("store_response", 1)
+    yield d
+    d.close()
 
 
-def check_frame(det, O, img, frame=0, what="", params=None):
-    """Compare every intermediate product of `frame` of the detector's last batch."""
-    h, w = img.shape[:2]
-    ref, d = O.refined_saddle_points(img, params=params, debug=True)
-    assert bits_equal(det.debug_fetch(frame, "blur", (h, w)), d["blur"]), what + ": blur plane"
-    assert bits_equal(det.debug_fetch(frame, "resp", (h, w)), d["resp"]), what + ": response plane"
-    assert bits_equal(np.float32(det.debug_fetch(frame, "min")), np.float32(d["min_resp"])), what + ": min"
-    c = det.debug_fetch(frame, "centers")
-    assert len(c) == len(d["centers"]), what + ": cluster count %d vs %d" % (len(c), len(d["centers"]))
-    assert np.array_equal(c["first_index"], d["first_index"]), what + ": cluster first pixels"
-    assert np.array_equal(c["size"], d["sizes"]), what + ": cluster sizes"
-    assert bits_equal(c["cx"], d["centers"][:, 0]) and bits_equal(c["cy"], d["centers"][:, 1]), what + ": centroids"
-    check_saddles(det.debug_fetch(frame, "refined"), d["refined"], what + " (unfiltered)")
-    return ref
+@pytest.mark.parametrize("name", ALL_IMAGES)
+def test_fixture_images_in_register_response(det_resp, oracle, name):
+    """The Hessian response as the blur kernel itself evaluates it (image_util.rs:88-106), bit for bit."""
+    img = load_image(name)
+    got = det_resp.refined_saddle_points(img, as_array=True)
+    check_saddles(got, check_frame(det_resp, oracle, img, 0, name), name)
+
+
+@pytest.mark.parametrize("shape", [(2, 2), (3, 5), (10, 11), (37, 53), (33, 260), (100, 1023), (24, 2100)])
+def test_ragged_sizes_in_register_response(det_resp, oracle, shape):
+    rng = np.random.default_rng(shape[0] * 977 + shape[1])
+    img = rng.integers(0, 256, shape, dtype=np.uint8)
+    got = det_resp.refined_saddle_points(img, as_array=True)
+    check_saddles(got, check_frame(det_resp, oracle, img, 0, "random %dx%d" % shape), str(shape))
 
 
 @pytest.mark.parametrize("name", ALL_IMAGES)

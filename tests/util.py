@@ -36,3 +36,44 @@ def synth_module():
     import aprilgrid_rs_amd  # noqa: F401  (registers the package)
     from aprilgrid_rs_amd import synth
     return synth
+
+
+ANGLE_TOL_DEG = 1e-3  # |theta|, |phi| difference allowed, degrees (observed ~1e-5)
+
+
+def check_saddles(gpu, ref, what=""):
+    assert len(gpu) == len(ref), "%s: %d saddles vs oracle %d" % (what, len(gpu), len(ref))
+    for f in ("x", "y", "k"):
+        assert bits_equal(gpu[f], ref[f]), "%s: field %s differs" % (what, f)
+    for f in ("theta", "phi"):
+        if len(ref):
+            assert np.max(np.abs(gpu[f] - ref[f])) <= ANGLE_TOL_DEG, (what, f)
+
+
+def check_frame(det, O, img, frame=0, what="", params=None):
+    """Compare every intermediate product of `frame` of the detector's last batch with the oracle:
+    blur plane, the response recomputed from it (separate kernel), per-frame min, cluster table,
+    unfiltered refine output -- and, when the detector runs with store_response, the response
+    the blur kernel itself evaluated in registers."""
+    h, w = img.shape[:2]
+    ref, d = O.refined_saddle_points(img, params=params, debug=True)
+    assert bits_equal(det.debug_fetch(frame, "blur", (h, w)), d["blur"]), what + ": blur plane"
+    assert bits_equal(det.debug_fetch(frame, "resp_recomputed", (h, w)), d["resp"]), what + ": response plane (recomputed)"
+    if det.get_option("store_response"):
+        assert bits_equal(det.debug_fetch(frame, "resp", (h, w)), d["resp"]), what + ": response plane (K1 registers)"
+    assert bits_equal(np.float32(det.debug_fetch(frame, "min")), np.float32(d["min_resp"])), what + ": min"
+    c = det.debug_fetch(frame, "centers")
+    assert len(c) == len(d["centers"]), what + ": cluster count %d vs %d" % (len(c), len(d["centers"]))
+    assert np.array_equal(c["first_index"], d["first_index"]), what + ": cluster first pixels"
+    assert np.array_equal(c["size"], d["sizes"]), what + ": cluster sizes"
+    assert bits_equal(c["cx"], d["centers"][:, 0]) and bits_equal(c["cy"], d["centers"][:, 1]), what + ": centroids"
+    check_saddles(det.debug_fetch(frame, "refined"), d["refined"], what + " (unfiltered)")
+    return ref
+
+
+def oracle_saddles_parallel(O, frames_host, threads=8, params=None):
+    """Oracle saddle lists of many frames (ctypes releases the GIL: frame-parallel)."""
+    from concurrent.futures import ThreadPoolExecutor
+    O.lib()
+    with ThreadPoolExecutor(threads) as ex:
+        return list(ex.map(lambda f: O.refined_saddle_points(f, params=params), frames_host))
