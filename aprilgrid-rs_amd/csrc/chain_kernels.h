@@ -60,7 +60,8 @@ struct ChainArgs {
     // input
     const uint8_t *frames;
     long long frame_stride;  // bytes
-    int row_stride;          // bytes, multiple of 4
+    int row_stride;          // bytes
+    int byte_rows;           // rows / frames are not 4-byte aligned: the blur kernel gathers bytes
     int fmt;                 // agx_format
     int W, H, n_frames;
     long long plane;  // W*H
@@ -103,7 +104,8 @@ struct ChainArgs {
     // generic path: candidate arrays [n_frames][cap_cand]
     uint32_t *cand;    // pixel index | left<<30 | up<<31
     uint32_t *parent;
-    uint32_t *sumx, *sumy, *cnt, *minidx;
+    unsigned long long *sumx, *sumy;
+    uint32_t *cnt, *minidx;
     uint32_t *roots;      // [n_frames][cap_roots]
     RefinedRec *refined;  // [n_frames][cap_roots]
     // output
@@ -124,6 +126,9 @@ size_t k5_lds_bytes(const ChainArgs &a);
 constexpr int MASK_PAD_X = 64;  // zero columns on each side of the transposed mask (flood windows)  // flood window rows below the last image row
 
 // Debug: recompute the Hessian response plane of `frame` from its blur plane into dst.
+// Per-device kernel attributes (current device); hipError_t.
+int init_device_kernels();
+
 int launch_debug_resp(const ChainArgs &a, int frame, float *dst, void *stream);
 
 }  // namespace agx

@@ -110,7 +110,7 @@ struct RawPx {
 };
 
 template <int FMT, bool A4>
-__device__ __forceinline__ RawPx<FMT> load_raw(const uint8_t *__restrict__ rowp, int c0, int W)
+__device__ __forceinline__ RawPx<FMT> load_raw(const uint8_t *__restrict__ rowp, int c0, int W, bool byte_rows)
 {
     constexpr int BPP = RawPx<FMT>::BPP;
     RawPx<FMT> r;
@@ -123,7 +123,7 @@ __device__ __forceinline__ RawPx<FMT> load_raw(const uint8_t *__restrict__ rowp,
         r.d[0] = c0 < 0 ? first : (c0 >= W ? last : d);
         return r;
     }
-    if (c0 >= 0 && c0 + 3 < W) {
+    if (c0 >= 0 && c0 + 3 < W && !byte_rows) {
         const uint32_t *p = reinterpret_cast<const uint32_t *>(rowp + (size_t)c0 * BPP);
 #pragma unroll
         for (int i = 0; i < BPP; ++i) r.d[i] = p[i];
@@ -370,10 +370,10 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
 #pragma unroll
         for (int k = 0; k < 7; ++k) issue_load(r0 + k, ring[k]);
     } else {
-        raw_a = load_raw<FMT, A4>(rowptr(r0), c0, W);
-        raw_b = load_raw<FMT, A4>(rowptr(r0 + 1), c0, W);
-        raw_c = load_raw<FMT, A4>(rowptr(r0 + 2), c0, W);
-        raw_d = load_raw<FMT, A4>(rowptr(r0 + 3), c0, W);
+        raw_a = load_raw<FMT, A4>(rowptr(r0), c0, W, a.byte_rows);
+        raw_b = load_raw<FMT, A4>(rowptr(r0 + 1), c0, W, a.byte_rows);
+        raw_c = load_raw<FMT, A4>(rowptr(r0 + 2), c0, W, a.byte_rows);
+        raw_d = load_raw<FMT, A4>(rowptr(r0 + 3), c0, W, a.byte_rows);
     }
 
 #pragma unroll 1
@@ -423,7 +423,7 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
                 raw_a = raw_b;
                 raw_b = raw_c;
                 raw_c = raw_d;
-                raw_d = load_raw<FMT, A4>(rowptr(r + 4), c0, W);
+                raw_d = load_raw<FMT, A4>(rowptr(r + 4), c0, W, a.byte_rows);
             }
 
             // horizontal pass, image_util.rs:137-185: taps in index order, mul then add
@@ -1020,8 +1020,8 @@ __device__ __forceinline__ void generic_frame(const ChainArgs &a, int frame)
                 const size_t o = base + slot;
                 a.cand[o] = p | (((lm >> b) & 1u) << 30) | (((um >> b) & 1u) << 31);
                 a.parent[o] = slot;
-                a.sumx[o] = 0u;
-                a.sumy[o] = 0u;
+                a.sumx[o] = 0ull;
+                a.sumy[o] = 0ull;
                 a.cnt[o] = 0u;
                 a.minidx[o] = 0xffffffffu;
                 slot_plane[p] = slot;
@@ -1048,8 +1048,8 @@ __device__ __forceinline__ void generic_frame(const ChainArgs &a, int frame)
     for (uint32_t s = t; s < n; s += T) {
         const uint32_t p = a.cand[base + s] & 0x3fffffffu;
         const uint32_t r = uf_find_atomic(parent, s);
-        atomicAdd(&a.sumx[base + r], p % (uint32_t)a.W);
-        atomicAdd(&a.sumy[base + r], p / (uint32_t)a.W);
+        atomicAdd(&a.sumx[base + r], (unsigned long long)(p % (uint32_t)a.W));  // 64 bit: a component of millions of
+        atomicAdd(&a.sumy[base + r], (unsigned long long)(p / (uint32_t)a.W));  // pixels exceeds 2^32
         atomicAdd(&a.cnt[base + r], 1u);
         atomicMin(&a.minidx[base + r], p);
         if (r == s) {
@@ -1066,8 +1066,11 @@ __device__ __forceinline__ void generic_frame(const ChainArgs &a, int frame)
         const size_t q = (size_t)frame * a.cap_roots + i;
         a.clu_key[q] = __hip_atomic_load(&a.minidx[base + s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         a.clu_cnt[q] = __hip_atomic_load(&a.cnt[base + s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        a.clu_sx[q] = __hip_atomic_load(&a.sumx[base + s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        a.clu_sy[q] = __hip_atomic_load(&a.sumy[base + s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the cluster record keeps 32 bits; a sum beyond that saturates (>= 2^24: K4 raises FLAG_CENTROID_INEXACT)
+        const unsigned long long sx64 = __hip_atomic_load(&a.sumx[base + s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long sy64 = __hip_atomic_load(&a.sumy[base + s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a.clu_sx[q] = sx64 > 0xffffffffull ? 0xffffffffu : (uint32_t)sx64;
+        a.clu_sy[q] = sy64 > 0xffffffffull ? 0xffffffffu : (uint32_t)sy64;
     }
     if (t == 0) ctr.n_clusters = nr;
 }
@@ -1381,7 +1384,7 @@ static hipError_t launch_k1(const ChainArgs &a, hipStream_t st)
     dim3 grid((unsigned)((units + 3) / 4)), block(256);
     // the aligned form addresses a frame and its blur plane with 32-bit buffer offsets
     const bool small = a.plane * 4 < (1ll << 31) && (long long)a.H * a.row_stride < (1ll << 31);
-    const bool a4 = (a.W & 3) == 0 && small;
+    const bool a4 = (a.W & 3) == 0 && small && !a.byte_rows;
     if (a.resp_dbg) {  // parity-test instantiation: also stores the response it evaluates
         if (a4) hipLaunchKernelGGL((k_blur_hessian<FMT, true, true>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((k_blur_hessian<FMT, false, true>), grid, block, 0, st, a);
@@ -1434,14 +1437,7 @@ int launch_kernel(int which, const ChainArgs &a, const RefineConsts &rc, void *s
         return hipGetLastError();
     }
     case K_FILTER_SORT: {
-        size_t lds = k5_lds_bytes(a);
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute((const void *)k_filter_sort,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-            if (e != hipSuccess) return e;
-            attr_set = true;
-        }
+        size_t lds = k5_lds_bytes(a);  // (the large-LDS attribute is set per device in init_device_kernels)
         dim3 grid(a.n_frames), block(512);  // measured: 128 -> 34, 256 -> 23, 512 / 1024 -> 18 us
         hipLaunchKernelGGL(k_filter_sort, grid, block, lds, st, a, (uint32_t)(lds / 8));
         return hipGetLastError();
@@ -1449,6 +1445,13 @@ int launch_kernel(int which, const ChainArgs &a, const RefineConsts &rc, void *s
     default:
         return hipErrorInvalidValue;
     }
+}
+
+// Function attributes belong to the function object of the CURRENT device: called by
+// agx_detector_create after hipSetDevice, once per handle (any number of devices per process).
+int init_device_kernels()
+{
+    return hipFuncSetAttribute((const void *)k_filter_sort, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
 }
 
 int launch_debug_resp(const ChainArgs &a, int frame, float *dst, void *stream)

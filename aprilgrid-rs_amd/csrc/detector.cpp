@@ -454,6 +454,12 @@ int agx_detector_create(int family, const agx_params *params, int device, agx_de
         return AGX_ERR_HIP;
     }
     d->stream = d->own_stream;
+    e = (hipError_t)init_device_kernels();  // function attributes are per device
+    if (e != hipSuccess) {
+        g_create_error = std::string("hipFuncSetAttribute: ") + hipGetErrorString(e);
+        (void)hipStreamDestroy(d->own_stream);
+        return AGX_ERR_HIP;
+    }
     make_blur_weights(1.5f, d->blur_w);
     make_refine_consts(d->rc);
     *out = d.release();
@@ -550,10 +556,15 @@ static int batch_enqueue_impl(agx_detector *det, const void *d_frames, int n_fra
     if (!valid_format(format)) return fail(det, AGX_ERR_FORMAT, "format must be AGX_L8, AGX_L16 or AGX_RGB8");
     if (width < 2 || height < 2) return fail(det, AGX_ERR_ARG, "width and height must be >= 2");
     if ((long long)width * height >= (1ll << 30) || width > 65000) return fail(det, AGX_ERR_ARG, "frame too large (>= 2^30 px or wider than 65000)");
-    if (row_stride_bytes < (size_t)width * bytes_per_px(format) || (row_stride_bytes & 3) ||
-        ((uintptr_t)d_frames & 3) || (frame_stride_bytes & 3) ||
+    const size_t px_bytes = (size_t)bytes_per_px(format);
+    if (row_stride_bytes < (size_t)width * px_bytes || row_stride_bytes > 0x7fffffffu ||
         (n_frames > 1 && frame_stride_bytes < row_stride_bytes * (size_t)height))
-        return fail(det, AGX_ERR_ARG, "strides must be multiples of 4 bytes and cover the frame");
+        return fail(det, AGX_ERR_ARG, "strides must cover a row / a frame");
+    if (format == AGX_L16 && ((row_stride_bytes | frame_stride_bytes | (uintptr_t)d_frames) & 1))
+        return fail(det, AGX_ERR_ARG, "16-bit pixels must be 2-byte aligned");
+    // rows that are not 4-byte aligned (tightly packed L8 / RGB8 of a width that is not a multiple
+    // of 4, odd-width L16): the blur kernel gathers bytes instead of loading dwords
+    const bool byte_rows = ((row_stride_bytes | (uintptr_t)d_frames | (n_frames > 1 ? frame_stride_bytes : 0)) & 3) != 0;
     if (n_frames > 65535) return fail(det, AGX_ERR_ARG, "at most 65535 frames per batch");
     HIP_TRY(det, hipSetDevice(det->device));
     int rc = ensure_workspace(det, n_frames, width, height);
@@ -562,6 +573,7 @@ static int batch_enqueue_impl(agx_detector *det, const void *d_frames, int n_fra
     a.frames = (const uint8_t *)d_frames;
     a.frame_stride = (long long)frame_stride_bytes;
     a.row_stride = (int)row_stride_bytes;
+    a.byte_rows = byte_rows ? 1 : 0;
     a.fmt = format;
     a.W = width;
     a.H = height;

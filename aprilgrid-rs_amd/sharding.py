@@ -19,10 +19,10 @@ def shard_range(rank, world, frames_per_rank):
     return lo, lo + frames_per_rank
 
 
-def alloc_result_buffers(n_frames, device):
-    """(saddles [n_frames*SLAB_RECORDS, 5] f32, table [n_frames, 4] i32: count, offset, status,
+def alloc_result_buffers(n_frames, device, slab_records=SLAB_RECORDS):
+    """(saddles [n_frames*slab_records, 5] f32, table [n_frames, 4] i32: count, offset, status,
     clusters) -- the caller-owned device buffers of agx_saddles_batch_enqueue_to."""
-    return (torch.zeros((n_frames * SLAB_RECORDS, 5), dtype=torch.float32, device=device),
+    return (torch.zeros((n_frames * slab_records, 5), dtype=torch.float32, device=device),
             torch.zeros((n_frames, 4), dtype=torch.int32, device=device))
 
 
@@ -56,13 +56,14 @@ class GatherPipeline:
         gathered = pipe.finish()             # on dst: (list_of_saddles, list_of_tables) of the LAST step
     """
 
-    def __init__(self, n_frames, device, dst=0, group=None, depth=2, always_depth=False):
+    def __init__(self, n_frames, device, dst=0, group=None, depth=2, always_depth=False, slab_records=SLAB_RECORDS):
         self.dst, self.group = dst, group
         self.multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
         self.world = dist.get_world_size(group) if self.multi else 1
         self.rank = dist.get_rank(group) if self.multi else 0
         # one rank alone needs a single buffer pair unless several batches are in flight (ChainPipeline)
-        self.bufs = [alloc_result_buffers(n_frames, device) for _ in range(depth if (self.multi or always_depth) else 1)]
+        self.bufs = [alloc_result_buffers(n_frames, device, slab_records)
+                     for _ in range(depth if (self.multi or always_depth) else 1)]
         self.recv = None
         if self.multi and self.rank == dst:
             self.recv = [([torch.empty_like(s) for _ in range(self.world)], [torch.empty_like(t) for _ in range(self.world)])
@@ -115,7 +116,7 @@ class ChainPipeline:
         saddles, tables = pipe.finish()   # results of the LAST batch (lists over ranks on dst)
     """
 
-    def __init__(self, tag_family, n_frames, device, depth=2, params=None, dst=0, group=None):
+    def __init__(self, tag_family, n_frames, device, depth=2, params=None, dst=0, group=None, slab_records=SLAB_RECORDS):
         from .detector import TagDetector
         dev = torch.device(device)
         index = dev.index if dev.index is not None else torch.cuda.current_device()
@@ -126,7 +127,7 @@ class ChainPipeline:
         # depth 1 stays on the caller's stream (no cross-stream events at all)
         self.streams = [torch.cuda.Stream(dev) for _ in range(self.depth)] if self.depth > 1 else [None]
         self.gather = GatherPipeline(n_frames, dev, dst=dst, group=group, depth=max(2, self.depth),
-                                     always_depth=self.depth > 1)
+                                     always_depth=self.depth > 1, slab_records=slab_records)
         self.i = -1
         self.last_table = None
 

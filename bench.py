@@ -13,16 +13,26 @@ slabs to rank 0.
         --master-port P bench.py --gpus N --steps K --warmup W
 
 Rank 0 prints ONE JSON line.  value = pixels of all ranks through the chain per second
-(Mpix/s), inputs resident in HBM.  roofline = K1 (the dominant kernel): algorithmic bytes per
-launch / average launch duration from hipEvents recorded on the launch stream inside the
-timed region.  cpu_baseline = the C oracle (port of the reference CPU path, 1 thread; all_cores =
-the same frame-parallel on the host cores) on a bounded sample of the same frames, rank 0, N = 1
-only.  The timed region is strictly serial (one batch at a time); at N = 1 a second pass with
---extra-pipeline batches in flight (sharding.ChainPipeline) is reported as "pipelined".
+(Mpix/s), inputs resident in HBM, over the K timed steps (wall clock between two fences);
+ms_per_step_median = median of the K per-step device times (events between the steps).
+roofline = K1 (the dominant kernel): algorithmic bytes per launch / average launch duration from
+hipEvents recorded on the launch stream inside the timed region.  The timed region is strictly
+serial (one batch at a time); at N = 1 a second pass with --extra-pipeline batches in flight
+(sharding.ChainPipeline) is reported as "pipelined".
+
+N = 1 additionally reports, in the same line:
+  cpu_baseline   the C oracle (port of the reference CPU path, 1 thread; all_cores = the same
+                 frame-parallel on the host cores) on a bounded sample of the same frames;
+  verified_frames  the bench's own frames whose GPU saddle lists were compared with the oracle
+                 (outside the timed region; the run aborts on a mismatch);
+  extra_configs  BASELINE.json configs[3] (3840x2160 x32), configs[4] (RGB8 x256, the kornia
+                 front-end layout), L16 x256 and the pure-noise sensitivity row, each with its own
+                 K1 roofline and oracle check.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -33,12 +43,13 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec)
 HBM_MEASURED_GBPS = 6290.0    # float4-copy ceiling measured on MI355X (same guide)
 IN_BYTES = {"L8": 1, "L16": 2, "RGB8": 3}
+ANGLE_TOL_DEG = 1e-3          # theta / phi: device acosf / atan2f vs glibc (tests/util.py)
 
 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=256, help="frames per GPU per step")
     ap.add_argument("--width", type=int, default=1280)
@@ -49,14 +60,16 @@ def parse_args():
                          "indices rank*F .. rank*F+F-1 of the seeded generator; rendering is not timed)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--noise", action="store_true", help="pure-noise frames (sensitivity row)")
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the bench's own frames")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra configurations (4K, RGB8, L16, noise)")
+    ap.add_argument("--noise", action="store_true", help="pure-noise frames (sensitivity row) as the main workload")
     ap.add_argument("--pipeline", type=int, default=1,
                     help="batches in flight per GPU in the timed region (detectors on separate HIP streams; "
                          "1 = strictly serial: value, ms_per_step and roofline then describe the same launches)")
     ap.add_argument("--extra-pipeline", type=int, default=3,
                     help="N = 1 only: a second, separately reported timed pass with this many batches in flight (0 = skip)")
     ap.add_argument("--settle-ms", type=float, default=300.0,
-                    help="untimed: keep the chain running this long before the W warm-up steps so that workspace "
+                    help="untimed: keep the chain running about this long before the W warm-up steps so that workspace "
                          "allocation is done and the GPU clocks have ramped (0 = off)")
     ap.add_argument("--pmc-traffic", type=float, default=None,
                     help="HBM bytes per K1 launch from a separate rocprofv3 --pmc run (profiles/)")
@@ -73,6 +86,35 @@ def make_workload(first_frame, n_frames, width, height, fmt, unique, noise, devi
     reps = (n_frames + uniq - 1) // uniq
     frames = base.repeat((reps,) + (1,) * (base.dim() - 1))[:n_frames].contiguous()
     return frames, uniq
+
+
+def host_view(frames, fmt):
+    import numpy as np
+    h = frames.cpu().numpy()
+    return h.view(np.uint16) if fmt == "L16" else h
+
+
+def verify_against_oracle(results, frames_host, what, threads=8):
+    """GPU saddle lists (arrays [n, 5]: x, y, k, theta, phi) against the oracle on the same frames:
+    count and order identical, x / y / k bit-exact, theta / phi within ANGLE_TOL_DEG.  Outside the
+    timed region.  Returns the number of frames compared; raises on the first mismatch."""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as O
+    O.lib()
+    with ThreadPoolExecutor(max(1, threads)) as ex:
+        refs = list(ex.map(O.refined_saddle_points, frames_host))
+    for i, (got, ref) in enumerate(zip(results, refs)):
+        if got is None or len(got) != len(ref):
+            raise SystemExit("VERIFY FAILED (%s frame %d): %s saddles vs oracle %d"
+                             % (what, i, "no" if got is None else len(got), len(ref)))
+        for j, f in enumerate(("x", "y", "k")):
+            if not np.array_equal(np.ascontiguousarray(got[:, j]).view(np.uint32), ref[f].view(np.uint32)):
+                raise SystemExit("VERIFY FAILED (%s frame %d): field %s is not bit-exact" % (what, i, f))
+        for j, f in ((3, "theta"), (4, "phi")):
+            if len(ref) and float(np.max(np.abs(got[:, j] - ref[f]))) > ANGLE_TOL_DEG:
+                raise SystemExit("VERIFY FAILED (%s frame %d): field %s beyond %g deg" % (what, i, f, ANGLE_TOL_DEG))
+    return len(refs)
 
 
 def cpu_baseline(frames_host, fmt, budget_s):
@@ -135,13 +177,87 @@ def cpu_baseline(frames_host, fmt, budget_s):
             "ms_per_frame": round(1e3 * t_used / n_done, 3)}
 
 
+def k1_roofline(px, in_b, k1_ms, k1_n, traffic=None, traffic_src=None):
+    """K1 reads the input once, writes the blur plane (f32) and 1 bit / px of candidate mask."""
+    avg = k1_ms / max(k1_n, 1)
+    nbytes = px * (in_b + 4 + 0.125)
+    gbps = nbytes / (avg * 1e-3) / 1e9 if avg > 0 else 0.0
+    return {"kernel": "k_blur_hessian (K1)", "bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4),
+            "frac_of_measured_copy_ceiling": round(gbps / HBM_MEASURED_GBPS, 4),
+            "traffic": traffic, "traffic_source": traffic_src,
+            "algorithmic_bytes_per_px": in_b + 4.125, "bytes_per_launch": nbytes,
+            "avg_launch_ms": round(avg, 5), "launches_timed": k1_n}
+
+
+def recorded_traffic(key):
+    """HBM bytes per K1 launch from rocprofv3 PMC passes (FETCH_SIZE x2 per the calibration +
+    WRITE_SIZE), collected separately (tools/final_profile.sh) and kept under profiles/."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "k1_traffic.json")))
+        if key in rec:
+            return rec[key]["bytes_per_launch"], rec[key]["source"]
+    except Exception:
+        pass
+    return None, None
+
+
+def extra_leg(torch, A, dev, name, workload, n_frames, width, height, fmt, unique, noise, steps, warmup, verify_n):
+    """One extra configuration on its own detector, strictly serial: wall-clock value, per-step
+    median, K1 roofline from hipEvents in the timed region, oracle check of the first frames."""
+    frames, uniq = make_workload(0, n_frames, width, height, fmt, unique, noise, dev)
+    det = A.TagDetector(A.TagFamily.T36H11, None, device=dev.index)
+    px = n_frames * width * height
+    try:
+        for _ in range(max(warmup, 1) + 2):
+            det.saddles_batch_enqueue(frames)
+        torch.cuda.synchronize(dev)
+        det.profile_enable(1)
+        det.profile_reset()
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            evs[i].record()
+            det.saddles_batch_enqueue(frames)
+        evs[steps].record()
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        k1_ms, k1_n = det.profile_read()["k_blur_hessian"]
+        det.profile_enable(0)
+        per_step = [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]
+        res, status = det.saddles_batch_fetch(raise_on_overflow=False)
+        import numpy as np
+        bad = int((status != 0).sum())
+        verified = 0
+        if verify_n and not bad:
+            host = host_view(frames[:min(verify_n, uniq)], fmt)
+            got = [np.stack([r["x"], r["y"], r["k"], r["theta"], r["phi"]], axis=1) if len(r) else np.zeros((0, 5), np.float32)
+                   for r in res[:len(host)]]
+            verified = verify_against_oracle(got, host, name)
+        key = "%dx%dx%d_%s%s" % (n_frames, width, height, fmt, "_noise" if noise else "")
+        traffic, src = recorded_traffic(key)
+        return {"workload": workload, "frames": n_frames, "distinct_frames": uniq, "width": width, "height": height,
+                "format": fmt, "steps": steps, "value": round(px * steps / dt / 1e6, 1), "unit": "Mpix/s",
+                "ms_per_step": round(1e3 * dt / steps, 4), "ms_per_step_median": round(statistics.median(per_step), 4),
+                "frames_per_s": round(n_frames * steps / dt, 1),
+                "saddles_per_frame": round(float(sum(len(r) for r in res)) / max(len(res), 1), 1),
+                "frames_over_capacity": bad, "verified_frames": verified,
+                "k1_rows_per_segment": det.get_option("k1_rows_per_segment"),
+                "roofline": k1_roofline(px, IN_BYTES[fmt], k1_ms, k1_n, traffic, src)}
+    finally:
+        det.close()
+        del frames
+        torch.cuda.empty_cache()
+
+
 def main():
     args = parse_args()
     import numpy as np
     import torch
     import torch.distributed as dist
     import aprilgrid_rs_amd as A
-    from aprilgrid_rs_amd import synth, sharding
+    from aprilgrid_rs_amd import sharding
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -159,7 +275,7 @@ def main():
 
     W, H, F = args.width, args.height, args.frames
     # ---- synthetic workload: frames [rank*F, rank*F + F) of the seeded generator, rendered
-    # straight into HBM; `unique` distinct frames tiled (rendering is outside the timed region)
+    # straight into HBM (rendering is outside the timed region)
     first_frame, _ = sharding.shard_range(rank, world, F)
     frames, uniq = make_workload(first_frame, F, W, H, args.format, args.unique, args.noise, dev)
     px_per_step_rank = F * W * H
@@ -168,23 +284,36 @@ def main():
     # i+1 overlaps the short, latency-bound sparse kernels of step i.  Result buffers stay in
     # HBM; for N > 1 they are gathered to rank 0 asynchronously (RCCL over xGMI) -- the one
     # collective of the path -- so the gather of a step overlaps the chain of the next.
-    pipe = sharding.ChainPipeline(A.TagFamily.T36H11, F, dev, depth=args.pipeline, dst=0)
+    slab = 8192 if args.noise else sharding.SLAB_RECORDS  # pure noise: ~7100 saddles per 1280x800 frame
+    pipe = sharding.ChainPipeline(A.TagFamily.T36H11, F, dev, depth=args.pipeline, dst=0, slab_records=slab)
 
     def step():
         pipe.submit(frames)
 
     def fence():
-        pipe.finish()
+        res = pipe.finish()
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize(dev)
+        return res
 
-    # setup, untimed: first call allocates the workspace; then run until the clocks have settled
+    # setup, untimed: first call allocates the workspace; then run until the clocks have settled.
+    # Every rank issues the SAME sequence of collectives: the number of settle rounds is fixed from the
+    # first round's duration as rank 0 measured it (broadcast), never from a rank's own clock.
+    t_round = time.perf_counter()
     step()
     fence()
-    t_settle = time.perf_counter()
-    while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
+    for _ in range(8):
+        step()
+    fence()
+    t_round = time.perf_counter() - t_round
+    rounds = int(min(64, max(0, args.settle_ms * 1e-3 / max(t_round, 1e-4))))
+    if world > 1:
+        rt = torch.tensor([rounds], dtype=torch.int64, device=dev)
+        dist.broadcast(rt, src=0)
+        rounds = int(rt.item())
+    for _ in range(rounds):
         for _ in range(8):
             step()
         fence()
@@ -192,30 +321,65 @@ def main():
         step()
     fence()
     tb = pipe.last_table.cpu().numpy()
-    assert (tb[:, 2] & 7 == 0).all(), "capacity overflow in the bench workload: %s" % tb[tb[:, 2] != 0][:4]
+    over = int(((tb[:, 2] & 7) != 0).sum())
+    assert over == 0, "capacity overflow in the bench workload (%d frames): %s" % (over, tb[(tb[:, 2] & 7) != 0][:4])
     generic_frames = int(((tb[:, 2] & 16) != 0).sum())
     saddles_per_frame = float(tb[:, 0].mean())
     clusters_per_frame = float(tb[:, 3].mean())
 
-    # timed region: hipEvents (on the launch stream) around K1 only -- 2 records per step
+    # timed region: hipEvents (on the launch stream) around K1 only -- 2 records per step -- and one
+    # event between the steps (strictly serial: the chain launches on the current stream)
     for d in pipe.dets:
         d.profile_enable(1)
         d.profile_reset()
+    serial = pipe.depth == 1
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)] if serial else []
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        if serial:
+            evs[i].record()
         step()
-    fence()
+    if serial:
+        evs[args.steps].record()
+    gathered = fence()
     dt = time.perf_counter() - t0
+    per_step = [evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)] if serial else []
     k1_ms, k1_n = 0.0, 0
     for d in pipe.dets:
         ms, n = d.profile_read()["k_blur_hessian"]
         k1_ms, k1_n = k1_ms + ms, k1_n + n
         d.profile_enable(0)
+
+    # results of the last timed step: the gathered tables must be complete on rank 0 (every rank's
+    # frames present, no blocking status) -- the first multi-GPU hardware run checks itself
+    own = sharding.unpack_frames(pipe.gather.bufs[pipe.gather.i][0], pipe.gather.bufs[pipe.gather.i][1])
+    gather_check = None
+    if rank == 0:
+        gs, gt = gathered
+        assert len(gs) == world and len(gt) == world, "gather returned %d ranks" % len(gt)
+        tot = 0
+        for r in range(world):
+            t = gt[r].cpu().numpy()
+            assert t.shape == (F, 4) and (t[:, 2] & 7 == 0).all(), "rank %d: blocking frame status in the gathered table" % r
+            assert (t[:, 0] > 0).all(), "rank %d: frames without saddles in the gathered table" % r
+            tot += int(t[:, 0].sum())
+        mine = sharding.unpack_frames(gs[0], gt[0])
+        assert all(a.tobytes() == b.tobytes() for a, b in zip(mine, own)), "rank 0's gathered slab differs from its own results"
+        gather_check = {"ranks": world, "frames": world * F, "saddles": tot}
+        if world > 1 and not args.no_verify:
+            # first frame of every other rank, re-rendered here from its seed, against the oracle
+            from aprilgrid_rs_amd import synth
+            for r in range(1, world):
+                fr, _ = synth.render_batch(sharding.shard_range(r, world, F)[0], 1, W, H, device=dev, fmt=args.format,
+                                           pure_noise=args.noise)
+                verify_against_oracle(sharding.unpack_frames(gs[r], gt[r])[:1], host_view(fr, args.format), "rank %d" % r)
+            gather_check["oracle_checked_remote_frames"] = world - 1
+
     # separate, untimed pass for the per-kernel breakdown: one detector, strictly serial, events
     # around every launch (each kernel alone on the GPU)
     det = pipe.dets[0]
-    out_s, out_t = sharding.alloc_result_buffers(F, dev)
+    out_s, out_t = sharding.alloc_result_buffers(F, dev, slab)
     det.profile_enable(2)
     det.profile_reset()
     for _ in range(min(args.steps, 10)):
@@ -223,11 +387,12 @@ def main():
     fence()
     prof = det.profile_read()
     det.profile_enable(0)
+    rows_per_seg = det.get_option("k1_rows_per_segment")
 
     # N = 1: the same K steps again with several batches in flight (reported as "pipelined")
     pipelined = None
     if world == 1 and args.extra_pipeline > 1 and args.pipeline == 1:
-        pipe2 = sharding.ChainPipeline(A.TagFamily.T36H11, F, dev, depth=args.extra_pipeline, dst=0)
+        pipe2 = sharding.ChainPipeline(A.TagFamily.T36H11, F, dev, depth=args.extra_pipeline, dst=0, slab_records=slab)
         t_settle = time.perf_counter()  # same untimed settle as the main pass: fresh workspaces, clocks
         while True:
             for _ in range(max(args.warmup, 2 * pipe2.depth)):
@@ -258,26 +423,19 @@ def main():
         ms_per_step = 1e3 * dt / args.steps
         mpix = total_px / dt / 1e6
         in_b = IN_BYTES[args.format]
-        k1_avg_ms = k1_ms / max(k1_n, 1)
         k1_alone_ms = prof["k_blur_hessian"][0] / max(prof["k_blur_hessian"][1], 1)
-        # K1 reads the input once, writes the blur plane (f32) and 1 bit / px of candidate mask
-        k1_bytes = px_per_step_rank * (in_b + 4 + 0.125)
-        k1_gbps = k1_bytes / (k1_avg_ms * 1e-3) / 1e9
         chain_ms = sum(v[0] / max(v[1], 1) for v in prof.values())
-        # HBM bytes per K1 launch from rocprofv3 PMC passes (FETCH_SIZE x2 per the calibration,
-        # + WRITE_SIZE), collected separately (tools/final_profile.sh) and kept under profiles/
         traffic, traffic_src = args.pmc_traffic, "--pmc-traffic" if args.pmc_traffic else None
         if traffic is None and world == 1:
-            try:
-                rec = json.load(open(os.path.join(ROOT, "profiles", "k1_traffic.json")))
-                key = "%dx%dx%d_%s" % (F, W, H, args.format)
-                if key in rec:
-                    traffic, traffic_src = rec[key]["bytes_per_launch"], rec[key]["source"]
-            except Exception:
-                pass
+            traffic, traffic_src = recorded_traffic("%dx%dx%d_%s%s" % (F, W, H, args.format, "_noise" if args.noise else ""))
         a_mat = in_b + 12  # SURVEY.md 8(d) A_mat: input + blur write + response write + response re-read
         a_design = in_b + 4 + 0.125 + 0.125  # this design: input + blur write + mask write (K1) + mask read (K2);
         # the sparse stages (verify / refine gathers at ~2.4 % of the pixels, lists) add < 0.5 B/px
+        roof = k1_roofline(px_per_step_rank, in_b, k1_ms, k1_n, traffic, traffic_src)
+        # the same kernel alone on the GPU (serial pass below the timed region): with
+        # --pipeline > 1 the timed launches share the chip with another step's sparse kernels
+        roof["alone_avg_launch_ms"] = round(k1_alone_ms, 5)
+        roof["alone_frac"] = round(roof["bytes_per_launch"] / (k1_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
         result = {
             "metric": "Mpix/s through the saddle chain (blur->threshold->gradient->saddle), frames resident in HBM",
             "value": round(mpix, 1),
@@ -292,35 +450,19 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "configs[%d]: %d synthetic %dx%d %s AprilGrid frames per GPU (T36H11 6x6 board, "
-                            "seeded renderer, %d distinct frames tiled)%s" % (
-                                1 if world == 1 else 2, F, W, H, args.format, uniq,
-                                ", pure noise" if args.noise else ""),
-                "frames_per_gpu": F, "width": W, "height": H, "format": args.format,
+                "workload": "configs[%d]: %d synthetic %dx%d %s AprilGrid frames per GPU (T36H11 6x6 board, seeded "
+                            "renderer, frame indices %d..%d per rank: %d distinct%s)%s" % (
+                                1 if world == 1 else 2, F, W, H, args.format, 0, uniq - 1, uniq,
+                                "" if uniq == F else " tiled", ", pure noise" if args.noise else ""),
+                "frames_per_gpu": F, "width": W, "height": H, "format": args.format, "distinct_frames_per_gpu": uniq,
                 "frames_per_s": round(F * world * args.steps / dt, 1),
                 "saddles_per_frame": round(saddles_per_frame, 1),
                 "clusters_per_frame": round(clusters_per_frame, 1),
                 "parallelism": "frame-sharded x%d, RCCL gather of result slabs" % world if world > 1 else "1 GPU",
                 "batches_in_flight": pipe.depth,
+                "k1_rows_per_segment": rows_per_seg,
             },
-            "roofline": {
-                "kernel": "k_blur_hessian (K1)",
-                "bound": "hbm",
-                "achieved": round(k1_gbps, 1),
-                "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s",
-                "frac": round(k1_gbps / HBM_PEAK_GBPS, 4),
-                "frac_of_measured_copy_ceiling": round(k1_gbps / HBM_MEASURED_GBPS, 4),
-                "traffic": traffic, "traffic_source": traffic_src,
-                "algorithmic_bytes_per_px": in_b + 4.125,
-                "bytes_per_launch": k1_bytes,
-                "avg_launch_ms": round(k1_avg_ms, 5),
-                "launches_timed": k1_n,
-                # the same kernel alone on the GPU (serial pass below the timed region): with
-                # --pipeline > 1 the timed launches share the chip with another step's sparse kernels
-                "alone_avg_launch_ms": round(k1_alone_ms, 5),
-                "alone_frac": round(k1_bytes / (k1_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-            },
+            "roofline": roof,
             "chain": {
                 "a_mat_bytes_per_px": a_mat,
                 "kernel_ms_per_step": {k: round(v[0] / max(v[1], 1), 5) for k, v in prof.items()},
@@ -329,19 +471,46 @@ def main():
                 "a_mat_frac_of_peak": round(px_per_step_rank * a_mat / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                 "design_bytes_per_px": a_design,
                 "design_GBps": round(px_per_step_rank * a_design / (chain_ms * 1e-3) / 1e9, 1),
+                "design_frac_of_peak": round(px_per_step_rank * a_design / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                 "frames_on_generic_path": generic_frames,
             },
+            "gather_check": gather_check,
         }
+        if per_step:
+            result["ms_per_step_median"] = round(statistics.median(per_step), 4)
+            result["ms_per_step_min"] = round(min(per_step), 4)
         if pipelined:
             result["pipelined"] = pipelined
-        if world == 1 and not args.no_cpu_baseline:
-            sample = frames[:uniq].cpu().numpy()
-            if args.format == "L16":
-                sample = sample.view(np.uint16)
-            result["cpu_baseline"] = cpu_baseline(sample, args.format, args.cpu_seconds)
-            result["cpu_baseline"]["host_cores_available"] = os.cpu_count()
-        print(json.dumps(result), flush=True)
+        if world == 1:
+            host = host_view(frames[:uniq], args.format)
+            if not args.no_verify:
+                result["verified_frames"] = verify_against_oracle(own[:uniq], host, "main workload",
+                                                                  threads=min(16, os.cpu_count() or 1))
+            if not args.no_cpu_baseline:
+                result["cpu_baseline"] = cpu_baseline(host, args.format, args.cpu_seconds)
+                result["cpu_baseline"]["host_cores_available"] = os.cpu_count()
     pipe.close()
+    del pipe
+    if world == 1 and rank == 0 and not args.no_extra:
+        del frames, out_s, out_t
+        torch.cuda.empty_cache()
+        st = max(10, args.steps // 2)
+        vf = 0 if args.no_verify else 1
+        result["extra_configs"] = {
+            "configs[3]_4K": extra_leg(torch, A, dev, "4K", "configs[3]: 32 synthetic 3840x2160 L8 frames (8 distinct, tiled: "
+                                       "rendering a 4K frame costs 8 frames of 1280x800)", 32, 3840, 2160, "L8", 8, False, st,
+                                       args.warmup, 2 * vf),
+            "configs[4]_RGB8": extra_leg(torch, A, dev, "RGB8", "configs[4]: 256 synthetic 1280x800 RGB8 frames, HWC "
+                                         "interleaved as kornia::Image<u8,3> (64 distinct, tiled)", 256, 1280, 800, "RGB8", 64,
+                                         False, st, args.warmup, 64 * vf),
+            "L16": extra_leg(torch, A, dev, "L16", "256 synthetic 1280x800 L16 frames (64 distinct, tiled)", 256, 1280, 800,
+                             "L16", 64, False, st, args.warmup, 64 * vf),
+            "pure_noise": extra_leg(torch, A, dev, "noise", "sensitivity row: 64 pure-noise 1280x800 L8 frames (16 distinct, "
+                                    "tiled; ~7000 saddles per frame: worst case for the sparse stages)", 64, 1280, 800, "L8",
+                                    16, True, st, args.warmup, 4 * vf),
+        }
+    if rank == 0:
+        print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

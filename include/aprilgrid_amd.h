@@ -144,7 +144,8 @@ int agx_detect(agx_detector *det, const void *pixels, int width, int height,
 /* Enqueue the whole saddle chain (luma -> blur -> Hessian response -> min/threshold ->
  * clustering -> rochade_refine -> k/phi filter) for n_frames frames on the detector's
  * stream and return without waiting.  d_frames: DEVICE pointer; frame i starts at
- * d_frames + i*frame_stride_bytes.  row_stride_bytes must be a multiple of 4. */
+ * d_frames + i*frame_stride_bytes.  Any row stride that covers a row is accepted (16-bit pixels
+ * 2-byte aligned); rows and frames aligned to 4 bytes with width % 4 == 0 take the fast path. */
 int agx_saddles_batch_enqueue(agx_detector *det, const void *d_frames, int n_frames, int width,
                               int height, size_t row_stride_bytes, size_t frame_stride_bytes,
                               int format);

@@ -320,6 +320,26 @@ def test_randomised_sizes_formats_batches(det, oracle):
             check_saddles(res[i], oracle.refined_saddle_points(host[i]), "case %d %s %dx%d frame %d" % (case, fmt, w, h, i))
 
 
+@pytest.mark.parametrize("fmt", ["L8", "L16", "RGB8"])
+@pytest.mark.parametrize("width", [33, 250, 701, 1283])
+def test_unaligned_width_device_batches(det, oracle, fmt, width):
+    """Tightly packed device batches whose rows are not 4-byte aligned: the batch API
+    takes them as they are (byte-gathering loads), like the single-frame API and the reference."""
+    import torch
+    synth = synth_module()
+    fr, _ = synth.render_batch(77, 3, (width + 3) // 4 * 4, 96, device="cuda", fmt=fmt)
+    frames = fr[:, :, :width].contiguous()
+    host = frames.cpu().numpy()
+    if fmt == "L16":
+        host = host.view(np.uint16)
+    det.saddles_batch_enqueue(frames)
+    res, status = det.saddles_batch_fetch()
+    assert (status == 0).all()
+    for i in range(3):
+        ref = check_frame(det, oracle, host[i], i, "%s width %d frame %d" % (fmt, width, i))
+        check_saddles(res[i], ref, "%s width %d frame %d" % (fmt, width, i))
+
+
 def test_plain_c_client_of_the_abi(oracle, tmp_path):
     """examples/c_client.c (C99, no Python / torch in the process) on a synthetic board frame:
     the same counts and first saddle as the oracle."""
