@@ -11,7 +11,7 @@ AGX_ERR_ARG, AGX_ERR_FORMAT, AGX_ERR_CAPACITY, AGX_ERR_HIP = -1, -2, -3, -4
 AGX_ERR_NO_DEVICE, AGX_ERR_FAMILY, AGX_ERR_STATE = -5, -6, -7
 AGX_L8, AGX_L16, AGX_RGB8 = 0, 1, 2
 AGX_DBG_BLUR, AGX_DBG_RESP, AGX_DBG_MIN, AGX_DBG_CENTERS, AGX_DBG_REFINED = 0, 1, 2, 3, 4
-AGX_N_KERNELS = 6
+AGX_N_KERNELS = 5
 
 
 class Params(C.Structure):

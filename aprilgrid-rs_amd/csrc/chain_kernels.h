@@ -12,10 +12,11 @@ enum Kernel : int {
                          //     (exact response recomputed from the blur plane at set bits only),
                          //     then mask scan -> flood seeds
     K_FLOOD = 2,         // K3: bit-parallel flood fill per seed (32x32 per lane, 128x64 per wave) -> cluster records
-    K_GENERIC = 3,       // K3g: guarded fallback (4 launches) for frames with oversized clusters
-    K_REFINE = 4,        // K4: rochade_refine per cluster
-    K_FILTER_SORT = 5,   // K5: k/phi filter, reference-order emission
-    K_COUNT = 6
+    K_REFINE = 3,        // K4: rochade_refine per cluster + k/phi filter and reference-order emission
+                         //     (by the frame's last workgroup)
+    K_RARE = 4,          // K5: one guarded launch: generic clustering fallback for frames with oversized
+                         //     clusters (then refine + emission), large-list emission (> 512 saddles)
+    K_COUNT = 5
 };
 
 // One record of K4's output list.
@@ -39,7 +40,9 @@ struct FrameCounters {
     uint32_t n_cand;       // generic path: candidate pixels
     uint32_t n_roots;      // generic path: union-find roots
     uint32_t n_big;        // seeds handed to the wave-wide second flood tier
-    uint32_t pad1[22];
+    uint32_t refine_done;  // workgroups of k_refine that have finished this frame
+    uint32_t pad1;
+    uint32_t stats[20];    // debug_ablation & 128: verify statistics by word row within a 128-row segment
 };
 enum : uint32_t {
     FLAG_CAND_OVERFLOW = 1u,   // seed list (fast path) or candidate list (generic path) full
@@ -47,7 +50,8 @@ enum : uint32_t {
     FLAG_OUT_OVERFLOW = 4u,
     FLAG_CENTROID_INEXACT = 8u,  // a cluster's coordinate sum reached 2^24 (f32 sums of the
                                  // reference would round there)
-    FLAG_BIG_CLUSTER = 16u       // a component left the flood windows: frame redone generically
+    FLAG_BIG_CLUSTER = 16u,      // a component left the flood windows: frame redone generically
+    FLAG_LARGE_RESULT = 64u      // more saddles than k_refine's emission tail sorts: emitted by k_rare
 };
 
 struct RefineConsts {

@@ -16,17 +16,19 @@
 //                       row loop.  The response is NOT stored.  K1 also writes a candidate
 //                       SUPERSET as a transposed 1 bit / pixel mask: resp < 0.05*m for a running
 //                       minimum m >= min_frame.
-//   K2 k_verify         the exact threshold resp < 0.05*min_frame (detector.rs:418,177) at the set
-//                       bits that can still fail (response recomputed from the blur plane);
-//                       k_seeds: flood seeds from the mask
+//   K2 k_verify_seeds   the exact threshold resp < 0.05*min_frame (detector.rs:418,177) at the set
+//                       bits that can still fail (response recomputed from the blur plane) and the
+//                       flood seeds, in one pass over the mask
 //   K3 k_flood          4-connected components (image_util.rs:208-236) + centroid sums
 //                       (detector.rs:421-429): one component per lane, bit-parallel flood fill
 //                       of a 32x32 window of the mask held in registers; oversized components
 //                       by the whole wave in a 128x64 window
-//   K3g k_generic       guarded generic fallback (mask -> candidate list -> lock-free
-//                       union-find -> sums) for frames where a component leaves that window too
-//   K4 k_refine         rochade_refine (detector.rs:194-361), one cluster per lane
-//   K5 k_filter_sort    k/phi filter (detector.rs:436-445), emission in reference order
+//   K4 k_refine         rochade_refine (detector.rs:194-361), one cluster per lane; the workgroup
+//                       of a frame that finishes last applies the k/phi filter (detector.rs:436-445)
+//                       and emits the frame's saddles in reference order
+//   K5 k_rare           one guarded launch for the rare frames: generic clustering fallback (mask
+//                       -> candidate list -> lock-free union-find -> sums) where a component leaves
+//                       the flood windows, and the large-list sort (> 512 saddles per frame)
 #include <hip/hip_runtime.h>
 
 #include "chain_kernels.h"
@@ -228,10 +230,23 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
     const int total_full = per_frame_full * a.n_frames;
     int frame, strip, seg;
     if (u < total_full) {
-        frame = u / per_frame_full;
-        const int r = u - frame * per_frame_full;
-        seg = r / a.n_strips;
-        strip = r - seg * a.n_strips;
+        if (a.dbg & 1024) {  // A/B: the former frame-major order
+            frame = u / per_frame_full;
+            const int r = u - frame * per_frame_full;
+            seg = r / a.n_strips;
+            strip = r - seg * a.n_strips;
+        } else {
+            // segment-major over the whole batch: segment s of every frame before segment s+1 of any.
+            // The chip holds about half of the batch's waves at a time, so the later segments of a
+            // frame start when its earlier ones have published their minima: they threshold against a
+            // nearly final value from their first row on (a wave that starts with nothing known admits
+            // every noise-level negative response of its first rows, all of which K2 has to re-test).
+            const int per_seg = a.n_strips * a.n_frames;
+            seg = u / per_seg;
+            const int r = u - seg * per_seg;
+            frame = r / a.n_strips;
+            strip = r - frame * a.n_strips;
+        }
     } else {
         const int v = u - total_full;
         if (n_full == a.n_segs || v >= a.n_strips * a.n_frames) return;  // whole wave: padding of the last workgroup
@@ -615,103 +630,265 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
     if (lane == 0) atomicMax(&ctr.min_key_inv, ~f32_order_key(run_min));  // always: the word must end up valid
 }
 
+// The Hessian determinant of pixel c[0] of the blur plane -- same expression, same operands as K1.
+__device__ __forceinline__ float det_at(const float *c, int W)
+{
+    const float v11 = c[-W - 1], v12 = c[-W], v13 = c[-W + 1];
+    const float v21 = c[-1], v22 = c[0], v23 = c[1];
+    const float v31 = c[W - 1], v32 = c[W], v33 = c[W + 1];
+    const float t22 = v22 * 2.0f;
+    const float lxx = (v21 - t22) + v23;
+    const float lyy = (v12 - t22) + v32;
+    const float lxy = (((v13 - v11) + v31) - v33) * 0.25f;
+    return lxx * lyy - lxy * lxy;
+}
+
 // Re-test the set bits of one mask word against the final threshold (exact response from the blur
-// plane, same expression and operands as K1); returns the bits that stay.
+// plane); returns the bits that stay.  Four bits per round: their 36 loads are in flight together
+// (a word's bits are mostly a vertical run, so the windows share lines); a round with fewer bits
+// left repeats the last one.
 __device__ __forceinline__ uint32_t retest_word(const float *blur, int W, int yb, int x, uint32_t m0, float thr)
 {
     uint32_t m = m0, keep = m0;
+    const float *col = blur + (size_t)(yb * 32) * W + x;  // interior pixels only (K1 sets no border bits)
     while (m) {
-        const int b = __ffs(m) - 1;
+        int b[4];
+        b[0] = __ffs(m) - 1;
         m &= m - 1;
-        const float *c = blur + (size_t)(yb * 32 + b) * W + x;  // interior pixel (K1 sets no border bits)
-        const float v11 = c[-W - 1], v12 = c[-W], v13 = c[-W + 1];
-        const float v21 = c[-1], v22 = c[0], v23 = c[1];
-        const float v31 = c[W - 1], v32 = c[W], v33 = c[W + 1];
-        const float t22 = v22 * 2.0f;
-        const float lxx = (v21 - t22) + v23;
-        const float lyy = (v12 - t22) + v32;
-        const float lxy = (((v13 - v11) + v31) - v33) * 0.25f;
-        const float d = lxx * lyy - lxy * lxy;
-        if (!(d < thr)) keep &= ~(1u << b);
+#pragma unroll
+        for (int q = 1; q < 4; ++q) {
+            b[q] = m ? __ffs(m) - 1 : b[q - 1];
+            m &= m - 1;  // 0 stays 0
+        }
+        float d[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) d[q] = det_at(col + (size_t)b[q] * W, W);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (!(d[q] < thr)) keep &= ~(1u << b[q]);
     }
     return keep;
 }
 
 // ------------------------------------------------------------------------------------------
-// K2: verify.  K1 left a superset of the candidates in the mask (threshold from a running
-// minimum).  One thread per mask word: at every set bit recompute the Hessian determinant from
-// the blur plane -- same expression, same operands as K1 -- and keep the bit only if
-// resp < 0.05*min_frame (detector.rs:418, :177).  Each thread owns its word: no atomics.
+// K2: verify + seeds in ONE pass over the mask.  K1 left a superset of the candidates (threshold
+// from a running minimum).  Where the weakest candidate K1 admitted in a word's block does not
+// already pass the final threshold, the Hessian determinant is recomputed from the blur plane at
+// the set bits -- same expression, same operands as K1 -- and a bit stays only if
+// resp < 0.05*min_frame (detector.rs:418, :177).  Flood seeds come out of the same registers: a
+// seed is a candidate with no candidate to its left and none above, minus those whose run along
+// the row reaches (within 7 columns) a pixel with a candidate above it -- such a pixel is
+// 4-connected to an earlier one, so it cannot be the first pixel of its component, and dropping it
+// here saves a whole flood (2.1 -> 1.1 seeds per cluster).
+//
+// One wave owns 56 columns x up to 8 word rows (256 image rows): lane = column, lane 0 and lanes
+// 57..63 are halo lanes (the left neighbour and the 7 columns of look-ahead), verified redundantly
+// (verification is idempotent, so it does not matter whether the owning wave has already rewritten
+// a word).  The kernel is a chain of memory round trips, so each of them is made wide: all of a
+// lane's words, then all their block maxima, are fetched together; the bits that need the blur
+// plane go into a work list in LDS (wave prefix sum) and are re-tested one bit per lane with all
+// loads in flight, whatever lane they came from; failures clear their bit with an LDS atomic.  The
+// seeds of the tile are collected in LDS and appended to the frame's list with one atomic.
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_verify(ChainArgs a)
+constexpr int VS_OWN = 56;         // owner lanes of a wave (1 left halo + 56 + 7 look-ahead = 64)
+constexpr int VS_ROWS = 8;         // word rows per tile
+constexpr uint32_t VS_LIST = 512;  // re-test work list entries per pass
+constexpr uint32_t VS_SEEDS = 256; // seeds buffered per tile
+
+__global__ void __launch_bounds__(64) k_verify_seeds(ChainArgs a)
 {
-    const int frame = (int)(gridDim.y - 1 - blockIdx.y);  // latest-written blur planes first (cache)
-    const FrameCounters &ctr = a.ctr[frame];
+    __shared__ uint32_t s_keep[(VS_ROWS + 1) * 64];  // row VS_ROWS: bit 0 = the pixel above the tile's first row
+    __shared__ uint32_t s_list[VS_LIST];  // re-test work list, then the tile's seeds (VS_SEEDS <= VS_LIST)
+    uint32_t *s_seeds = s_list;
+    __shared__ uint32_t s_nseeds, s_base;
+    const FrameSlot fs = frame_slot(a.n_frames, true);  // latest-written blur planes first (cache)
+    const int frame = fs.frame;
+    FrameCounters &ctr = a.ctr[frame];
     const float thr = f32_from_order_key(~ctr.min_key_inv) * 0.05f;
     uint32_t *mask = a.mask + (size_t)frame * (size_t)a.mask_plane;
     const float *blur = a.blur + (size_t)frame * (size_t)a.plane;
-    const int W = a.W;
-    const int total = ((a.H + 31) >> 5) * W;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const int yb = i / W, x = i - yb * W;
-        uint32_t *wp = mask + (size_t)yb * a.mask_wpr + MASK_PAD_X + x;
-        const uint32_t m0 = *wp;
-        if (!m0) continue;
-        // every candidate K1 admitted in this word's 4-column x 32-row block is <= cand_max: if that
-        // is below the final threshold they all pass and nothing needs recomputing
-        if (a.cand_max[((size_t)frame * a.mask_yb + yb) * (a.mask_wpr >> 2) + ((MASK_PAD_X + x) >> 2)] < thr) continue;
-        const uint32_t keep = retest_word(blur, W, yb, x, m0, thr);
-        if (keep != m0) *wp = keep;
-    }
-}
-
-// Flood seeds = candidates with no candidate to the left and none above, from the mask; one
-// thread per 4 mask words (16-byte loads).
-__global__ void __launch_bounds__(256) k_seeds(ChainArgs a)
-{
-    const int frame = blockIdx.y;
-    FrameCounters &ctr = a.ctr[frame];
-    const uint32_t *mask = a.mask + (size_t)frame * (size_t)a.mask_plane;
-    const int W = a.W, wpr = a.mask_wpr, W4 = (W + 3) >> 2;
-    const int total = ((a.H + 31) >> 5) * W4;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const int yb = i / W4, x = (i - yb * W4) * 4;
-        const uint32_t *wp = mask + (size_t)yb * wpr + MASK_PAD_X + x;  // 16-byte aligned
-        const uint4 m4 = *reinterpret_cast<const uint4 *>(wp);          // words past W are zero padding
-        if (!(m4.x | m4.y | m4.z | m4.w)) continue;
-        const uint4 u4 = yb > 0 ? *reinterpret_cast<const uint4 *>(wp - wpr) : make_uint4(0u, 0u, 0u, 0u);
-        // the next four columns as well: a seed whose run along its row reaches a pixel with a
-        // candidate above it is 4-connected to an earlier pixel, so it cannot be the canonical seed
-        // of its component -- dropping it here saves a whole flood (about half of the raw seeds)
-        const uint4 n4 = *reinterpret_cast<const uint4 *>(wp + 4);  // inside the zero padding at the row's end
-        const uint4 v4 = yb > 0 ? *reinterpret_cast<const uint4 *>(wp - wpr + 4) : make_uint4(0u, 0u, 0u, 0u);
-        const uint32_t mm[8] = {m4.x, m4.y, m4.z, m4.w, n4.x, n4.y, n4.z, n4.w};
-        const uint32_t uw[8] = {u4.x, u4.y, u4.z, u4.w, v4.x, v4.y, v4.z, v4.w};
-        uint32_t up[8];  // bit r: the pixel above (column, row r) is a candidate
+    const float *cmax_f = a.cand_max + (size_t)frame * (size_t)a.mask_yb * (size_t)(a.mask_wpr >> 2);
+    const int W = a.W, wpr = a.mask_wpr;
+    const int lane = threadIdx.x;
+    const int n_yb = (a.H + 31) >> 5;
+    const int groups = (W + VS_OWN - 1) / VS_OWN;
+    const int tiles = ((n_yb + VS_ROWS - 1) / VS_ROWS) * groups;
+    if (lane == 0) s_nseeds = 0u;
+    __syncthreads();
+    for (int t = (int)fs.slot; t < tiles; t += (int)fs.n_slots) {  // wave-uniform
+        const int ch = t / groups, g = t - ch * groups;
+        const int yb0 = ch * VS_ROWS;
+        const int nr = min(VS_ROWS, n_yb - yb0);
+        const int x = g * VS_OWN - 1 + lane;  // -1 .. W + 62: inside the mask's zero padding
+        uint32_t *wp0 = mask + (size_t)yb0 * wpr + MASK_PAD_X + x;
+        const size_t cm_col = (size_t)((MASK_PAD_X + x) >> 2);
+        // round trip 1: the lane's words, the word above the tile, their blocks' maxima
+        uint32_t m[VS_ROWS];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) up[c] = (mm[c] << 1) | (uw[c] >> 31);
-        uint32_t left = wp[-1];
+        for (int r = 0; r < VS_ROWS; ++r) m[r] = r < nr ? wp0[(size_t)r * wpr] : 0u;
+        const uint32_t uword = yb0 > 0 ? wp0[-wpr] : 0u;
+        // (the block maxima are fetched in the same round trip, needed or not: the plane is small)
+        float cm_pre[VS_ROWS];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t m = mm[j];
-            uint32_t sd = m & ~left & ~up[j];
-            left = m;
-            uint32_t alive = sd;  // rows whose run still continues and has not met a pixel with one above
+        for (int r = 0; r < VS_ROWS; ++r) cm_pre[r] = r < nr ? cmax_f[(size_t)(yb0 + r) * (wpr >> 2) + cm_col] : 0.0f;
+        const float cmu_pre = yb0 > 0 ? cmax_f[(size_t)(yb0 - 1) * (wpr >> 2) + cm_col] : 0.0f;
+        uint32_t any = 0u;
 #pragma unroll
-            for (int c = j + 1; c < 8; ++c) {
-                alive &= mm[c];
-                const uint32_t kill = alive & up[c];
+        for (int r = 0; r < VS_ROWS; ++r) any |= m[r];
+        if (!__any(any != 0u)) continue;
+        // every candidate K1 admitted in a word's 4-column x 32-row block is <= cand_max;
+        // if that is below the final threshold they all pass and nothing needs recomputing
+        float cm[VS_ROWS];
+#pragma unroll
+        for (int r = 0; r < VS_ROWS; ++r) cm[r] = m[r] ? cm_pre[r] : -__builtin_inff();
+        // the pixel above row 0 of the tile is bit 31 of the word above: its verified state
+        const bool up_need = (m[0] & 1u) && (uword >> 31);
+        const float cmu = up_need ? cmu_pre : -__builtin_inff();
+        uint32_t needmask = 0u;
+#pragma unroll
+        for (int r = 0; r < VS_ROWS; ++r)
+            if (m[r] && !(cm[r] < thr)) needmask |= 1u << r;
+        const bool up_retest = up_need && !(cmu < thr);
+        if (a.dbg & 128) {  // statistics by word row within the K1 segment (4 word rows of 128 rows)
+            const bool own = lane >= 1 && lane <= VS_OWN && x < W;
+#pragma unroll
+            for (int r = 0; r < VS_ROWS; ++r)
+                if (own && m[r]) {
+                    const int q = (yb0 + r) & 3;
+                    atomicAdd(&ctr.stats[q * 4 + 0], 1u);                          // words with candidates
+                    atomicAdd(&ctr.stats[q * 4 + 1], (uint32_t)__popc(m[r]));      // candidate bits (superset)
+                    if (needmask & (1u << r)) {
+                        atomicAdd(&ctr.stats[q * 4 + 2], 1u);                      // words to re-test
+                        atomicAdd(&ctr.stats[q * 4 + 3], (uint32_t)__popc(m[r]));  // bits to re-test
+                    }
+                }
+        }
+        // Work list in ROW-MAJOR order (image row, then column): neighbouring lanes then re-test
+        // neighbouring columns of one row, so their nine loads each fall into one or two cache lines
+        // (a list in lane order -- every lane's bits one after the other -- put 64 different rows
+        // into every load and was 5x slower).  Built with one ballot per (word row, bit) that any
+        // lane needs; most of the volume is the first rows of a K1 segment, where the running
+        // threshold was still 0 and every lane has the same rows.
+        uint32_t keep[VS_ROWS];
+#pragma unroll
+        for (int r = 0; r < VS_ROWS; ++r) keep[r] = m[r];
+        uint32_t upbit = up_need ? 1u : 0u;
+        const unsigned long long need_any = __ballot(needmask != 0u || up_retest);
+        if (need_any && !(a.dbg & 32)) {  // wave-uniform
+            uint32_t rows_any = needmask;  // wave OR of the word rows that need the blur plane
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) rows_any |= __shfl_xor(rows_any, off, 64);
+            rows_any = __builtin_amdgcn_readfirstlane(rows_any);
+            uint32_t n_list = 0;  // wave-uniform fill of s_list
+            auto run_list = [&]() {
+                __syncthreads();
+                for (uint32_t e0 = 0; e0 < n_list; e0 += 128) {  // two bits per lane and round: 18 loads in flight
+                    float d[2];
+                    uint32_t ent[2];
+                    bool on[2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const uint32_t e = e0 + q * 64 + (uint32_t)lane;
+                        on[q] = e < n_list;
+                        ent[q] = s_list[on[q] ? e : 0u];  // (word row * 64 + lane) << 5 | bit
+                        const int ln = (int)((ent[q] >> 5) & 63u), r = (int)(ent[q] >> 11), b = (int)(ent[q] & 31u);
+                        const int row = r == VS_ROWS ? yb0 * 32 - 1 : (yb0 + r) * 32 + b;
+                        d[q] = (a.dbg & 256) ? 0.0f : det_at(blur + (size_t)row * W + (g * VS_OWN - 1 + ln), W);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        if (on[q] && !(d[q] < thr)) atomicAnd(&s_keep[ent[q] >> 5], ~(1u << (ent[q] & 31u)));
+                }
+                __syncthreads();
+                n_list = 0;
+            };
+            auto push = [&](bool mine, uint32_t entry) {  // one ballot: the lanes that have this (row, bit)
+                const unsigned long long bal = __ballot(mine);
+                const uint32_t k = (uint32_t)__popcll(bal);
+                if (n_list + k > VS_LIST) run_list();
+                if (mine) s_list[n_list + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = entry;
+                n_list += k;
+            };
+            s_keep[VS_ROWS * 64 + lane] = 1u;
+            if (__any(up_retest)) push(up_retest, (uint32_t)(VS_ROWS * 64 + lane) << 5);
+#pragma unroll
+            for (int r = 0; r < VS_ROWS; ++r) {
+                if (!(rows_any & (1u << r))) continue;  // wave-uniform
+                s_keep[r * 64 + lane] = m[r];
+                const uint32_t mr = (needmask & (1u << r)) ? m[r] : 0u;
+                uint32_t bits_any = mr;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) bits_any |= __shfl_xor(bits_any, off, 64);
+                bits_any = __builtin_amdgcn_readfirstlane(bits_any);
+                while (bits_any) {  // scalar loop over the image rows of this word row that any lane needs
+                    const int b = __builtin_ctz(bits_any);
+                    bits_any &= bits_any - 1;
+                    push((mr >> b) & 1u, ((uint32_t)(r * 64 + lane) << 5) | (uint32_t)b);
+                }
+            }
+            if (n_list) run_list();
+#pragma unroll
+            for (int r = 0; r < VS_ROWS; ++r)
+                if (rows_any & (1u << r)) keep[r] = s_keep[r * 64 + lane];
+            if (up_retest) upbit = s_keep[VS_ROWS * 64 + lane] & 1u;
+        }
+        const bool owner = lane >= 1 && lane <= VS_OWN && x < W;
+#pragma unroll
+        for (int r = 0; r < VS_ROWS; ++r)
+            if (owner && keep[r] != m[r]) wp0[(size_t)r * wpr] = keep[r];
+        if (a.dbg & 128) {
+#pragma unroll
+            for (int r = 0; r < VS_ROWS; ++r)
+                if (owner && m[r]) atomicAdd(&ctr.stats[16 + ((yb0 + r) & 3)], (uint32_t)__popc(keep[r]));  // bits that stay
+        }
+        // seeds, word row by word row; the bit above a word's row 0 is bit 31 of the word before
+        uint32_t carry = upbit;
+        if (a.dbg & 64) continue;
+#pragma unroll
+        for (int r = 0; r < VS_ROWS; ++r) {
+            const uint32_t kw = keep[r];  // rows past the tile's end hold no bits
+            const uint32_t upw = (kw << 1) | carry;  // bit q: the pixel above (column, row q) is a candidate
+            carry = kw >> 31;
+            uint32_t sd = kw & ~from_left_u(kw) & ~upw;
+            uint32_t alive = sd, mk = kw, uk = upw;  // rows whose run still continues and has not met a pixel with one above
+#pragma unroll
+            for (int k = 1; k < 8; ++k) {
+                mk = from_right_u(mk);
+                uk = from_right_u(uk);
+                alive &= mk;
+                const uint32_t kill = alive & uk;
                 sd &= ~kill;
                 alive &= ~kill;
             }
+            if (!owner) sd = 0u;
             while (sd) {
                 const int b = __ffs(sd) - 1;
                 sd &= sd - 1;
-                const uint32_t o = atomicAdd(&ctr.n_seeds, 1u);
-                if (o < a.cap_roots)
-                    a.seeds[(size_t)frame * a.cap_roots + o] = (uint32_t)(yb * 32 + b) * (uint32_t)W + (uint32_t)(x + j);
+                const uint32_t pix = (uint32_t)((yb0 + r) * 32 + b) * (uint32_t)W + (uint32_t)x;
+                const uint32_t i = atomicAdd(&s_nseeds, 1u);
+                if (i < VS_SEEDS) {
+                    s_seeds[i] = pix;
+                } else {  // buffer full (dense noise): straight to the frame's list
+                    const uint32_t o = atomicAdd(&ctr.n_seeds, 1u);
+                    if (o < a.cap_roots) a.seeds[(size_t)frame * a.cap_roots + o] = pix;
+                    else atomicOr(&ctr.flags, FLAG_CAND_OVERFLOW);
+                }
+            }
+        }
+        // append the tile's seeds to the frame's list: one atomic, coalesced stores
+        __syncthreads();
+        const uint32_t ns = min(s_nseeds, VS_SEEDS);
+        if (ns) {  // wave-uniform
+            if (lane == 0) s_base = atomicAdd(&ctr.n_seeds, ns);
+            __syncthreads();
+            for (uint32_t i = (uint32_t)lane; i < ns; i += 64u) {
+                const uint32_t o = s_base + i;
+                if (o < a.cap_roots) a.seeds[(size_t)frame * a.cap_roots + o] = s_seeds[i];
                 else atomicOr(&ctr.flags, FLAG_CAND_OVERFLOW);
             }
+            __syncthreads();
+            if (lane == 0) s_nseeds = 0u;
+            __syncthreads();
         }
     }
 }
@@ -851,12 +1028,13 @@ __device__ __forceinline__ bool flood_lane(const ChainArgs &a, int frame, const 
         comp[c] = 0u;
     }
     comp[16] = 2u;  // the seed: column sx, row sy
-    // A right-to-left sweep applies the full update rule to every column with its current
-    // neighbours, so "that sweep changed nothing" IS the fixed point: the left-to-right
-    // sweep before it need not be watched (convex blobs finish after one pair of sweeps).
-    uint32_t changed;
+    // One left-to-right and one right-to-left sweep, then the fixed-point test.  After a sweep every
+    // comp[c] is a union of whole vertical runs of cand[c], so the update rule would change column c
+    // exactly if a neighbouring column holds a component pixel next to a candidate of c that is not
+    // in comp[c] yet: 4 operations per column instead of a third and fourth sweep (convex blobs are
+    // complete after the first pair).
+    uint32_t pending;
     do {
-        changed = 0u;
 #pragma unroll
         for (int c = 0; c < FLOOD_COLS; ++c) {  // left-to-right sweep
             uint32_t s = comp[c];
@@ -869,11 +1047,17 @@ __device__ __forceinline__ bool flood_lane(const ChainArgs &a, int frame, const 
             uint32_t s = comp[c];
             if (c > 0) s |= comp[c - 1];
             if (c < FLOOD_COLS - 1) s |= comp[c + 1];
-            const uint32_t f = fill_runs(s & cand[c], cand[c]);
-            changed |= f ^ comp[c];
-            comp[c] = f;
+            comp[c] = fill_runs(s & cand[c], cand[c]);
         }
-    } while (changed);
+        pending = 0u;
+#pragma unroll
+        for (int c = 0; c < FLOOD_COLS; ++c) {
+            uint32_t nb = 0u;
+            if (c > 0) nb |= comp[c - 1];
+            if (c < FLOOD_COLS - 1) nb |= comp[c + 1];
+            pending |= nb & cand[c] & ~comp[c];
+        }
+    } while (pending);
     uint32_t all = 0u, left_of_seed = 0u;
 #pragma unroll
     for (int c = 0; c < FLOOD_COLS; ++c) {
@@ -912,7 +1096,7 @@ __device__ __forceinline__ bool flood_lane(const ChainArgs &a, int frame, const 
     return false;
 }
 
-__global__ void __launch_bounds__(64) k_flood(ChainArgs a)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) k_flood(ChainArgs a)
 {
     const FrameSlot fs = frame_slot(a.n_frames, false);
     const int frame = fs.frame;
@@ -1075,13 +1259,6 @@ __device__ __forceinline__ void generic_frame(const ChainArgs &a, int frame)
     if (t == 0) ctr.n_clusters = nr;
 }
 
-__global__ void __launch_bounds__(1024) k_generic(ChainArgs a)
-{
-    const int frame = blockIdx.x;
-    if (!frame_is_generic(a, a.ctr[frame])) return;  // whole workgroup
-    generic_frame(a, frame);
-}
-
 
 // Debug only (agx_debug_fetch AGX_DBG_RESP): the response plane K2 thresholds, materialised.
 __global__ void k_debug_resp(const float *__restrict__ blur, float *__restrict__ resp, int W, int H)
@@ -1204,30 +1381,14 @@ __device__ __forceinline__ void refine_cluster(const ChainArgs &a, const RefineC
     const float phi = acosf(-c5 / k) / 2.0f / PI_F * 180.0f;
     const float theta = atan2f(c3, c4) / 2.0f / PI_F * 180.0f;
     uint32_t o = atomicAdd(n_refined, 1u);  // o < n_clusters <= cap_roots
-    RefinedRec rec;
-    rec.key = a.clu_key[cbase + s];
-    rec.x = rxf + x0;
-    rec.y = ryf + y0;
-    rec.k = k;
-    rec.theta = theta;
-    rec.phi = phi;
-    a.refined[(size_t)frame * a.cap_roots + o] = rec;
+    // The record is handed to another workgroup (the frame's emission tail, possibly on another
+    // CU): write-through stores (sc1) here, bypassing loads there -- no cache-wide release fence.
+    uint32_t *rec = reinterpret_cast<uint32_t *>(a.refined + (size_t)frame * a.cap_roots + o);
+    const uint32_t f[6] = {a.clu_key[cbase + s], __float_as_uint(rxf + x0), __float_as_uint(ryf + y0),
+                           __float_as_uint(k),  __float_as_uint(theta),     __float_as_uint(phi)};
+#pragma unroll
+    for (int q = 0; q < 6; ++q) __hip_atomic_store(rec + q, f[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     atomicMax(max_k_bits, __float_as_uint(k));
-}
-
-template <bool VEC>
-__global__ void __launch_bounds__(64, 4) k_refine(ChainArgs a, RefineConsts rc)
-{
-    const FrameSlot fs = frame_slot(a.n_frames, true);  // latest-written blur planes first (cache)
-    const int frame = fs.frame;
-    if (a.ctr[frame].flags & (FLAG_CAND_OVERFLOW | FLAG_ROOT_OVERFLOW)) return;
-    const uint32_t n = min(a.ctr[frame].n_clusters, a.cap_roots);
-    const size_t cbase = (size_t)frame * a.cap_roots;
-    const float *img = a.blur + (size_t)frame * (size_t)a.plane;
-    const int W = a.W, H = a.H;
-    for (uint32_t i = fs.slot * blockDim.x + threadIdx.x; i < n; i += fs.n_slots * blockDim.x) {
-        refine_cluster<VEC>(a, rc, frame, cbase, img, W, H, i, &a.ctr[frame].n_refined, &a.ctr[frame].max_k_bits);
-    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1242,7 +1403,9 @@ __device__ __forceinline__ void filter_sort_emit(const ChainArgs &a, int frame, 
 {
     const uint32_t t = threadIdx.x, T = blockDim.x;
     FrameCounters &ctr = a.ctr[frame];
-    const RefinedRec *rec = a.refined + (size_t)frame * a.cap_roots;
+    // records written by other workgroups: every read bypasses this CU's L1 / this XCD's L2 (sc1)
+    uint32_t *rec = reinterpret_cast<uint32_t *>(a.refined + (size_t)frame * a.cap_roots);
+    auto rec_u = [&](uint32_t i, int field) { return __hip_atomic_load(rec + (size_t)i * 6 + field, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     if (t == 0) *s_count = 0;
     __syncthreads();
     uint32_t nf = 0;
@@ -1250,11 +1413,11 @@ __device__ __forceinline__ void filter_sort_emit(const ChainArgs &a, int frame, 
     if (n != 0) {  // detector.rs:432-434: nothing refined -> empty result
         const float s_max_k = __uint_as_float(max_k_bits) / 10.0f;
         for (uint32_t i = t; i < n; i += T) {
-            const float k = rec[i].k, phi = rec[i].phi;
+            const float k = __uint_as_float(rec_u(i, 3)), phi = __uint_as_float(rec_u(i, 5));
             if (k >= s_max_k && phi >= a.min_angle && phi <= a.max_angle) {
                 uint32_t o = atomicAdd(s_count, 1u);
                 if (o < lds_entries) {
-                    keys[o] = rec[i].key;
+                    keys[o] = rec_u(i, 0);
                     idxs[o] = i;
                 }
             }
@@ -1301,35 +1464,179 @@ __device__ __forceinline__ void filter_sort_emit(const ChainArgs &a, int frame, 
         ctr.out_offset = off;
         if (a.frame_table) {
             uint32_t *row = a.frame_table + (size_t)frame * 4;
-            const uint32_t flags = ctr.flags;
+            const uint32_t flags = __hip_atomic_load(&ctr.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const bool bad = (flags & (FLAG_CAND_OVERFLOW | FLAG_ROOT_OVERFLOW | FLAG_OUT_OVERFLOW)) != 0;
             row[0] = bad ? 0u : nf;
             row[1] = off;
             row[2] = flags;
-            row[3] = ctr.n_clusters;
+            row[3] = __hip_atomic_load(&ctr.n_clusters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     __syncthreads();
     if (!ok || !nf || !*s_fits) return;
     float *out = a.out + (size_t)*s_offset * 5;
     for (uint32_t i = t; i < nf; i += T) {
-        const RefinedRec r = rec[idxs[i]];
-        out[i * 5 + 0] = r.x;
-        out[i * 5 + 1] = r.y;
-        out[i * 5 + 2] = r.k;
-        out[i * 5 + 3] = r.theta;
-        out[i * 5 + 4] = r.phi;
+        const uint32_t src = idxs[i];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) out[i * 5 + q] = __uint_as_float(rec_u(src, q + 1));
     }
 }
 
-__global__ void k_filter_sort(ChainArgs a, uint32_t lds_entries)
+// The emission tail of k_refine: filter and ordered emission of one frame by ONE wave, for up to
+// TAIL_CAP refined records.  Every lane fetches its records' (key, k, phi) with the loads in flight
+// together, rejected records get the key 0xffffffff, and a surviving record's output position is
+// its rank = the number of smaller keys (keys are distinct: the first pixel of distinct clusters) --
+// no sort passes, two memory round trips.  Returns false (nothing emitted) if the list is longer.
+constexpr uint32_t TAIL_CAP = 1024;
+
+__device__ __forceinline__ bool emit_small(const ChainArgs &a, int frame, uint32_t n, uint32_t max_k_bits, uint32_t *keys,
+                                           uint32_t *s_misc)
+{
+    const uint32_t t = threadIdx.x;  // 64 threads
+    FrameCounters &ctr = a.ctr[frame];
+    if (n > TAIL_CAP) {
+        if (t == 0) atomicOr(&ctr.flags, FLAG_LARGE_RESULT);
+        return false;
+    }
+    uint32_t *rec = reinterpret_cast<uint32_t *>(a.refined + (size_t)frame * a.cap_roots);
+    auto rec_u = [&](uint32_t i, int field) { return __hip_atomic_load(rec + (size_t)i * 6 + field, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    const float s_max_k = __uint_as_float(max_k_bits) / 10.0f;  // detector.rs:436
+    uint32_t mine = 0;
+    for (uint32_t i0 = 0; i0 < n; i0 += 256) {  // 4 records per lane and round, 12 loads in flight
+        uint32_t key[4], kb[4], pb[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t i = i0 + q * 64 + t;
+            key[q] = kb[q] = pb[q] = 0u;
+            if (i < n) {
+                key[q] = rec_u(i, 0);
+                kb[q] = rec_u(i, 3);
+                pb[q] = rec_u(i, 5);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t i = i0 + q * 64 + t;
+            if (i < n) {
+                const float k = __uint_as_float(kb[q]), phi = __uint_as_float(pb[q]);
+                const bool pass = k >= s_max_k && phi >= a.min_angle && phi <= a.max_angle;
+                keys[i] = pass ? key[q] : 0xffffffffu;
+                mine += pass ? 1u : 0u;
+            }
+        }
+    }
+    // pad to a multiple of 4 for the 16-byte reads of the rank loop
+    if (t < 4 && n + t < ((n + 3u) & ~3u)) keys[n + t] = 0xffffffffu;
+    uint32_t nf = mine;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) nf += __shfl_xor(nf, off, 64);
+    if (t == 0) {
+        uint32_t off = 0, fits = 1;
+        const bool ok = nf <= a.cap_out;
+        if (ok && nf) {
+            off = atomicAdd(a.total_out, nf);
+            if (off + nf > a.out_total_cap) fits = 0;  // caller's buffer is full
+        }
+        if (!ok || !fits) atomicOr(&ctr.flags, FLAG_OUT_OVERFLOW);
+        s_misc[0] = off;
+        s_misc[1] = (ok && fits) ? 1u : 0u;
+        ctr.n_out = nf;
+        ctr.out_offset = off;
+        if (a.frame_table) {
+            uint32_t *row = a.frame_table + (size_t)frame * 4;
+            const uint32_t flags = __hip_atomic_load(&ctr.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool bad = (flags & (FLAG_CAND_OVERFLOW | FLAG_ROOT_OVERFLOW | FLAG_OUT_OVERFLOW)) != 0;
+            row[0] = bad ? 0u : nf;
+            row[1] = off;
+            row[2] = flags;
+            row[3] = __hip_atomic_load(&ctr.n_clusters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    if (!nf || !s_misc[1]) return true;
+    float *out = a.out + (size_t)s_misc[0] * 5;
+    const uint32_t n4 = (n + 3u) >> 2;
+    for (uint32_t i = t; i < n; i += 64) {
+        const uint32_t key = keys[i];
+        if (key == 0xffffffffu) continue;
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < n4; ++j) {  // every lane reads the same 16 bytes: LDS broadcast
+            const uint4 q = reinterpret_cast<const uint4 *>(keys)[j];
+            rank += (q.x < key ? 1u : 0u) + (q.y < key ? 1u : 0u) + (q.z < key ? 1u : 0u) + (q.w < key ? 1u : 0u);
+        }
+        uint32_t f[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) f[q] = rec_u(i, q + 1);
+#pragma unroll
+        for (int q = 0; q < 5; ++q) out[(size_t)rank * 5 + q] = __uint_as_float(f[q]);
+    }
+    return true;
+}
+
+// K4 launch: rochade_refine of every cluster, then -- by the workgroup of a frame that finishes
+// last -- the k / phi filter and the ordered emission of that frame (up to TAIL_CAP refined
+// records; longer lists are left to k_rare).  Frames on the generic clustering path are skipped
+// here altogether and done by k_rare.
+template <bool VEC>
+__global__ void __launch_bounds__(64, 4) k_refine(ChainArgs a, RefineConsts rc)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t s_keys[TAIL_CAP + 4];
+    __shared__ uint32_t s_misc[2], s_last;
+    const FrameSlot fs = frame_slot(a.n_frames, true);  // latest-written blur planes first (cache)
+    const int frame = fs.frame;
+    FrameCounters &ctr = a.ctr[frame];
+    if (frame_is_generic(a, ctr)) return;  // whole frame: k_rare
+    if (!(ctr.flags & (FLAG_CAND_OVERFLOW | FLAG_ROOT_OVERFLOW))) {
+        const uint32_t n = min(ctr.n_clusters, a.cap_roots);
+        const size_t cbase = (size_t)frame * a.cap_roots;
+        const float *img = a.blur + (size_t)frame * (size_t)a.plane;
+        for (uint32_t i = fs.slot * blockDim.x + threadIdx.x; i < n; i += fs.n_slots * blockDim.x)
+            refine_cluster<VEC>(a, rc, frame, cbase, img, a.W, a.H, i, &ctr.n_refined, &ctr.max_k_bits);
+    }
+    // The workgroup of this frame that arrives last emits the frame.  Everything it reads from the
+    // others (records, counters, flags) was written by write-through stores / atomics and is read by
+    // bypassing loads, so the hand-off needs only "my stores have left" -- an agent-scope release
+    // fence would write back the XCD's whole L2 once per workgroup (6144 times per launch).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(&ctr.refine_done, 1u) == fs.n_slots - 1u;
+    __syncthreads();
+    if (!s_last) return;
+    const uint32_t n_ref = __hip_atomic_load(&ctr.n_refined, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t maxk = __hip_atomic_load(&ctr.max_k_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    emit_small(a, frame, n_ref, maxk, s_keys, s_misc);
+}
+
+// Rare paths, one guarded launch at the end of the chain (a 1024-thread workgroup per frame that
+// returns at once unless the frame is flagged):
+//   FLAG_BIG_CLUSTER   a component left the flood windows: the frame is clustered again by the
+//                      generic union-find path, refined and emitted here;
+//   FLAG_LARGE_RESULT  more than TAIL_CAP refined records: filter and ordered emission with the large
+//                      LDS sort.
+__global__ void __launch_bounds__(1024) k_rare(ChainArgs a, RefineConsts rc, uint32_t lds_entries)
 {
     extern __shared__ uint32_t lds_u[];
     __shared__ uint32_t s_count, s_offset, s_fits;
     const int frame = blockIdx.x;
-    const FrameCounters &ctr = a.ctr[frame];
-    filter_sort_emit(a, frame, ctr.n_refined, ctr.max_k_bits, lds_u, lds_u + lds_entries, lds_entries, &s_count, &s_offset,
-                     &s_fits);
+    FrameCounters &ctr = a.ctr[frame];
+    const bool generic = frame_is_generic(a, ctr);
+    if (!generic && !(ctr.flags & FLAG_LARGE_RESULT)) return;  // whole workgroup
+    if (generic) {
+        generic_frame(a, frame);
+        phase_barrier();
+        const uint32_t flags = __hip_atomic_load(&ctr.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!(flags & (FLAG_CAND_OVERFLOW | FLAG_ROOT_OVERFLOW))) {
+            const uint32_t n = min(__hip_atomic_load(&ctr.n_clusters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), a.cap_roots);
+            const size_t cbase = (size_t)frame * a.cap_roots;
+            const float *img = a.blur + (size_t)frame * (size_t)a.plane;
+            for (uint32_t i = threadIdx.x; i < n; i += blockDim.x)
+                refine_cluster<false>(a, rc, frame, cbase, img, a.W, a.H, i, &ctr.n_refined, &ctr.max_k_bits);
+        }
+        phase_barrier();
+    }
+    const uint32_t n_ref = __hip_atomic_load(&ctr.n_refined, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t maxk = __hip_atomic_load(&ctr.max_k_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    filter_sort_emit(a, frame, n_ref, maxk, lds_u, lds_u + lds_entries, lds_entries, &s_count, &s_offset, &s_fits);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1415,19 +1722,18 @@ int launch_kernel(int which, const ChainArgs &a, const RefineConsts &rc, void *s
         if (a.fmt == 1) return launch_k1<1>(a, st);
         return launch_k1<2>(a, st);
     case K_THRESHOLD: {
-        dim3 grid(sparse_grid_x(a, 128, "AGX_G_VERIFY"), a.n_frames), grid4(sparse_grid_x(a, 16, "AGX_G_SEEDS"), a.n_frames), block(256);
-        hipLaunchKernelGGL(k_verify, grid, dim3(64), 0, st, a);  // single-wave workgroups: a slot frees when its wave is done
-        hipLaunchKernelGGL(k_seeds, grid4, block, 0, st, a);
+        // one workgroup (= one wave) per tile of 56 columns x 8 word rows, at most 256 per frame
+        const int n_yb = (a.H + 31) >> 5;
+        int tiles = ((n_yb + 7) / 8) * ((a.W + 55) / 56);
+        if (tiles > 256) tiles = 256;
+        const int per_frame = env_int("AGX_G_VERIFY", tiles);
+        dim3 grid((unsigned)per_frame * (unsigned)a.n_frames), block(64);  // slot-major, see frame_slot
+        hipLaunchKernelGGL(k_verify_seeds, grid, block, 0, st, a);
         return hipGetLastError();
     }
     case K_FLOOD: {
         dim3 grid((unsigned)sparse_grid_x(a, 48, "AGX_G_FLOOD") * (unsigned)a.n_frames), block(64);  // slot-major, see frame_slot
         hipLaunchKernelGGL(k_flood, grid, block, 0, st, a);
-        return hipGetLastError();
-    }
-    case K_GENERIC: {
-        dim3 grid(a.n_frames), block(1024);
-        hipLaunchKernelGGL(k_generic, grid, block, 0, st, a);
         return hipGetLastError();
     }
     case K_REFINE: {
@@ -1436,10 +1742,10 @@ int launch_kernel(int which, const ChainArgs &a, const RefineConsts &rc, void *s
         else hipLaunchKernelGGL(k_refine<false>, grid, block, 0, st, a, rc);
         return hipGetLastError();
     }
-    case K_FILTER_SORT: {
+    case K_RARE: {
         size_t lds = k5_lds_bytes(a);  // (the large-LDS attribute is set per device in init_device_kernels)
-        dim3 grid(a.n_frames), block(512);  // measured: 128 -> 34, 256 -> 23, 512 / 1024 -> 18 us
-        hipLaunchKernelGGL(k_filter_sort, grid, block, lds, st, a, (uint32_t)(lds / 8));
+        dim3 grid(a.n_frames), block(1024);
+        hipLaunchKernelGGL(k_rare, grid, block, lds, st, a, rc, (uint32_t)(lds / 8));
         return hipGetLastError();
     }
     default:
@@ -1451,7 +1757,7 @@ int launch_kernel(int which, const ChainArgs &a, const RefineConsts &rc, void *s
 // agx_detector_create after hipSetDevice, once per handle (any number of devices per process).
 int init_device_kernels()
 {
-    return hipFuncSetAttribute((const void *)k_filter_sort, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+    return hipFuncSetAttribute((const void *)k_rare, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
 }
 
 int launch_debug_resp(const ChainArgs &a, int frame, float *dst, void *stream)

@@ -20,8 +20,7 @@ using namespace agx;
 
 namespace {
 
-const char *kKernelNames[K_COUNT] = {"k_blur_hessian", "k_threshold", "k_flood",
-                                     "k_generic",   "k_refine",    "k_filter_sort"};
+const char *kKernelNames[K_COUNT] = {"k_blur_hessian", "k_verify_seeds", "k_flood", "k_refine_emit", "k_rare"};
 
 struct EventPair {
     hipEvent_t a, b;
@@ -871,6 +870,12 @@ int agx_debug_fetch(agx_detector *det, int frame, int what, void *host_out, size
         if (cap_bytes < 8 * sizeof(uint32_t)) return AGX_ERR_CAPACITY;
         const uint32_t v[8] = {c.flags, c.n_seeds, c.n_big, c.n_clusters, c.n_cand, c.n_roots, c.n_refined, c.n_out};
         std::memcpy(host_out, v, sizeof v);
+        return AGX_OK;
+    }
+    case 7: {  // verify statistics (debug_ablation & 128), 20 x uint32
+        *n_items = 20;
+        if (cap_bytes < 20 * sizeof(uint32_t)) return AGX_ERR_CAPACITY;
+        std::memcpy(host_out, c.stats, sizeof c.stats);
         return AGX_OK;
     }
     case AGX_DBG_MIN: {

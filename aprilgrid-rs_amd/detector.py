@@ -306,7 +306,7 @@ class TagDetector:
         """Intermediate product of the last batch: 'blur', 'resp' (HxW f32; K1's in-register response,
         needs set_option("store_response", 1) before the batch), 'resp_recomputed', 'min' (f32),
         'centers' (cluster table sorted by first pixel), 'refined' (unfiltered saddles)."""
-        code = {"blur": 0, "resp": 1, "min": 2, "centers": 3, "refined": 4, "counters": 5, "resp_recomputed": 6}[what]
+        code = {"blur": 0, "resp": 1, "min": 2, "centers": 3, "refined": 4, "counters": 5, "resp_recomputed": 6, "verify_stats": 7}[what]
         n = C.c_size_t(0)
         if code in (0, 1, 6):
             assert shape is not None
@@ -315,6 +315,8 @@ class TagDetector:
             buf = np.empty(1, np.float32)
         elif code == 5:
             buf = np.empty(8, np.uint32)
+        elif code == 7:
+            buf = np.empty(20, np.uint32)
         elif code == 3:
             buf = np.empty(1 << 20, _CLUSTER_DTYPE)
         else:
@@ -325,6 +327,8 @@ class TagDetector:
         if code == 5:
             return dict(zip(["flags", "seeds", "big_seeds", "clusters", "generic_candidates", "generic_roots",
                              "refined", "saddles"], [int(v) for v in buf]))
+        if code == 7:
+            return buf
         if code in (3, 4):
             return buf[: n.value].copy()
         return buf

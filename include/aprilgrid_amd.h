@@ -177,7 +177,8 @@ enum {
     AGX_FRAME_SADDLE_OVERFLOW = 4,
     AGX_FRAME_CENTROID_INEXACT = 8, /* informational: a cluster's coordinate sum reached 2^24 */
     AGX_FRAME_GENERIC_PATH = 16,    /* informational: clustered by the generic kernels         */
-    AGX_FRAME_DENSE_THRESHOLD = 32  /* informational: thresholded by the dense fallback kernel */
+    AGX_FRAME_DENSE_THRESHOLD = 32, /* (unused) */
+    AGX_FRAME_LARGE_RESULT = 64     /* informational: more than 512 saddles, emitted by the large-list kernel */
 };
 int agx_saddles_batch_enqueue_to(agx_detector *det, const void *d_frames, int n_frames, int width,
                                  int height, size_t row_stride_bytes, size_t frame_stride_bytes,
@@ -209,7 +210,7 @@ int agx_luma8(const void *pixels, int width, int height, size_t row_stride_bytes
 /* Per-kernel device time of the chain, from hipEvents recorded on the detector's stream
  * around each launch while profiling is on.  names/ms/launches are arrays of
  * AGX_N_KERNELS entries; ms accumulates since the last reset. */
-#define AGX_N_KERNELS 6
+#define AGX_N_KERNELS 5
 int agx_profile_enable(agx_detector *det, int on); /* 0 off, 1 = the blur kernel only (2 events per batch), 2 = every kernel */
 int agx_profile_reset(agx_detector *det);
 int agx_profile_read(agx_detector *det, const char **names, double *ms_total, uint64_t *launches);
