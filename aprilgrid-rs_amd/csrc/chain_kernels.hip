@@ -516,13 +516,18 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
                         const float v11 = up[j], v12 = up[j + 1], v13 = up[j + 2];
                         const float v21 = mid[j], v22 = mid[j + 1], v23 = mid[j + 2];
                         const float v31 = dn[j], v32 = dn[j + 1], v33 = dn[j + 2];
-                        const float t22 = v22 * 2.0f;
-                        const float lxx = (v21 - t22) + v23;
-                        const float lyy = (v12 - t22) + v32;
-                        const float lxy = (((v13 - v11) + v31) - v33) * 0.25f;
+                        // image_util.rs:100-104 with three roundings removed that cannot happen: 2*v22 is
+                        // exact, so (v21 - 2*v22) rounds once either way; lxy = s*0.25 and lxy*lxy =
+                        // RN(s*s)/16 are exact scalings (luma from 8 / 16-bit integers: s is 0 or far above
+                        // the subnormal range), so lxx*lyy - lxy*lxy = RN(RN(lxx*lyy) - RN(s*s)/16), which
+                        // is what the last fma evaluates.  Checked bit for bit against the oracle through
+                        // the stored-response instantiation (AGX_DBG_RESP).
+                        const float lxx = __builtin_fmaf(v22, -2.0f, v21) + v23;
+                        const float lyy = __builtin_fmaf(v22, -2.0f, v12) + v32;
+                        const float sxy = ((v13 - v11) + v31) - v33;
                         // columns outside the lane's share (halo lanes, the image's border ring) hold a
                         // meaningless value here; they are masked where the columns are combined
-                        dv[j] = lxx * lyy - lxy * lxy;
+                        dv[j] = __builtin_fmaf(sxy * sxy, -0.0625f, lxx * lyy);
                     }
                     if (RESP) {  // the in-register response itself (border ring stays zero)
                         float *rrow = a.resp_dbg + (size_t)frame * (size_t)a.plane + (size_t)y * W + c0;

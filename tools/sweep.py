@@ -6,8 +6,10 @@ import aprilgrid_rs_amd as A
 from aprilgrid_rs_amd import synth
 F = int(os.environ.get("FRAMES", "256"))
 rows = [int(x) for x in (sys.argv[1:] or ["0"])]
-base, _ = synth.render_batch(0, 32, 1280, 800, device="cuda")
-frames = base.repeat((F // 32 + 1, 1, 1))[:F].contiguous()
+U = int(os.environ.get("UNIQUE", "32"))
+W, H = int(os.environ.get("WIDTH", "1280")), int(os.environ.get("HEIGHT", "800"))
+base, _ = synth.render_batch(0, U, W, H, device="cuda")
+frames = base.repeat((F // U + 1, 1, 1))[:F].contiguous()
 det = A.TagDetector("t36h11")
 import time
 DBG = [int(x) for x in os.environ.get("DBG", "0").split(",")]
