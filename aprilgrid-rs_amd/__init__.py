@@ -6,8 +6,8 @@ include/aprilgrid_amd.h.  All compute happens in libaprilgrid_amd.so (hand-writt
 gfx950 plus the C++ host tail); importing this package fails loudly if that library has not
 been built -- there is no CPU fallback.
 """
-from .detector import (DetectorParams, Saddle, TagDetector, TagFamily, AgxError, SADDLE_DTYPE,
+from .detector import (DetectorGroup, DetectorParams, Saddle, TagDetector, TagFamily, AgxError, SADDLE_DTYPE,
                        build_library, library_path)
 
-__all__ = ["DetectorParams", "Saddle", "TagDetector", "TagFamily", "AgxError", "SADDLE_DTYPE",
+__all__ = ["DetectorGroup", "DetectorParams", "Saddle", "TagDetector", "TagFamily", "AgxError", "SADDLE_DTYPE",
            "build_library", "library_path"]

@@ -10,6 +10,7 @@ AGX_OK = 0
 AGX_ERR_ARG, AGX_ERR_FORMAT, AGX_ERR_CAPACITY, AGX_ERR_HIP = -1, -2, -3, -4
 AGX_ERR_NO_DEVICE, AGX_ERR_FAMILY, AGX_ERR_STATE = -5, -6, -7
 AGX_L8, AGX_L16, AGX_RGB8 = 0, 1, 2
+AGX_GATHER_RCCL, AGX_GATHER_PEER = 0, 1
 AGX_DBG_BLUR, AGX_DBG_RESP, AGX_DBG_MIN, AGX_DBG_CENTERS, AGX_DBG_REFINED = 0, 1, 2, 3, 4
 AGX_N_KERNELS = 5
 
@@ -53,6 +54,14 @@ SYMBOLS = {
     "agx_saddles_batch_fetch": (C.c_int, [_P, _P, C.c_uint32, _P, _P]),
     "agx_saddles_batch_enqueue_to": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_int,
                                                _P, C.c_uint32, _P]),
+    "agx_group_create": (C.c_int, [C.c_int, C.POINTER(Params), C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(_P)]),
+    "agx_group_destroy": (None, [_P]),
+    "agx_group_size": (C.c_int, [_P]),
+    "agx_group_detector": (_P, [_P, C.c_int]),
+    "agx_group_saddles_enqueue": (C.c_int, [_P, C.POINTER(_P), C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_int,
+                                            C.c_uint32]),
+    "agx_group_saddles_fetch": (C.c_int, [_P, _P, C.c_uint32, _P, _P]),
+    "agx_group_last_error": (C.c_char_p, [_P]),
     "agx_detect_from_saddles": (C.c_int, [_P, _P, C.c_uint32, _P, C.c_int, C.c_int, C.c_size_t, _P, C.c_uint32,
                                           C.POINTER(C.c_uint32)]),
     "agx_detect_tail": (C.c_int, [C.c_int, C.POINTER(Params), _P, C.c_uint32, _P, C.c_int, C.c_int, C.c_size_t, _P,

@@ -14,6 +14,7 @@
 
 #include "../../include/aprilgrid_amd.h"
 #include "chain_kernels.h"
+#include "detector_internal.h"
 #include "host_tail.hpp"
 
 using namespace agx;
@@ -81,7 +82,7 @@ struct agx_detector {
 
 namespace {
 
-std::string g_create_error;  // reason of the last failed agx_detector_create (det == NULL)
+thread_local std::string g_create_error;  // reason of this thread's last failed agx_detector_create (det == NULL)
 
 int fail(agx_detector *d, int status, const std::string &msg)
 {
@@ -370,6 +371,9 @@ int bytes_per_px(int f) { return f == AGX_L8 ? 1 : (f == AGX_L16 ? 2 : 3); }
 extern "C" {
 
 int agx_abi_version(void) { return AGX_ABI_VERSION; }
+
+__attribute__((visibility("hidden"))) void *agx_internal_stream(agx_detector *det) { return det ? (void *)det->stream : nullptr; }
+__attribute__((visibility("hidden"))) int agx_internal_device(const agx_detector *det) { return det ? det->device : -1; }
 
 const char *agx_status_string(int status)
 {

@@ -332,3 +332,72 @@ class TagDetector:
         if code in (3, 4):
             return buf[: n.value].copy()
         return buf
+
+
+class DetectorGroup:
+    """Several GPUs of one node from ONE process over the C ABI's detector groups (agx_group_*):
+    rank r = one TagDetector on devices[r] with its own stream; a batch shards by frame and the
+    per-rank result slabs are gathered to devices[0] (transport "rccl": ncclSend / ncclRecv over
+    xGMI; "peer": hipMemcpyPeerAsync -- also accepts the same device twice, for one-GPU boxes)."""
+
+    def __init__(self, tag_family, devices, optional_detector_params=None, transport="rccl"):
+        self._lib = _ffi.lib()
+        self._g = C.c_void_p()
+        fam = TagFamily.from_str(tag_family) if isinstance(tag_family, str) else TagFamily(tag_family)
+        prm = optional_detector_params._c() if optional_detector_params is not None else None
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        tr = {"rccl": _ffi.AGX_GATHER_RCCL, "peer": _ffi.AGX_GATHER_PEER}[transport]
+        st = self._lib.agx_group_create(int(fam), C.byref(prm) if prm is not None else None, devs, len(devices), tr,
+                                        C.byref(self._g))
+        if st != _ffi.AGX_OK:
+            self._g = C.c_void_p()
+            raise AgxError(st, "agx_group_create: %s" % self._lib.agx_group_last_error(None).decode())
+        self.devices = list(devices)
+        self._keep = None
+        self._frames_per_rank = 0
+
+    def close(self):
+        if getattr(self, "_g", None) and self._g.value:
+            self._lib.agx_group_destroy(self._g)
+            self._g = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return self._lib.agx_group_size(self._g)
+
+    def _check(self, st):
+        if st != _ffi.AGX_OK:
+            raise AgxError(st, self._lib.agx_group_last_error(self._g).decode())
+
+    def saddles_enqueue(self, frames_per_rank, records_per_frame=0):
+        """frames_per_rank: one contiguous device tensor per rank ([F,H,W] u8 / int16 or [F,H,W,3] u8,
+        same shape everywhere), rank r's on devices[r]; the caller has made sure they are ready
+        (e.g. torch.cuda.synchronize): the ranks run on their detectors' own streams."""
+        assert len(frames_per_rank) == len(self.devices)
+        fmt, bpp = TagDetector._tensor_format(frames_per_rank[0])
+        n, h, w = frames_per_rank[0].shape[:3]
+        for t in frames_per_rank:
+            assert tuple(t.shape) == tuple(frames_per_rank[0].shape) and t.is_contiguous() and t.is_cuda
+        ptrs = (C.c_void_p * len(frames_per_rank))(*[t.data_ptr() for t in frames_per_rank])
+        self._check(self._lib.agx_group_saddles_enqueue(self._g, ptrs, n, w, h, w * bpp, w * h * bpp, fmt,
+                                                        records_per_frame))
+        self._keep = list(frames_per_rank)
+        self._frames_per_rank = n
+
+    def saddles_fetch(self, cap_per_frame=2048, raise_on_overflow=True):
+        """-> (list of SADDLE_DTYPE arrays, global frame r*F + f; status array)."""
+        n = self._frames_per_rank * len(self.devices)
+        out = np.zeros((n, cap_per_frame), SADDLE_DTYPE)
+        counts = np.zeros(n, np.uint32)
+        status = np.zeros(n, np.int32)
+        st = self._lib.agx_group_saddles_fetch(self._g, out.ctypes.data, cap_per_frame, counts.ctypes.data,
+                                               status.ctypes.data)
+        if st != _ffi.AGX_OK and (raise_on_overflow or st != _ffi.AGX_ERR_CAPACITY):
+            self._check(st)
+        self._keep = None
+        return [out[i, : counts[i]].copy() for i in range(n)], status

@@ -188,6 +188,41 @@ int agx_saddles_batch_enqueue_to(agx_detector *det, const void *d_frames, int n_
 /* Block until everything enqueued on the detector's stream has finished. */
 int agx_detector_sync(agx_detector *det);
 
+/* ---- detector groups: several GPUs of one node driven from ONE process ----------------- */
+
+/* The reference's detect(&self) is stateless, so a batch shards by frame:
+ * rank r of a group owns one device, runs the whole chain for its own frames on its own stream,
+ * and the only exchange step is the gather of the per-rank result slabs to the root device
+ * (devices[0]).  A Rust host drives all GPUs of a node through these calls without torch. */
+typedef struct agx_group agx_group;
+enum {
+    AGX_GATHER_RCCL = 0, /* ncclSend / ncclRecv in one group over xGMI (librccl opened on first use);
+                            devices must be distinct */
+    AGX_GATHER_PEER = 1  /* hipMemcpyPeerAsync + events over the same links; accepts a device more than
+                            once (test configuration on one-GPU boxes) */
+};
+/* One detector (TagDetector::new, src/detector.rs:364-406) per entry of devices[] (NULL:
+ * 0..n_devices-1). */
+int agx_group_create(int family, const agx_params *params, const int *devices, int n_devices, int transport,
+                     agx_group **out);
+void agx_group_destroy(agx_group *group);
+int agx_group_size(const agx_group *group);
+/* Borrow rank r's detector (limits, options, profiling); owned by the group. */
+agx_detector *agx_group_detector(agx_group *group, int rank);
+/* refined_saddle_points (src/detector.rs:408-446) over n_devices * frames_per_rank frames: rank r's
+ * frames are resident on ITS device at d_frames[r] (layout as agx_saddles_batch_enqueue).  Enqueues
+ * every rank's chain and the gather and returns without waiting.  records_per_frame: average saddle
+ * records per frame the per-rank result slab holds (0 = 512). */
+int agx_group_saddles_enqueue(agx_group *group, const void *const *d_frames, int frames_per_rank, int width,
+                              int height, size_t row_stride_bytes, size_t frame_stride_bytes, int format,
+                              uint32_t records_per_frame);
+/* Wait for the gather; frame f of rank r is global frame r*frames_per_rank + f of out / counts /
+ * frame_status (sized n_devices*frames_per_rank, as agx_saddles_batch_fetch). */
+int agx_group_saddles_fetch(agx_group *group, agx_saddle *out, uint32_t cap_per_frame, uint32_t *counts,
+                            int *frame_status);
+/* group == NULL: the reason of this thread's last failed agx_group_create. */
+const char *agx_group_last_error(const agx_group *group);
+
 /* Host tail only: TagDetector::detect's board search + decode (src/detector.rs:510-539)
  * from a saddle list and the u8 luma plane (to_luma8, :507), both in host memory.
  * saddles is not modified. */

@@ -1,0 +1,126 @@
+"""One process, several detectors / devices: per-handle and per-device state of the
+C ABI, handles driven from threads, and the C-level detector groups with their result gather.
+Every test is parametrised by what the box has and passes with a single GPU (two ranks may share
+device 0 with the peer-copy transport; the RCCL transport needs distinct devices and runs where
+there are at least two)."""
+import threading
+
+import numpy as np
+import pytest
+
+from tests.util import check_saddles, oracle_saddles_parallel, synth_module
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import oracle as O
+    O.lib()
+    return O
+
+
+def _frames(first, n, device, w=640, h=400):
+    synth = synth_module()
+    fr, _ = synth.render_batch(first, n, w, h, device=device)
+    return fr
+
+
+def test_one_handle_per_device_from_threads(oracle):
+    """One TagDetector per visible device, each created and driven by its own thread of ONE process
+    (plus two more handles on device 0): every result equals the oracle's.  Exercises the per-device
+    kernel attributes (a process-wide flag used to configure device 0 only) and the per-thread
+    current-device / error state."""
+    import torch
+    import aprilgrid_rs_amd as A
+    n_dev = torch.cuda.device_count()
+    jobs = [(d, 100 + 8 * d) for d in range(n_dev)] + [(0, 300), (0, 400)]
+    results, errors = {}, []
+
+    def work(slot, dev, first):
+        try:
+            det = A.TagDetector("t36h11", None, device=dev)
+            fr = _frames(first, 3, "cuda:%d" % dev)
+            torch.cuda.synchronize(dev)
+            for _ in range(3):  # several batches per handle while the other threads run theirs
+                det.saddles_batch_enqueue(fr)
+                res, status = det.saddles_batch_fetch()
+            assert (status == 0).all()
+            results[slot] = (fr.cpu().numpy(), res)
+            det.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append((slot, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(i, d, f)) for i, (d, f) in enumerate(jobs)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for slot, (host, res) in results.items():
+        refs = oracle_saddles_parallel(oracle, host, threads=3)
+        for i in range(len(res)):
+            check_saddles(res[i], refs[i], "job %d frame %d" % (slot, i))
+
+
+@pytest.mark.parametrize("ranks", [1, 2, 3])
+def test_group_peer_transport(oracle, ranks):
+    """agx_group_* with the peer-copy gather: `ranks` ranks over the visible devices (round-robin, so
+    a one-GPU box runs them all on device 0).  The gathered, rank-major frame list must equal the
+    oracle frame by frame."""
+    import torch
+    import aprilgrid_rs_amd as A
+    n_dev = torch.cuda.device_count()
+    devices = [r % n_dev for r in range(ranks)]
+    grp = A.DetectorGroup("t36h11", devices, transport="peer")
+    assert len(grp) == ranks
+    frames = [_frames(50 + 4 * r, 4, "cuda:%d" % devices[r]) for r in range(ranks)]
+    for d in set(devices):
+        torch.cuda.synchronize(d)
+    for rep in range(2):  # twice: slab reuse
+        grp.saddles_enqueue(frames)
+        res, status = grp.saddles_fetch()
+    assert (status == 0).all() and len(res) == 4 * ranks
+    host = np.concatenate([f.cpu().numpy() for f in frames])
+    refs = oracle_saddles_parallel(oracle, host, threads=4)
+    for i in range(len(res)):
+        check_saddles(res[i], refs[i], "global frame %d" % i)
+    grp.close()
+
+
+def test_group_reports_overflow_per_frame(oracle):
+    import torch
+    import aprilgrid_rs_amd as A
+    grp = A.DetectorGroup("t36h11", [0, 0], transport="peer")
+    frames = [_frames(9, 2, "cuda:0"), _frames(11, 2, "cuda:0")]
+    torch.cuda.synchronize(0)
+    grp.saddles_enqueue(frames, records_per_frame=16)  # slabs of 32 records: nothing fits
+    with pytest.raises(A.AgxError) as e:
+        grp.saddles_fetch()
+    assert e.value.status == -3
+    grp.saddles_enqueue(frames)
+    res, status = grp.saddles_fetch()
+    assert (status == 0).all() and all(len(r) > 50 for r in res)
+    grp.close()
+
+
+def test_group_rccl_transport(oracle):
+    """The RCCL gather (ncclSend / ncclRecv over xGMI) on every visible device; with one GPU the
+    group has a single rank and must not need librccl at all."""
+    import torch
+    import aprilgrid_rs_amd as A
+    n_dev = torch.cuda.device_count()
+    grp = A.DetectorGroup("t36h11", list(range(n_dev)), transport="rccl")
+    frames = [_frames(70 + 3 * r, 3, "cuda:%d" % r) for r in range(n_dev)]
+    for d in range(n_dev):
+        torch.cuda.synchronize(d)
+    grp.saddles_enqueue(frames)
+    res, status = grp.saddles_fetch()
+    assert (status == 0).all()
+    host = np.concatenate([f.cpu().numpy() for f in frames])
+    refs = oracle_saddles_parallel(oracle, host, threads=4)
+    for i in range(len(res)):
+        check_saddles(res[i], refs[i], "global frame %d" % i)
+    grp.close()
+    with pytest.raises(A.AgxError):
+        A.DetectorGroup("t36h11", [0, 0], transport="rccl")  # duplicate devices: refused, not hung
