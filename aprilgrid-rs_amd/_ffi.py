@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(_PKG_DIR, "libaprilgrid_amd.so")
 AGX_OK = 0
 AGX_ERR_ARG, AGX_ERR_FORMAT, AGX_ERR_CAPACITY, AGX_ERR_HIP = -1, -2, -3, -4
 AGX_ERR_NO_DEVICE, AGX_ERR_FAMILY, AGX_ERR_STATE = -5, -6, -7
-AGX_L8, AGX_L16, AGX_RGB8 = 0, 1, 2
+AGX_L8, AGX_L16, AGX_RGB8, AGX_LF32 = 0, 1, 2, 3
 AGX_GATHER_RCCL, AGX_GATHER_PEER = 0, 1
 AGX_DBG_BLUR, AGX_DBG_RESP, AGX_DBG_MIN, AGX_DBG_CENTERS, AGX_DBG_REFINED = 0, 1, 2, 3, 4
 AGX_N_KERNELS = 5
@@ -50,6 +50,7 @@ SYMBOLS = {
                                             C.POINTER(C.c_uint32)]),
     "agx_detect": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_size_t, C.c_int, _P, C.c_uint32,
                              C.POINTER(C.c_uint32)]),
+    "agx_detect_planes": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_size_t, C.c_int, C.c_int, _P, C.c_uint32, C.POINTER(C.c_uint32)]),
     "agx_saddles_batch_enqueue": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_int]),
     "agx_saddles_batch_fetch": (C.c_int, [_P, _P, C.c_uint32, _P, _P]),
     "agx_saddles_batch_enqueue_to": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_int,

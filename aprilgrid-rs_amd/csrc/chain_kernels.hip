@@ -104,10 +104,10 @@ __device__ __forceinline__ uint32_t from_right_u(uint32_t v)
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true);
 }
 
-// Raw pixel words of 4 consecutive pixels: L8 1 dword, L16 2 dwords, RGB8 3 dwords.
+// Raw pixel words of 4 consecutive pixels: L8 1 dword, L16 2 dwords, RGB8 3 dwords, LF32 4 dwords.
 template <int FMT>
 struct RawPx {
-    static constexpr int BPP = FMT == 0 ? 1 : (FMT == 1 ? 2 : 3);
+    static constexpr int BPP = FMT == 0 ? 1 : (FMT == 1 ? 2 : (FMT == 2 ? 3 : 4));
     uint32_t d[BPP];
 };
 
@@ -160,6 +160,9 @@ __device__ __forceinline__ void convert_px(const RawPx<FMT> &r, float m[4])
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             m[j] = div_const<65535>((float)((r.d[j >> 1] >> (16 * (j & 1))) & 0xffffu));
+    } else if (FMT == 3) {  // the caller's own to_luma32f plane
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m[j] = __uint_as_float(r.d[j]);
     } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -345,7 +348,7 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
     // BUF: W % 4 == 0, any format -- the rows of a group are fetched together through the buffer
     // resource one group ahead (L16 keeps its raw 2 dwords per row and converts row by row).
     constexpr bool BUF = A4;
-    constexpr int RW = FMT == 2 ? 3 : (FMT == 1 ? 2 : 1);  // input dwords per lane and row
+    constexpr int RW = FMT == 2 ? 3 : (FMT == 1 ? 2 : (FMT == 3 ? 4 : 1));  // input dwords per lane and row
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
     uint32_t ring[7][RW];
@@ -364,7 +367,14 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
     __amdgpu_buffer_rsrc_t rs_blur = __builtin_amdgcn_make_buffer_rsrc((void *)blur_f, 0, (int)blur_bytes, RSRC_WORD3);
     auto issue_load = [&](int r, uint32_t (&dst)[RW]) {
         const int rr = r < 0 ? 0 : (r > H - 1 ? H - 1 : r);
-        if (FMT == 2) {
+        if (FMT == 3) {
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_in, cc * 4, rr * a.row_stride, 0);
+            dst[0] = v.x;
+            dst[RW > 1 ? 1 : 0] = v.y;
+            dst[RW > 2 ? 2 : 0] = v.z;
+            dst[RW > 3 ? 3 : 0] = v.w;
+        } else if (FMT == 2) {
             const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(rs_in, cc * 3, rr * a.row_stride, 0);
             dst[0] = v.x;
             dst[RW > 1 ? 1 : 0] = v.y;
@@ -426,6 +436,10 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
                 const uint32_t dd = __builtin_amdgcn_perm(cur[k], cur[k], edge_sel);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) P[j] = s_lut4[(dd >> (8 * j)) & 0xffu];
+            } else if (BUF && FMT == 3) {  // LF32, aligned: lanes left / right of the image replicate the edge pixel
+                const uint32_t first = got[k][0], last = got[k][RW > 3 ? 3 : 0];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) m[j] = __uint_as_float(c0 < 0 ? first : (c0 >= W ? last : got[k][RW > j ? j : 0]));
             } else if (BUF) {  // L16, aligned: 4 x u16 in two dwords, edge lanes replicate by permute
                 const uint32_t d0 = got[k][0], d1 = got[k][RW > 1 ? 1 : 0];
                 const uint32_t e0 = __builtin_amdgcn_perm(d1, d0, sel16_lo), e1 = __builtin_amdgcn_perm(d1, d0, sel16_hi);
@@ -516,18 +530,26 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
                         const float v11 = up[j], v12 = up[j + 1], v13 = up[j + 2];
                         const float v21 = mid[j], v22 = mid[j + 1], v23 = mid[j + 2];
                         const float v31 = dn[j], v32 = dn[j + 1], v33 = dn[j + 2];
-                        // image_util.rs:100-104 with three roundings removed that cannot happen: 2*v22 is
-                        // exact, so (v21 - 2*v22) rounds once either way; lxy = s*0.25 and lxy*lxy =
-                        // RN(s*s)/16 are exact scalings (luma from 8 / 16-bit integers: s is 0 or far above
-                        // the subnormal range), so lxx*lyy - lxy*lxy = RN(RN(lxx*lyy) - RN(s*s)/16), which
-                        // is what the last fma evaluates.  Checked bit for bit against the oracle through
-                        // the stored-response instantiation (AGX_DBG_RESP).
-                        const float lxx = __builtin_fmaf(v22, -2.0f, v21) + v23;
-                        const float lyy = __builtin_fmaf(v22, -2.0f, v12) + v32;
-                        const float sxy = ((v13 - v11) + v31) - v33;
                         // columns outside the lane's share (halo lanes, the image's border ring) hold a
                         // meaningless value here; they are masked where the columns are combined
-                        dv[j] = __builtin_fmaf(sxy * sxy, -0.0625f, lxx * lyy);
+                        if (FMT == 3) {  // arbitrary f32 planes: image_util.rs:100-104 literally
+                            const float t22 = v22 * 2.0f;
+                            const float lxx = (v21 - t22) + v23;
+                            const float lyy = (v12 - t22) + v32;
+                            const float lxy = (((v13 - v11) + v31) - v33) * 0.25f;
+                            dv[j] = lxx * lyy - lxy * lxy;
+                        } else {
+                            // the same with three roundings removed that cannot happen: 2*v22 is exact, so
+                            // (v21 - 2*v22) rounds once either way; lxy = s*0.25 and lxy*lxy = RN(s*s)/16 are
+                            // exact scalings (luma from 8 / 16-bit integers: s is 0 or far above the subnormal
+                            // range), so lxx*lyy - lxy*lxy = RN(RN(lxx*lyy) - RN(s*s)/16), which is what the
+                            // last fma evaluates.  Checked bit for bit against the oracle through the
+                            // stored-response instantiation (AGX_DBG_RESP).
+                            const float lxx = __builtin_fmaf(v22, -2.0f, v21) + v23;
+                            const float lyy = __builtin_fmaf(v22, -2.0f, v12) + v32;
+                            const float sxy = ((v13 - v11) + v31) - v33;
+                            dv[j] = __builtin_fmaf(sxy * sxy, -0.0625f, lxx * lyy);
+                        }
                     }
                     if (RESP) {  // the in-register response itself (border ring stays zero)
                         float *rrow = a.resp_dbg + (size_t)frame * (size_t)a.plane + (size_t)y * W + c0;
@@ -1725,6 +1747,7 @@ int launch_kernel(int which, const ChainArgs &a, const RefineConsts &rc, void *s
     case K_BLUR_HESSIAN:
         if (a.fmt == 0) return launch_k1<0>(a, st);
         if (a.fmt == 1) return launch_k1<1>(a, st);
+        if (a.fmt == 3) return launch_k1<3>(a, st);
         return launch_k1<2>(a, st);
     case K_THRESHOLD: {
         // one workgroup (= one wave) per tile of 56 columns x 8 word rows, at most 256 per frame

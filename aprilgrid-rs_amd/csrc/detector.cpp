@@ -77,6 +77,9 @@ struct agx_detector {
     double prof_ms[K_COUNT]{};
     uint64_t prof_launches[K_COUNT]{};
 
+    std::vector<agx_saddle> scratch_saddles;  // host staging of agx_detect / agx_detect_planes (reused)
+    std::vector<uint8_t> scratch_grey;
+
     std::string last_error;
 };
 
@@ -363,8 +366,9 @@ int frame_status_of(const FrameCounters &c, uint32_t cap_per_frame)
     return AGX_OK;
 }
 
-bool valid_format(int f) { return f == AGX_L8 || f == AGX_L16 || f == AGX_RGB8; }
-int bytes_per_px(int f) { return f == AGX_L8 ? 1 : (f == AGX_L16 ? 2 : 3); }
+bool valid_format(int f) { return f == AGX_L8 || f == AGX_L16 || f == AGX_RGB8 || f == AGX_LF32; }
+int bytes_per_px(int f) { return f == AGX_L8 ? 1 : (f == AGX_L16 ? 2 : (f == AGX_RGB8 ? 3 : 4)); }
+const char *kFormatMsg = "format must be AGX_L8, AGX_L16, AGX_RGB8 or AGX_LF32";
 
 }  // namespace
 
@@ -556,7 +560,7 @@ static int batch_enqueue_impl(agx_detector *det, const void *d_frames, int n_fra
                               uint32_t saddle_capacity, void *d_frame_table)
 {
     if (!det || !d_frames || n_frames <= 0) return fail(det, AGX_ERR_ARG, "null frames or n_frames <= 0");
-    if (!valid_format(format)) return fail(det, AGX_ERR_FORMAT, "format must be AGX_L8, AGX_L16 or AGX_RGB8");
+    if (!valid_format(format)) return fail(det, AGX_ERR_FORMAT, kFormatMsg);
     if (width < 2 || height < 2) return fail(det, AGX_ERR_ARG, "width and height must be >= 2");
     if ((long long)width * height >= (1ll << 30) || width > 65000) return fail(det, AGX_ERR_ARG, "frame too large (>= 2^30 px or wider than 65000)");
     const size_t px_bytes = (size_t)bytes_per_px(format);
@@ -565,6 +569,8 @@ static int batch_enqueue_impl(agx_detector *det, const void *d_frames, int n_fra
         return fail(det, AGX_ERR_ARG, "strides must cover a row / a frame");
     if (format == AGX_L16 && ((row_stride_bytes | frame_stride_bytes | (uintptr_t)d_frames) & 1))
         return fail(det, AGX_ERR_ARG, "16-bit pixels must be 2-byte aligned");
+    if (format == AGX_LF32 && ((row_stride_bytes | frame_stride_bytes | (uintptr_t)d_frames) & 3))
+        return fail(det, AGX_ERR_ARG, "f32 pixels must be 4-byte aligned");
     // rows that are not 4-byte aligned (tightly packed L8 / RGB8 of a width that is not a multiple
     // of 4, odd-width L16): the blur kernel gathers bytes instead of loading dwords
     const bool byte_rows = ((row_stride_bytes | (uintptr_t)d_frames | (n_frames > 1 ? frame_stride_bytes : 0)) & 3) != 0;
@@ -682,7 +688,7 @@ int agx_refined_saddle_points(agx_detector *det, const void *pixels, int width, 
                               int format, agx_saddle *out, uint32_t cap, uint32_t *n_out)
 {
     if (!det || !pixels || !n_out) return fail(det, AGX_ERR_ARG, "null argument");
-    if (!valid_format(format)) return fail(det, AGX_ERR_FORMAT, "format must be AGX_L8, AGX_L16 or AGX_RGB8");
+    if (!valid_format(format)) return fail(det, AGX_ERR_FORMAT, kFormatMsg);
     if (width < 2 || height < 2) return fail(det, AGX_ERR_ARG, "width and height must be >= 2");
     const size_t row_bytes = (size_t)width * bytes_per_px(format);
     if (row_stride_bytes < row_bytes) return fail(det, AGX_ERR_ARG, "row stride smaller than a row");
@@ -701,15 +707,18 @@ int agx_refined_saddle_points(agx_detector *det, const void *pixels, int width, 
                                   hipMemcpyHostToDevice, det->stream));
     int rc = agx_saddles_batch_enqueue(det, det->d_stage, 1, width, height, pitch, need, format);
     if (rc) return rc;
-    // fetch into a private buffer first so that a too-small `cap` reports the needed size
+    // one frame: the pinned host mirror of the batch fetch holds the list; a too-small `cap` reports
+    // the needed size
     uint32_t count = 0;
     int st = AGX_OK;
-    std::vector<agx_saddle> tmp(det->args.cap_out);
-    rc = agx_saddles_batch_fetch(det, tmp.data(), det->args.cap_out, &count, &st);
-    *n_out = count;
-    if (rc) return rc;
-    if (count > cap) return fail(det, AGX_ERR_CAPACITY, "output capacity too small");
-    if (count) std::memcpy(out, tmp.data(), (size_t)count * sizeof(agx_saddle));
+    rc = agx_saddles_batch_fetch(det, nullptr, 0, &count, &st);  // cap 0: counts and status only
+    if (rc && rc != AGX_ERR_CAPACITY) return rc;
+    const FrameCounters &c = det->h_ctr[0];
+    if (c.flags & (FLAG_CAND_OVERFLOW | FLAG_ROOT_OVERFLOW | FLAG_OUT_OVERFLOW)) return AGX_ERR_CAPACITY;  // last_error set by fetch
+    *n_out = c.n_out;
+    if (c.n_out > cap) return fail(det, AGX_ERR_CAPACITY, "output capacity too small");
+    if (c.n_out) std::memcpy(out, det->h_out + (size_t)c.out_offset * 5, (size_t)c.n_out * sizeof(agx_saddle));
+    det->last_error.clear();
     return AGX_OK;
 }
 
@@ -757,19 +766,37 @@ int agx_detect(agx_detector *det, const void *pixels, int width, int height, siz
                agx_tag *out, uint32_t cap, uint32_t *n_out)
 {
     if (!det || !pixels || !n_out) return fail(det, AGX_ERR_ARG, "null argument");
-    if (!valid_format(format)) return fail(det, AGX_ERR_FORMAT, "format must be AGX_L8, AGX_L16 or AGX_RGB8");
+    if (!valid_format(format)) return fail(det, AGX_ERR_FORMAT, kFormatMsg);
     if (width < 2 || height < 2) return fail(det, AGX_ERR_ARG, "width and height must be >= 2");
+    if (format == AGX_LF32) return fail(det, AGX_ERR_FORMAT, "an f32 luma plane carries no u8 luma for the decode: use agx_detect_planes");
     // detector.rs:507-508: u8 luma for the decode, saddle chain on the device
-    std::vector<uint8_t> grey((size_t)width * height);
+    std::vector<uint8_t> &grey = det->scratch_grey;
+    grey.resize((size_t)width * height);
     int rc = luma8(pixels, width, height, row_stride_bytes, format, grey.data());
     if (rc) return rc;
-    std::vector<agx_saddle> saddles(16384);
+    std::vector<agx_saddle> &saddles = det->scratch_saddles;
+    saddles.resize(16384);
     uint32_t ns = 0;
     rc = agx_refined_saddle_points(det, pixels, width, height, row_stride_bytes, format, saddles.data(),
                                    (uint32_t)saddles.size(), &ns);
     if (rc) return rc;
     return agx_detect_from_saddles(det, saddles.data(), ns, grey.data(), width, height, (size_t)width, out, cap,
                                    n_out);
+}
+
+int agx_detect_planes(agx_detector *det, const float *luma32f, size_t stride32f_bytes, const uint8_t *luma8,
+                      size_t stride8_bytes, int width, int height, agx_tag *out, uint32_t cap, uint32_t *n_out)
+{
+    if (!det || !luma32f || !luma8 || !n_out) return fail(det, AGX_ERR_ARG, "null argument");
+    if (width < 2 || height < 2) return fail(det, AGX_ERR_ARG, "width and height must be >= 2");
+    if (stride8_bytes < (size_t)width) return fail(det, AGX_ERR_ARG, "row stride smaller than a row");
+    std::vector<agx_saddle> &saddles = det->scratch_saddles;
+    saddles.resize(16384);
+    uint32_t ns = 0;
+    int rc = agx_refined_saddle_points(det, luma32f, width, height, stride32f_bytes, AGX_LF32, saddles.data(),
+                                       (uint32_t)saddles.size(), &ns);
+    if (rc) return rc;
+    return agx_detect_from_saddles(det, saddles.data(), ns, luma8, width, height, stride8_bytes, out, cap, n_out);
 }
 
 int agx_profile_enable(agx_detector *det, int on)

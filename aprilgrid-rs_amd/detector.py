@@ -83,7 +83,9 @@ def _image_args(img):
         return a, _ffi.AGX_L16, a.shape[1] * 2
     if a.ndim == 3 and a.shape[2] == 3 and a.dtype == np.uint8:
         return a, _ffi.AGX_RGB8, a.shape[1] * 3
-    raise AgxError(_ffi.AGX_ERR_FORMAT, "image must be HxW uint8/uint16 or HxWx3 uint8, got %s %s"
+    if a.ndim == 2 and a.dtype == np.float32:  # the caller's own to_luma32f plane (any DynamicImage variant)
+        return a, _ffi.AGX_LF32, a.shape[1] * 4
+    raise AgxError(_ffi.AGX_ERR_FORMAT, "image must be HxW uint8/uint16/float32 or HxWx3 uint8, got %s %s"
                    % (a.shape, a.dtype))
 
 
@@ -146,6 +148,19 @@ class TagDetector:
         out = (_ffi.TagC * cap)()
         n = C.c_uint32(0)
         self._check(self._lib.agx_detect(self._h, a.ctypes.data, w, h, stride, fmt, out, cap, C.byref(n)))
+        return {int(out[i].id): np.array(out[i].xy, np.float32).reshape(4, 2) for i in range(n.value)}
+
+    def detect_planes(self, luma32f, luma8, cap=4096):
+        """detect() of any DynamicImage variant from its two planes: img.to_luma32f() (HxW float32)
+        for the saddle chain and img.to_luma8() (HxW uint8) for the decode."""
+        f = np.ascontiguousarray(luma32f, np.float32)
+        g = np.ascontiguousarray(luma8, np.uint8)
+        assert f.shape == g.shape and f.ndim == 2
+        h, w = f.shape
+        out = (_ffi.TagC * cap)()
+        n = C.c_uint32(0)
+        self._check(self._lib.agx_detect_planes(self._h, f.ctypes.data, w * 4, g.ctypes.data, w, w, h, out, cap,
+                                                C.byref(n)))
         return {int(out[i].id): np.array(out[i].xy, np.float32).reshape(4, 2) for i in range(n.value)}
 
     def detect_kornia(self, img):
@@ -234,6 +249,8 @@ class TagDetector:
             return _ffi.AGX_L16, 2
         if frames.dim() == 4 and frames.shape[3] == 3 and frames.dtype == torch.uint8:
             return _ffi.AGX_RGB8, 3
+        if frames.dim() == 3 and frames.dtype == torch.float32:
+            return _ffi.AGX_LF32, 4
         raise AgxError(_ffi.AGX_ERR_FORMAT, "unsupported frame tensor %s %s" % (tuple(frames.shape), frames.dtype))
 
     def saddles_batch_enqueue(self, frames):

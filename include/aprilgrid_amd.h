@@ -33,7 +33,8 @@ extern "C" {
 typedef enum agx_status {
     AGX_OK = 0,
     AGX_ERR_ARG = -1,       /* null pointer, zero size, w or h < 2, bad stride            */
-    AGX_ERR_FORMAT = -2,    /* pixel format / channel count the reference panics on       */
+    AGX_ERR_FORMAT = -2,    /* pixel format / channel count the reference panics on; agx_detect /
+                               agx_luma8 on AGX_LF32 (no u8 luma to derive: agx_detect_planes)     */
     AGX_ERR_CAPACITY = -3,  /* an output or internal list overflowed; nothing is truncated
                                silently -- raise the capacity (agx_detector_set_limits)    */
     AGX_ERR_HIP = -4,       /* a HIP runtime call failed; see agx_last_error              */
@@ -52,11 +53,15 @@ typedef enum agx_family {
 } agx_family;
 
 /* The three DynamicImage variants the reference's tests, benches and detect_kornia feed the
- * path (src/detector.rs:409,507,478-503): ImageLuma8, ImageLuma16, ImageRgb8 (HWC). */
+ * path (src/detector.rs:409,507,478-503): ImageLuma8, ImageLuma16, ImageRgb8 (HWC) -- their luma
+ * conversion (image crate to_luma32f) is fused into the blur kernel -- and, for every other
+ * variant (La8, Rgba8, Rgb16, Rgba16, Rgb32F ...), the caller's own img.to_luma32f() plane. */
 typedef enum agx_format {
     AGX_L8 = 0,   /* 1 byte / pixel                                    */
     AGX_L16 = 1,  /* 2 bytes / pixel, native endian                    */
-    AGX_RGB8 = 2  /* 3 bytes / pixel, interleaved R,G,B (kornia Image<u8,3>) */
+    AGX_RGB8 = 2, /* 3 bytes / pixel, interleaved R,G,B (kornia Image<u8,3>) */
+    AGX_LF32 = 3  /* 4 bytes / pixel: row-major f32 luma in [0,1] = DynamicImage::to_luma32f
+                     (src/detector.rs:409) as the caller computed it; taken as is */
 } agx_format;
 
 /* detector::DetectorParams -- src/detector.rs:25-41 */
@@ -138,6 +143,13 @@ int agx_refined_saddle_points(agx_detector *det, const void *pixels, int width, 
  * id (a later quad with the same id replaces the earlier one, as HashMap::insert). */
 int agx_detect(agx_detector *det, const void *pixels, int width, int height,
                size_t row_stride_bytes, int format, agx_tag *out, uint32_t cap, uint32_t *n_out);
+
+/* detect() for ANY DynamicImage variant: the caller hands over the two planes the reference
+ * derives from the image itself -- img.to_luma32f() for the saddle chain (src/detector.rs:409) and
+ * img.to_luma8() for the code decode (:507, :518) -- so the result does not depend on this
+ * library restating the image crate's conversions for that variant. */
+int agx_detect_planes(agx_detector *det, const float *luma32f, size_t stride32f_bytes, const uint8_t *luma8,
+                      size_t stride8_bytes, int width, int height, agx_tag *out, uint32_t cap, uint32_t *n_out);
 
 /* ---- batches of equally sized frames resident in device memory (HBM) ------------------ */
 

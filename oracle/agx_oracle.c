@@ -30,6 +30,7 @@
 #define ORC_FMT_L8 0
 #define ORC_FMT_L16 1
 #define ORC_FMT_RGB8 2
+#define ORC_FMT_LF32 3 /* the caller's own DynamicImage::to_luma32f plane (any other variant), taken as is */
 
 typedef struct {
     float x, y, k, theta, phi;
@@ -74,6 +75,8 @@ int orc_luma_f32(const void *pixels, int w, int h, long stride_bytes, int fmt, f
         } else if (fmt == ORC_FMT_RGB8) {
             for (int x = 0; x < w; ++x)
                 o[x] = (float)rgb_to_luma_u8(row[3 * x], row[3 * x + 1], row[3 * x + 2]) / 255.0f;
+        } else if (fmt == ORC_FMT_LF32) {
+            memcpy(o, row, (size_t)w * sizeof(float));
         } else {
             return -1;
         }

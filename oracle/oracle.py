@@ -14,7 +14,7 @@ import numpy as np
 _HERE = Path(__file__).resolve().parent
 _LIB_PATH = _HERE / "liborc.so"
 
-FMT_L8, FMT_L16, FMT_RGB8 = 0, 1, 2
+FMT_L8, FMT_L16, FMT_RGB8, FMT_LF32 = 0, 1, 2, 3
 
 
 class Saddle(C.Structure):
@@ -120,6 +120,8 @@ def image_fmt(img):
         return a, FMT_L16, a.shape[1] * 2
     if a.ndim == 3 and a.shape[2] == 3 and a.dtype == np.uint8:
         return a, FMT_RGB8, a.shape[1] * 3
+    if a.ndim == 2 and a.dtype == np.float32:
+        return a, FMT_LF32, a.shape[1] * 4
     raise ValueError("unsupported image: shape %s dtype %s" % (a.shape, a.dtype))
 
 

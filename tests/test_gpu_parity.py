@@ -404,3 +404,84 @@ def test_full_size_batch_properties(det, oracle):
 def torch_flip(frames):
     import torch
     return torch.flip(frames, dims=[0]).contiguous()
+
+
+# ---- AGX_LF32: the caller's own to_luma32f plane (any DynamicImage variant) ---------------------
+def _luma_planes_like_image_crate(kind, base_u8, rng):
+    """(pixel array of the variant, f32 luma plane, u8 luma plane) for DynamicImage variants the ABI
+    does not take natively.  The plane arithmetic is what a Rust caller gets from img.to_luma32f() /
+    img.to_luma8(); it is restated here only to have realistic planes -- the library and the oracle
+    are both fed THE SAME planes, which is the point of AGX_LF32."""
+    h, w = base_u8.shape
+    if kind == "La8":  # luma + alpha: alpha dropped
+        px = np.stack([base_u8, rng.integers(0, 256, (h, w), dtype=np.uint8)], -1)
+        return px, (base_u8.astype(np.float32) / np.float32(255.0)), base_u8.copy()
+    if kind == "Rgba8":
+        rgb = np.stack([np.clip(base_u8.astype(np.int32) + d, 0, 255).astype(np.uint8) for d in (-2, 0, 3)], -1)
+        px = np.concatenate([rgb, rng.integers(0, 256, (h, w, 1), dtype=np.uint8)], -1)
+        r32 = rgb.astype(np.uint32)
+        l8 = ((2126 * r32[..., 0] + 7152 * r32[..., 1] + 722 * r32[..., 2]) // 10000).astype(np.uint8)
+        return px, (l8.astype(np.float32) / np.float32(255.0)), l8
+    if kind == "Rgb16":
+        v = base_u8.astype(np.uint32) * 257
+        rgb = np.stack([np.clip(v.astype(np.int64) + d, 0, 65535).astype(np.uint32) for d in (-300, 0, 500)], -1)
+        r64 = rgb.astype(np.uint64)
+        l16 = (2126 * r64[..., 0] + 7152 * r64[..., 1] + 722 * r64[..., 2]) // 10000
+        return rgb.astype(np.uint16), (l16.astype(np.float32) / np.float32(65535.0)), ((l16 + 128) // 257).astype(np.uint8)
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("kind", ["La8", "Rgba8", "Rgb16"])
+def test_lf32_planes_of_other_image_variants(det, oracle, kind):
+    """La8 / Rgba8 / Rgb16 images go through the chain as their f32 luma plane, bit
+    for bit like the oracle fed the same plane; detect_planes == oracle tail on (saddles, u8 luma)."""
+    synth = synth_module()
+    base = np.asarray(synth.render_frame(21, 640, 480)[0])
+    _, f32, l8 = _luma_planes_like_image_crate(kind, base, np.random.default_rng(3))
+    got = det.refined_saddle_points(f32, as_array=True)
+    ref = check_frame(det, oracle, f32, 0, kind + " as LF32")
+    check_saddles(got, ref, kind)
+    tags = det.detect_planes(f32, l8)
+    ref_tags = oracle.detect_tail(l8, ref)
+    assert sorted(tags) == sorted(ref_tags) and len(tags) >= 30
+    for t in tags:
+        assert bits_equal(tags[t], ref_tags[t])
+    import aprilgrid_rs_amd as A
+    with pytest.raises(A.AgxError) as e:
+        det.detect(f32)  # no u8 luma to derive from an f32 plane
+    assert e.value.status == -2
+
+
+def test_lf32_equals_the_fused_l8_path(det, oracle):
+    """v / 255 handed over as a plane gives exactly what the fused L8 conversion gives (two different
+    kernels instantiations: product-table path vs plain path), at an aligned and a ragged width, and
+    as a device batch."""
+    import torch
+    synth = synth_module()
+    for w in (640, 613):
+        img = np.ascontiguousarray(np.asarray(synth.render_frame(33, 640, 400)[0])[:, :w])
+        a = det.refined_saddle_points(img, as_array=True)
+        f32 = img.astype(np.float32) / np.float32(255.0)
+        b = det.refined_saddle_points(f32, as_array=True)
+        assert a.tobytes() == b.tobytes() and len(a) > 100
+        check_frame(det, oracle, f32, 0, "LF32 width %d" % w)
+    fr, _ = synth.render_batch(5, 3, 320, 240, device="cuda")
+    planes = (fr.to(torch.float32) / 255.0).contiguous()
+    det.saddles_batch_enqueue(planes)
+    res, status = det.saddles_batch_fetch()
+    assert (status == 0).all()
+    host = planes.cpu().numpy()
+    for i in range(3):
+        check_saddles(res[i], check_frame(det, oracle, host[i], i, "LF32 batch frame %d" % i), "LF32 batch %d" % i)
+
+
+def test_lf32_arbitrary_float_planes(det_resp, oracle):
+    """Planes that no integer image produces (tiny, subnormal, irregular values): the LF32 kernel
+    evaluates image_util.rs:100-104 literally, so even the in-register response is bit-exact."""
+    rng = np.random.default_rng(11)
+    a = rng.random((96, 132), dtype=np.float32)
+    a[10:20, 10:60] *= np.float32(1e-20)
+    a[30:40, 40:90] = np.float32(1e-41) * rng.integers(0, 50, (10, 50)).astype(np.float32)  # subnormals
+    a[50:60, :] = rng.random((10, 132), dtype=np.float32) * np.float32(3e-19)
+    got = det_resp.refined_saddle_points(a, as_array=True)
+    check_saddles(got, check_frame(det_resp, oracle, a, 0, "arbitrary f32 plane"), "arbitrary f32")
