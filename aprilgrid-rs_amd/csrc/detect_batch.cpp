@@ -1,0 +1,188 @@
+// detect_batch.cpp -- TagDetector::detect (reference src/detector.rs:505-540) over a batch of
+// frames: the saddle chain of a chunk of frames runs on the device while a pool of host threads
+// runs the board search + decode (detect's loop body, :510-539) of the previous chunk.  The host
+// tail is the reference's exhaustive search (several milliseconds per frame and thread), so the
+// end-to-end rate is set by the number of host threads; the pool keeps them busy and the device
+// work disappears behind them.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/aprilgrid_amd.h"
+#include "detector_internal.h"
+#include "host_tail.hpp"
+
+namespace agx {
+
+// A fixed set of worker threads with a task queue; wait() blocks until every submitted task is done.
+class WorkerPool {
+public:
+    explicit WorkerPool(int n)
+    {
+        for (int i = 0; i < n; ++i) threads_.emplace_back([this] { run(); });
+    }
+    ~WorkerPool()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (std::thread &t : threads_) t.join();
+    }
+    int size() const { return (int)threads_.size(); }
+    void submit(std::function<void()> f)
+    {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            q_.push_back(std::move(f));
+            ++pending_;
+        }
+        cv_.notify_one();
+    }
+    void wait()
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [this] { return pending_ == 0; });
+    }
+
+private:
+    void run()
+    {
+        for (;;) {
+            std::function<void()> f;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [this] { return stop_ || !q_.empty(); });
+                if (q_.empty()) return;  // stop_ and nothing left
+                f = std::move(q_.front());
+                q_.pop_front();
+            }
+            f();
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                if (--pending_ == 0) done_.notify_all();
+            }
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::deque<std::function<void()>> q_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    size_t pending_ = 0;
+    bool stop_ = false;
+};
+
+void destroy_worker_pool(void *p) { delete static_cast<WorkerPool *>(p); }
+void *create_worker_pool(int n_threads) { return new WorkerPool(n_threads); }
+
+}  // namespace agx
+
+using namespace agx;
+
+extern "C" int agx_detect_batch(agx_detector *det, const void *frames, const void *d_frames, int n_frames, int width,
+                                int height, size_t row_stride_bytes, size_t frame_stride_bytes, int format, agx_tag *out,
+                                uint32_t cap_per_frame, uint32_t *counts, int *frame_status, int n_threads)
+{
+    if (!det || !frames || !counts || n_frames <= 0 || (!out && cap_per_frame)) return AGX_ERR_ARG;
+    if (format != AGX_L8 && format != AGX_L16 && format != AGX_RGB8) return AGX_ERR_FORMAT;  // the tail derives to_luma8 itself
+    if (width < 2 || height < 2) return AGX_ERR_ARG;
+    const size_t bpp = format == AGX_L8 ? 1 : (format == AGX_L16 ? 2 : 3);
+    if (row_stride_bytes < (size_t)width * bpp || (n_frames > 1 && frame_stride_bytes < row_stride_bytes * (size_t)height)) return AGX_ERR_ARG;
+    if (n_threads <= 0) n_threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 64u);
+    WorkerPool *pool = static_cast<WorkerPool *>(agx_internal_pool(det, n_threads));
+    if (!pool) return AGX_ERR_ARG;
+    const FamilyInfo *fam = static_cast<const FamilyInfo *>(agx_internal_family(det));
+    const int max_boards = agx_internal_max_boards(det);
+    hipStream_t st = (hipStream_t)agx_internal_stream(det);
+    if (hipSetDevice(agx_internal_device(det)) != hipSuccess) return AGX_ERR_HIP;
+
+    // chunks: large enough that the chain runs at batch efficiency, small enough that the pool has
+    // work while the next chunk is uploaded and processed
+    const int chunk = std::max(1, std::min(n_frames, std::max(2 * pool->size(), 32)));
+    const size_t chunk_bytes = (size_t)chunk * frame_stride_bytes;
+    uint8_t *d_stage = nullptr;
+    if (!d_frames) {
+        d_stage = static_cast<uint8_t *>(agx_internal_stage(det, 2 * chunk_bytes));  // double-buffered upload
+        if (!d_stage) return AGX_ERR_HIP;
+    }
+    std::vector<std::vector<agx_saddle>> saddles(2);  // per chunk parity: [chunk frames][cap]
+    std::vector<std::vector<uint32_t>> ns(2);
+    std::vector<std::vector<int>> fst(2);
+    const uint32_t cap_s = 16384;
+    std::atomic<int> first_bad{AGX_OK};
+    int rc = AGX_OK;
+    for (int c0 = 0, ci = 0; c0 < n_frames; c0 += chunk, ++ci) {
+        const int nf = std::min(chunk, n_frames - c0);
+        const int par = ci & 1;
+        const uint8_t *h_chunk = (const uint8_t *)frames + (size_t)c0 * frame_stride_bytes;
+        const void *d_chunk;
+        if (d_frames) {
+            d_chunk = (const uint8_t *)d_frames + (size_t)c0 * frame_stride_bytes;
+        } else {
+            uint8_t *dst = d_stage + (size_t)par * chunk_bytes;
+            if (hipMemcpyAsync(dst, h_chunk, (size_t)nf * frame_stride_bytes, hipMemcpyHostToDevice, st) != hipSuccess) { rc = AGX_ERR_HIP; break; }
+            d_chunk = dst;
+        }
+        rc = agx_saddles_batch_enqueue(det, d_chunk, nf, width, height, row_stride_bytes, frame_stride_bytes, format);
+        if (rc) break;
+        // the tails of the chunk two back read saddles[par]: they must be done before it is refilled
+        if (ci >= 2) pool->wait();
+        saddles[par].resize((size_t)nf * cap_s);
+        ns[par].assign(nf, 0);
+        fst[par].assign(nf, 0);
+        rc = agx_saddles_batch_fetch(det, saddles[par].data(), cap_s, ns[par].data(), fst[par].data());  // waits for the device
+        if (rc && rc != AGX_ERR_CAPACITY) break;
+        rc = AGX_OK;
+        for (int f = 0; f < nf; ++f) {
+            const int gf = c0 + f;
+            if (fst[par][f] != AGX_OK) {  // reported, never truncated
+                counts[gf] = 0;
+                if (frame_status) frame_status[gf] = fst[par][f];
+                int exp = AGX_OK;
+                first_bad.compare_exchange_strong(exp, fst[par][f]);
+                continue;
+            }
+            const agx_saddle *sp = saddles[par].data() + (size_t)f * cap_s;
+            const uint32_t n_s = ns[par][f];
+            const uint8_t *img = h_chunk + (size_t)f * frame_stride_bytes;
+            pool->submit([=, &first_bad] {
+                // detector.rs:507: u8 luma for the decode (a copy for L8 too: the tail reads rows at a tight pitch)
+                std::vector<uint8_t> grey;
+                const uint8_t *g = img;
+                size_t gstride = row_stride_bytes;
+                if (format != AGX_L8) {
+                    grey.resize((size_t)width * height);
+                    luma8(img, width, height, row_stride_bytes, format, grey.data());
+                    g = grey.data();
+                    gstride = (size_t)width;
+                }
+                std::vector<agx_tag> tags;
+                detect_tail(*fam, max_boards, std::vector<agx_saddle>(sp, sp + n_s), g, width, height, gstride, tags);
+                int stf = AGX_OK;
+                if (tags.size() > cap_per_frame) {
+                    stf = AGX_ERR_CAPACITY;
+                    int exp = AGX_OK;
+                    first_bad.compare_exchange_strong(exp, stf);
+                    counts[gf] = (uint32_t)tags.size();
+                } else {
+                    counts[gf] = (uint32_t)tags.size();
+                    if (!tags.empty()) std::memcpy(out + (size_t)gf * cap_per_frame, tags.data(), tags.size() * sizeof(agx_tag));
+                }
+                if (frame_status) frame_status[gf] = stf;
+            });
+        }
+    }
+    pool->wait();
+    if (rc) return rc;
+    return first_bad.load();
+}

@@ -77,6 +77,8 @@ struct agx_detector {
     double prof_ms[K_COUNT]{};
     uint64_t prof_launches[K_COUNT]{};
 
+    void *pool = nullptr;  // agx_detect_batch: worker threads of the host tail
+    int pool_threads = 0;
     std::vector<agx_saddle> scratch_saddles;  // host staging of agx_detect / agx_detect_planes (reused)
     std::vector<uint8_t> scratch_grey;
 
@@ -378,6 +380,33 @@ int agx_abi_version(void) { return AGX_ABI_VERSION; }
 
 __attribute__((visibility("hidden"))) void *agx_internal_stream(agx_detector *det) { return det ? (void *)det->stream : nullptr; }
 __attribute__((visibility("hidden"))) int agx_internal_device(const agx_detector *det) { return det ? det->device : -1; }
+__attribute__((visibility("hidden"))) void *agx_internal_pool(agx_detector *det, int n_threads)
+{
+    if (!det || n_threads < 1) return nullptr;
+    if (det->pool && det->pool_threads != n_threads) {
+        destroy_worker_pool(det->pool);
+        det->pool = nullptr;
+    }
+    if (!det->pool) {
+        det->pool = create_worker_pool(n_threads);
+        det->pool_threads = n_threads;
+    }
+    return det->pool;
+}
+__attribute__((visibility("hidden"))) const void *agx_internal_family(const agx_detector *det) { return &det->fam; }
+__attribute__((visibility("hidden"))) int agx_internal_max_boards(const agx_detector *det) { return det->params.max_num_of_boards; }
+__attribute__((visibility("hidden"))) void *agx_internal_stage(agx_detector *det, size_t bytes)
+{
+    if (bytes > det->stage_bytes) {
+        if (hipSetDevice(det->device) != hipSuccess || hipStreamSynchronize(det->stream) != hipSuccess) return nullptr;
+        if (det->d_stage) (void)hipFree(det->d_stage);
+        det->d_stage = nullptr;
+        det->stage_bytes = 0;
+        if (hipMalloc((void **)&det->d_stage, bytes) != hipSuccess) return nullptr;
+        det->stage_bytes = bytes;
+    }
+    return det->d_stage;
+}
 
 const char *agx_status_string(int status)
 {
@@ -481,6 +510,7 @@ void agx_detector_destroy(agx_detector *det)
     harvest_events(det);
     for (hipEvent_t e : det->free_events) (void)hipEventDestroy(e);
     free_workspace(det);
+    if (det->pool) destroy_worker_pool(det->pool);
     if (det->d_stage) (void)hipFree(det->d_stage);
     if (det->d_dbg_resp) (void)hipFree(det->d_dbg_resp);
     if (det->d_resp_store) (void)hipFree(det->d_resp_store);

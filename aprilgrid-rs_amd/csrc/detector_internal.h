@@ -7,4 +7,15 @@ extern "C" {
 // agx_detector_set_stream) and its device ordinal.
 void *agx_internal_stream(agx_detector *det);
 int agx_internal_device(const agx_detector *det);
+// agx_detect_batch: the detector's worker pool (created on first use, resized when n_threads
+// changes), its family table (agx::FamilyInfo), max_num_of_boards and a device staging buffer of
+// at least `bytes` (grown on demand).
+void *agx_internal_pool(agx_detector *det, int n_threads);
+const void *agx_internal_family(const agx_detector *det);
+int agx_internal_max_boards(const agx_detector *det);
+void *agx_internal_stage(agx_detector *det, size_t bytes);
+}
+namespace agx {
+void destroy_worker_pool(void *pool);
+void *create_worker_pool(int n_threads);
 }

@@ -163,6 +163,24 @@ class TagDetector:
                                                 C.byref(n)))
         return {int(out[i].id): np.array(out[i].xy, np.float32).reshape(4, 2) for i in range(n.value)}
 
+    def detect_batch(self, frames, n_threads=0, cap=1024, device_frames=None):
+        """detect() over a batch: frames = numpy [N,H,W] uint8 / uint16 or [N,H,W,3] uint8 in host
+        memory (optionally also resident on the GPU as the torch tensor device_frames).  The chain
+        runs on the device chunk by chunk while n_threads host threads (0 = all cores, <= 64) run the
+        board search + decode.  -> list of {tag_id: 4x2 corners}."""
+        a = np.ascontiguousarray(frames)
+        _, fmt, stride = _image_args(a[0])
+        if fmt == _ffi.AGX_LF32:
+            raise AgxError(_ffi.AGX_ERR_FORMAT, "detect_batch takes L8 / L16 / RGB8 frames")
+        n, h, w = a.shape[:3]
+        out = np.zeros((n, cap), np.dtype([("id", "u4"), ("xy", "f4", (8,))]))
+        counts = np.zeros(n, np.uint32)
+        status = np.zeros(n, np.int32)
+        dptr = device_frames.data_ptr() if device_frames is not None else None
+        self._check(self._lib.agx_detect_batch(self._h, a.ctypes.data, dptr, n, w, h, stride, stride * h, fmt,
+                                               out.ctypes.data, cap, counts.ctypes.data, status.ctypes.data, n_threads))
+        return [{int(t["id"]): t["xy"].reshape(4, 2).copy() for t in out[i, : counts[i]]} for i in range(n)]
+
     def detect_kornia(self, img):
         """kornia::image::Image<u8, N>: an HxWxN uint8 array, N in {1, 3} (else the reference
         panics 'Only support u8c1 and u8c3')."""

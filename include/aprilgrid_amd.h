@@ -200,6 +200,18 @@ int agx_saddles_batch_enqueue_to(agx_detector *det, const void *d_frames, int n_
 /* Block until everything enqueued on the detector's stream has finished. */
 int agx_detector_sync(agx_detector *det);
 
+/* TagDetector::detect (src/detector.rs:505-540) over a batch of equally sized frames in HOST memory
+ * (frame i at frames + i*frame_stride_bytes; formats AGX_L8 / AGX_L16 / AGX_RGB8).  The saddle
+ * chain of a chunk of frames runs on the device while n_threads host threads (0 = one per host
+ * core, at most 64; the pool lives as long as the detector) run the board search + decode of the
+ * previous chunk.  d_frames: optional device copy of the same frames (skips the upload), else
+ * NULL.  out: n_frames * cap_per_frame tags, frame i at out + i*cap_per_frame; counts[i] = tags of
+ * frame i; frame_status[i] (may be NULL) = AGX_OK or AGX_ERR_CAPACITY.  Returns the first non-OK
+ * frame status, else AGX_OK. */
+int agx_detect_batch(agx_detector *det, const void *frames, const void *d_frames, int n_frames, int width,
+                     int height, size_t row_stride_bytes, size_t frame_stride_bytes, int format, agx_tag *out,
+                     uint32_t cap_per_frame, uint32_t *counts, int *frame_status, int n_threads);
+
 /* ---- detector groups: several GPUs of one node driven from ONE process ----------------- */
 
 /* The reference's detect(&self) is stateless, so a batch shards by frame:

@@ -485,3 +485,27 @@ def test_lf32_arbitrary_float_planes(det_resp, oracle):
     a[50:60, :] = rng.random((10, 132), dtype=np.float32) * np.float32(3e-19)
     got = det_resp.refined_saddle_points(a, as_array=True)
     check_saddles(got, check_frame(det_resp, oracle, a, 0, "arbitrary f32 plane"), "arbitrary f32")
+
+
+@pytest.mark.parametrize("fmt", ["L8", "L16", "RGB8"])
+def test_detect_batch_equals_per_frame_detect(det, oracle, fmt):
+    """agx_detect_batch (chain per chunk on the device, board search + decode on a pool of host
+    threads): every frame's tag map equals detect() of that frame and the oracle's, with the frames
+    uploaded by the call and with a device copy handed in; a second call reuses the pool."""
+    synth = synth_module()
+    n = 70  # more than one chunk with 4 threads (chunk = 32 frames)
+    fr, gts = synth.render_batch(300, n, 320, 240, device="cuda", fmt=fmt)
+    host = fr.cpu().numpy()
+    if fmt == "L16":
+        host = host.view(np.uint16)
+    got = det.detect_batch(host, n_threads=4)
+    got_dev = det.detect_batch(host, n_threads=4, device_frames=fr)
+    assert len(got) == n
+    n_tags = 0
+    for i in range(n):
+        one = det.detect(host[i]) if i % 7 == 0 else oracle.detect(host[i])
+        assert sorted(got[i]) == sorted(one) == sorted(got_dev[i]), "frame %d" % i
+        for t in one:
+            assert bits_equal(got[i][t], one[t]) and bits_equal(got_dev[i][t], one[t])
+        n_tags += len(one)
+    assert n_tags > 20 * n
