@@ -71,6 +71,10 @@ def parse_args():
     ap.add_argument("--settle-ms", type=float, default=300.0,
                     help="untimed: keep the chain running about this long before the W warm-up steps so that workspace "
                          "allocation is done and the GPU clocks have ramped (0 = off)")
+    ap.add_argument("--images", action="store_true",
+                    help="instead of the batch benchmark: the reference's own bench shape (benches/bench_detection.rs, "
+                         "benches/bench_blur.rs) on its 7 / 3 fixture images, GPU path next to the CPU oracle "
+                         "(tools/bench_images.py)")
     ap.add_argument("--pmc-traffic", type=float, default=None,
                     help="HBM bytes per K1 launch from a separate rocprofv3 --pmc run (profiles/)")
     return ap.parse_args()
@@ -253,6 +257,10 @@ def extra_leg(torch, A, dev, name, workload, n_frames, width, height, fmt, uniqu
 
 def main():
     args = parse_args()
+    if args.images:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_images
+        return bench_images.main([])
     import numpy as np
     import torch
     import torch.distributed as dist

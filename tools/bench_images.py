@@ -1,0 +1,118 @@
+#!/usr/bin/env python3
+"""The reference's own bench shape on its own inputs, GPU path next to the CPU
+oracle in one run:
+
+  detection   benches/bench_detection.rs:7-36 -- the 7 images, decode OUTSIDE the timed region, time
+              TagDetector::detect only: here det.detect(img) through the host API (PCIe upload, chain
+              on the MI355X, saddles back, board search + decode on one host thread) vs the C oracle's
+              detect (oracle/agx_oracle.c -O3 -march=native, 1 thread), median of >= 10 runs each.
+  blur        benches/bench_blur.rs:20-46 -- the 3 images, img.to_luma32f() OUTSIDE the timed region,
+              time gaussian_blur_f32(&luma, 1.5) only: here the blur kernel on the f32 plane resident in
+              HBM (AGX_LF32; hipEvents around K1 -- K1 also evaluates the Hessian response, the running
+              minimum and the candidate mask, a "blur only" ablation build of it is timed beside it) vs
+              the oracle's gaussian_blur_f32, single frame and a batch of 64 copies.
+
+    python tools/bench_images.py [--runs 15] > profiles/r2_bench_images.json
+(needs tests/golden/images, i.e. the reference's fixture PNGs; prints ONE JSON object.)
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+DETECTION = ["iphone.png", "EuRoC.png", "TUM_VI.png", "right.png", "r45.png", "top.png", "two_boards.png"]
+BLUR = ["iphone.png", "EuRoC.png", "TUM_VI.png"]
+
+
+def median_ms(fn, runs):
+    fn()
+    ts = []
+    for _ in range(runs):
+        t0 = time.perf_counter()
+        fn()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    return round(statistics.median(ts), 4)
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--runs", type=int, default=15)
+    args = ap.parse_args(argv)
+    import numpy as np
+    import torch
+    import aprilgrid_rs_amd as A
+    from oracle import oracle as O
+    from tests.util import load_image
+    O.build()
+    native = C.CDLL(os.path.join(ROOT, "oracle", "liborc_native.so"))
+    native.orc_detect.argtypes = O.lib().orc_detect.argtypes
+    native.orc_gaussian_blur_f32.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p]
+    det = A.TagDetector("t36h11", None, device=0)
+    prm = O.default_params()
+    edge, border, hamming, _ = O.FAMILIES["T36H11"]
+    codes = O.family_codes("T36H11")
+    out = {"runs": args.runs, "cpu": "oracle/agx_oracle.c -O3 -march=native -ffp-contract=off, 1 thread (kind: port)",
+           "detection": {}, "blur": {}}
+    for name in DETECTION:
+        img = load_image(name)
+        a, fmt, stride = O.image_fmt(img)
+        h, w = a.shape[:2]
+        tags_buf = (O.Tag * 1024)()
+
+        def cpu():
+            return native.orc_detect(a.ctypes.data, w, h, stride, fmt, C.addressof(prm), border, edge, hamming,
+                                     codes.ctypes.data, len(codes), tags_buf, 1024)
+        n_cpu = cpu()
+        n_gpu = len(det.detect(img))
+        assert n_cpu == n_gpu, (name, n_cpu, n_gpu)
+        g_chain = median_ms(lambda: det.refined_saddle_points(img, as_array=True), args.runs)
+        g = median_ms(lambda: det.detect(img), args.runs)
+        c = median_ms(cpu, max(10, args.runs // 2))
+        out["detection"][name] = {"size": "%dx%d" % (w, h), "format": {0: "L8", 1: "L16", 2: "RGB8"}[fmt], "tags": n_gpu,
+                                  "gpu_detect_ms": g, "gpu_saddle_chain_ms_incl_pcie": g_chain, "cpu_detect_ms": c,
+                                  "speedup": round(c / g, 2)}
+    for name in BLUR:
+        img = load_image(name)
+        luma = O.luma_f32(img)  # to_luma32f, outside the timed region
+        h, w = luma.shape
+        blur_out = np.empty_like(luma)
+        c = median_ms(lambda: native.orc_gaussian_blur_f32(luma.ctypes.data, w, h, 1.5, blur_out.ctypes.data), args.runs)
+        row = {"size": "%dx%d" % (w, h), "cpu_gaussian_blur_f32_ms": c}
+        for label, nb in (("single_frame", 1), ("batch_64", 64)):
+            planes = torch.from_numpy(luma).cuda()[None].repeat(nb, 1, 1).contiguous()
+            for mode, dbg in (("k1_fused", 0), ("k1_blur_only_ablation", 4)):
+                det.set_option("debug_ablation", dbg)
+                for _ in range(3):
+                    det.saddles_batch_enqueue(planes)
+                det.sync()
+                det.profile_enable(1)
+                det.profile_reset()
+                for _ in range(args.runs):
+                    det.saddles_batch_enqueue(planes)
+                ms, n = det.profile_read()["k_blur_hessian"]
+                det.profile_enable(0)
+                row["gpu_%s_%s_ms_per_frame" % (mode, label)] = round(ms / n / nb, 5)
+            det.set_option("debug_ablation", 0)
+            if nb == 1:  # the timed kernel's blur plane is the oracle's, bit for bit
+                det.saddles_batch_enqueue(planes)
+                det.sync()
+                got = det.debug_fetch(0, "blur", (h, w))
+                native.orc_gaussian_blur_f32(luma.ctypes.data, w, h, 1.5, blur_out.ctypes.data)
+                assert np.array_equal(got.view(np.uint32), blur_out.view(np.uint32)), name
+                row["blur_plane_bit_exact"] = True
+        row["speedup_single_frame_fused"] = round(c / row["gpu_k1_fused_single_frame_ms_per_frame"], 1)
+        row["speedup_batch_64_fused"] = round(c / row["gpu_k1_fused_batch_64_ms_per_frame"], 1)
+        out["blur"][name] = row
+    det.close()
+    print(json.dumps(out, indent=1))
+    return out
+
+
+if __name__ == "__main__":
+    main()
