@@ -1451,7 +1451,9 @@ __device__ __forceinline__ void filter_sort_emit(const ChainArgs &a, int frame, 
         }
         __syncthreads();
         nf = *s_count;
-        ok = nf <= a.cap_out && nf <= lds_entries;
+        uint32_t need = 1;
+        while (need < nf) need <<= 1;  // the bitonic network pads to a power of two
+        ok = nf <= a.cap_out && need <= lds_entries;
     }
     if (ok && nf) {
         uint32_t np2 = 1;
@@ -1663,7 +1665,17 @@ __global__ void __launch_bounds__(1024) k_rare(ChainArgs a, RefineConsts rc, uin
     }
     const uint32_t n_ref = __hip_atomic_load(&ctr.n_refined, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const uint32_t maxk = __hip_atomic_load(&ctr.max_k_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    filter_sort_emit(a, frame, n_ref, maxk, lds_u, lds_u + lds_entries, lds_entries, &s_count, &s_offset, &s_fits);
+    if (n_ref <= lds_entries) {
+        filter_sort_emit(a, frame, n_ref, maxk, lds_u, lds_u + lds_entries, lds_entries, &s_count, &s_offset, &s_fits);
+    } else {
+        // Lists beyond the LDS sort (pure-noise frames of several megapixels; the reference's Vec has no
+        // limit): the same filter + bitonic network on two per-frame arrays in global memory that are
+        // free by now (the flood seeds and the generic path's root list, cap_roots words each).  All
+        // accesses come from this workgroup, i.e. one CU and its write-through L1, so the barriers
+        // between the passes order them.
+        filter_sort_emit(a, frame, n_ref, maxk, a.seeds + (size_t)frame * a.cap_roots, a.roots + (size_t)frame * a.cap_roots,
+                         a.cap_roots, &s_count, &s_offset, &s_fits);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1707,7 +1719,7 @@ bool plan_k1(ChainArgs &a, int override_rows_per_seg)
 size_t k5_lds_bytes(const ChainArgs &a)
 {
     uint32_t e = 1;
-    while (e < a.cap_out) e <<= 1;
+    while (e < a.cap_out && e < 16384u) e <<= 1;  // 16384 entries = 128 KB of the CU's 160 KB; longer lists sort in global memory
     return (size_t)e * 8;
 }
 

@@ -222,7 +222,7 @@ int ensure_workspace(agx_detector *d, int n_frames, int W, int H)
     const long long plane = (long long)W * H;
     const uint32_t cap_cand = d->lim_cand ? d->lim_cand : clamp_u32((unsigned long long)plane / 2, 4096, 1u << 28);
     const uint32_t cap_roots = d->lim_roots ? d->lim_roots : clamp_u32((unsigned long long)plane / 8, 1024, 1u << 26);
-    const uint32_t cap_out = d->lim_out ? d->lim_out : clamp_u32((unsigned long long)plane / 64, 256, 16384);
+    const uint32_t cap_out = d->lim_out ? d->lim_out : clamp_u32((unsigned long long)plane / 64, 256, 1u << 24);
     ChainArgs &a = d->args;
     const bool fits = (size_t)n_frames <= d->cap_frames && plane <= d->cap_plane && cap_cand <= d->alloc_cand &&
                       cap_roots <= d->alloc_roots && cap_out <= d->alloc_out &&
@@ -533,7 +533,7 @@ int agx_detector_family_info(const agx_detector *det, int *edge_bits, int *borde
 int agx_detector_set_limits(agx_detector *det, uint32_t max_candidates, uint32_t max_clusters, uint32_t max_saddles)
 {
     if (!det) return AGX_ERR_ARG;
-    if (max_candidates >= (1u << 30) || max_saddles > 16384) return AGX_ERR_ARG;
+    if (max_candidates >= (1u << 30) || max_saddles > (1u << 24)) return AGX_ERR_ARG;
     det->lim_cand = max_candidates;
     det->lim_roots = max_clusters;
     det->lim_out = max_saddles;
@@ -708,8 +708,9 @@ int agx_saddles_batch_fetch(agx_detector *det, agx_saddle *out, uint32_t cap_per
             }
             continue;
         }
-        std::memcpy(out + f * (size_t)cap_per_frame, det->h_out + (size_t)c.out_offset * 5,
-                    (size_t)c.n_out * sizeof(agx_saddle));
+        if (c.n_out)
+            std::memcpy(out + f * (size_t)cap_per_frame, det->h_out + (size_t)c.out_offset * 5,
+                        (size_t)c.n_out * sizeof(agx_saddle));
     }
     return first_bad;
 }
@@ -747,6 +748,18 @@ int agx_refined_saddle_points(agx_detector *det, const void *pixels, int width, 
     if (c.flags & (FLAG_CAND_OVERFLOW | FLAG_ROOT_OVERFLOW | FLAG_OUT_OVERFLOW)) return AGX_ERR_CAPACITY;  // last_error set by fetch
     *n_out = c.n_out;
     if (c.n_out > cap) return fail(det, AGX_ERR_CAPACITY, "output capacity too small");
+    if (c.n_out) std::memcpy(out, det->h_out + (size_t)c.out_offset * 5, (size_t)c.n_out * sizeof(agx_saddle));
+    det->last_error.clear();
+    return AGX_OK;
+}
+
+// The single frame of the last agx_refined_saddle_points call again, into a larger buffer (its
+// list is still in the pinned host mirror).
+static int refetch_single(agx_detector *det, agx_saddle *out, uint32_t cap, uint32_t *n_out)
+{
+    const FrameCounters &c = det->h_ctr[0];
+    *n_out = c.n_out;
+    if (c.n_out > cap) return AGX_ERR_CAPACITY;
     if (c.n_out) std::memcpy(out, det->h_out + (size_t)c.out_offset * 5, (size_t)c.n_out * sizeof(agx_saddle));
     det->last_error.clear();
     return AGX_OK;
@@ -805,10 +818,14 @@ int agx_detect(agx_detector *det, const void *pixels, int width, int height, siz
     int rc = luma8(pixels, width, height, row_stride_bytes, format, grey.data());
     if (rc) return rc;
     std::vector<agx_saddle> &saddles = det->scratch_saddles;
-    saddles.resize(16384);
+    if (saddles.size() < 16384) saddles.resize(16384);
     uint32_t ns = 0;
     rc = agx_refined_saddle_points(det, pixels, width, height, row_stride_bytes, format, saddles.data(),
                                    (uint32_t)saddles.size(), &ns);
+    if (rc == AGX_ERR_CAPACITY && ns > saddles.size()) {  // longer list than ever before: the batch is still fetchable
+        saddles.resize(ns);
+        rc = refetch_single(det, saddles.data(), (uint32_t)saddles.size(), &ns);
+    }
     if (rc) return rc;
     return agx_detect_from_saddles(det, saddles.data(), ns, grey.data(), width, height, (size_t)width, out, cap,
                                    n_out);
@@ -821,10 +838,14 @@ int agx_detect_planes(agx_detector *det, const float *luma32f, size_t stride32f_
     if (width < 2 || height < 2) return fail(det, AGX_ERR_ARG, "width and height must be >= 2");
     if (stride8_bytes < (size_t)width) return fail(det, AGX_ERR_ARG, "row stride smaller than a row");
     std::vector<agx_saddle> &saddles = det->scratch_saddles;
-    saddles.resize(16384);
+    if (saddles.size() < 16384) saddles.resize(16384);
     uint32_t ns = 0;
     int rc = agx_refined_saddle_points(det, luma32f, width, height, stride32f_bytes, AGX_LF32, saddles.data(),
                                        (uint32_t)saddles.size(), &ns);
+    if (rc == AGX_ERR_CAPACITY && ns > saddles.size()) {  // longer list than ever before: the batch is still fetchable
+        saddles.resize(ns);
+        rc = refetch_single(det, saddles.data(), (uint32_t)saddles.size(), &ns);
+    }
     if (rc) return rc;
     return agx_detect_from_saddles(det, saddles.data(), ns, luma8, width, height, stride8_bytes, out, cap, n_out);
 }

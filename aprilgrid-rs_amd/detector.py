@@ -133,8 +133,14 @@ class TagDetector:
         h, w = a.shape[:2]
         out = np.zeros(cap, SADDLE_DTYPE)
         n = C.c_uint32(0)
-        self._check(self._lib.agx_refined_saddle_points(self._h, a.ctypes.data, w, h, stride, fmt, out.ctypes.data,
-                                                        cap, C.byref(n)))
+        st = self._lib.agx_refined_saddle_points(self._h, a.ctypes.data, w, h, stride, fmt, out.ctypes.data, cap,
+                                                 C.byref(n))
+        if st == _ffi.AGX_ERR_CAPACITY and n.value > cap:  # the reference's Vec has no limit: retry with room
+            cap = int(n.value)
+            out = np.zeros(cap, SADDLE_DTYPE)
+            st = self._lib.agx_refined_saddle_points(self._h, a.ctypes.data, w, h, stride, fmt, out.ctypes.data, cap,
+                                                     C.byref(n))
+        self._check(st)
         res = out[: n.value].copy()
         if as_array:
             return res
@@ -299,11 +305,18 @@ class TagDetector:
                                                         fmt))
         self._batch = (n, None)
 
-    def saddles_batch_fetch(self, cap_per_frame=16384, raise_on_overflow=True):
-        """-> (list of SADDLE_DTYPE arrays, one per frame; per-frame status array)."""
+    def saddles_batch_fetch(self, cap_per_frame=None, raise_on_overflow=True):
+        """-> (list of SADDLE_DTYPE arrays, one per frame; per-frame status array).  cap_per_frame None:
+        sized from the batch's longest list."""
         if self._batch is None:
             raise AgxError(_ffi.AGX_ERR_STATE, "no batch enqueued")
         n = self._batch[0]
+        if cap_per_frame is None:
+            counts = np.zeros(n, np.uint32)
+            st = self._lib.agx_saddles_batch_fetch(self._h, None, 0, counts.ctypes.data, None)  # counts only
+            if st not in (_ffi.AGX_OK, _ffi.AGX_ERR_CAPACITY):
+                self._check(st)
+            cap_per_frame = max(1, int(counts.max()))
         out = np.zeros((n, cap_per_frame), SADDLE_DTYPE)
         counts = np.zeros(n, np.uint32)
         status = np.zeros(n, np.int32)

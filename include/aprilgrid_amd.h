@@ -103,7 +103,8 @@ int agx_detector_family_info(const agx_detector *det, int *edge_bits, int *borde
                              int *hamming_distance, const uint64_t **codes, int *n_codes);
 
 /* Internal list capacities per frame (0 = keep default).  Defaults scale with the frame:
- * candidates W*H/2, clusters W*H/8, saddles min(W*H/64, 16384) (also the largest max_saddles).
+ * candidates W*H/2, clusters W*H/8, saddles W*H/64 (lists of up to 16384 saddles are ordered in
+ * LDS, longer ones -- pure-noise frames of several megapixels -- in global memory).
  * Overflow of any of them
  * is reported as AGX_ERR_CAPACITY for that frame, never truncated. */
 int agx_detector_set_limits(agx_detector *det, uint32_t max_candidates, uint32_t max_clusters,

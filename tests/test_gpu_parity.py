@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from tests.util import (ALL_IMAGES, ANGLE_TOL_DEG, REFERENCE_TAG_COUNTS, bits_equal, check_frame, check_saddles, load_image,
-                        synth_module)
+                        oracle_saddles_parallel, synth_module)
 
 pytestmark = pytest.mark.gpu
 
@@ -509,3 +509,36 @@ def test_detect_batch_equals_per_frame_detect(det, oracle, fmt):
             assert bits_equal(got[i][t], one[t]) and bits_equal(got_dev[i][t], one[t])
         n_tags += len(one)
     assert n_tags > 20 * n
+
+
+def test_more_than_16384_saddles_per_frame(det, oracle):
+    """the reference's Vec<Saddle> has no size limit.  Pure-noise frames of a few
+    megapixels hold more saddles than the LDS sort takes (16384): they are ordered in global memory
+    and come back complete, through the batch API and the single-frame API, equal to the oracle."""
+    synth = synth_module()
+    frames, _ = synth.render_batch(3, 2, 2048, 1536, device="cuda", pure_noise=True)
+    det.saddles_batch_enqueue(frames)
+    res, status = det.saddles_batch_fetch()
+    assert (status == 0).all()
+    host = frames.cpu().numpy()
+    refs = oracle_saddles_parallel(oracle, host, threads=2)
+    for i in range(2):
+        assert len(refs[i]) > 16384, len(refs[i])
+        check_saddles(res[i], refs[i], "noise 2048x1536 frame %d" % i)
+        c = det.debug_fetch(i, "counters")
+        assert c["flags"] & 64, c  # emitted by the large-list path
+    one = det.refined_saddle_points(host[1], as_array=True)
+    check_saddles(one, refs[1], "single-frame API")
+    assert det.detect(host[0]) == {}  # no board in noise; the tail runs on > 16384 saddles without overflow
+
+
+def test_4k_pure_noise_frame(det, oracle):
+    """A 3840x2160 pure-noise frame (about 57 000 saddles): what round 1 reported as AGX_ERR_CAPACITY."""
+    synth = synth_module()
+    frames, _ = synth.render_batch(8, 1, 3840, 2160, device="cuda", pure_noise=True)
+    det.saddles_batch_enqueue(frames)
+    res, status = det.saddles_batch_fetch()
+    assert (status == 0).all()
+    ref = oracle.refined_saddle_points(frames[0].cpu().numpy(), cap=1 << 18)
+    assert len(ref) > 40000
+    check_saddles(res[0], ref, "4K noise")
