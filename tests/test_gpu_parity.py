@@ -135,7 +135,7 @@ def test_degenerate_and_bad_arguments(det):
         det.refined_saddle_points(np.zeros((1, 40), np.uint8))  # reference: height()-1 underflow panic
     assert e.value.status == -1
     with pytest.raises(A.AgxError) as e:
-        det.refined_saddle_points(np.zeros((8, 8), np.float32))
+        det.refined_saddle_points(np.zeros((8, 8), np.float64))
     assert e.value.status == -2
 
 
