@@ -149,6 +149,23 @@ def _build_c_client(tmp_path):
     return exe
 
 
+def _build_c_group_client(tmp_path):
+    """examples/c_group_client.c: the detector groups of the ABI from plain C (uses the HIP runtime
+    only to place the frames on the devices, as a Rust host would)."""
+    import subprocess
+    exe = str(tmp_path / "c_group_client")
+    pkg = os.path.join(ROOT, "aprilgrid-rs_amd")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-Wno-unused-function", "-D__HIP_PLATFORM_AMD__",
+                    "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+                    os.path.join(ROOT, "examples", "c_group_client.c"), "-L", pkg, "-laprilgrid_amd", "-L", "/opt/rocm/lib",
+                    "-lamdhip64", "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True)
+    return exe
+
+
+def test_c_group_client_builds(tmp_path):
+    assert os.path.exists(_build_c_group_client(tmp_path))
+
+
 def test_c_client_builds_and_fails_loudly_without_a_device(tmp_path):
     import subprocess
     import numpy as np

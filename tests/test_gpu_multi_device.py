@@ -124,3 +124,26 @@ def test_group_rccl_transport(oracle):
     grp.close()
     with pytest.raises(A.AgxError):
         A.DetectorGroup("t36h11", [0, 0], transport="rccl")  # duplicate devices: refused, not hung
+
+
+def test_plain_c_group_client(oracle, tmp_path):
+    """examples/c_group_client.c -- no Python / torch in that process: 3 ranks round-robin over the
+    visible devices with the peer-copy gather, and one rank per device with the RCCL gather; the
+    per-frame saddle counts it prints equal the oracle's."""
+    import subprocess
+    import torch
+    from tests.test_abi_cpu import _build_c_group_client
+    synth = synth_module()
+    exe = _build_c_group_client(tmp_path)
+    n_dev = torch.cuda.device_count()
+    for ranks, transport in ((3, "peer"), (n_dev, "rccl")):
+        fpr = 2
+        frames = np.stack([np.asarray(synth.render_frame(600 + i, 480, 320)[0]) for i in range(ranks * fpr)])
+        raw = tmp_path / ("frames_%s.raw" % transport)
+        frames.tofile(raw)
+        r = subprocess.run([exe, str(raw), "480", "320", str(fpr), str(ranks), transport], capture_output=True, text=True)
+        assert r.returncode == 0, (r.stdout, r.stderr)
+        refs = oracle_saddles_parallel(oracle, frames, threads=4)
+        for i, ref in enumerate(refs):
+            assert "frame %d: %d\n" % (i, len(ref)) in r.stdout, (i, len(ref), r.stdout)
+        assert "%d saddles in %d frames" % (sum(len(x) for x in refs), ranks * fpr) in r.stdout
