@@ -928,8 +928,8 @@ __global__ void __launch_bounds__(64) k_verify_seeds(ChainArgs a)
 // canonical one iff its component contains no pixel with a smaller raster index: then the lane
 // emits the cluster with exact integer sums.  A component that touches the window's left /
 // right / bottom edge may continue outside: it goes to the second tier (wave_flood_128x64,
-// 128 x 64 window); a component that leaves that window too sets FLAG_BIG_CLUSTER and the
-// whole frame is redone by the generic kernels.
+// 128 x 64 window, run by k_refine's first workgroups); a component that leaves that window too
+// sets FLAG_BIG_CLUSTER and the whole frame is redone by the generic path (k_rare).
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t fill_runs(uint32_t s, uint32_t m)
 {
@@ -980,8 +980,8 @@ __device__ __forceinline__ unsigned long long from_right_u64(unsigned long long 
     return (unsigned long long)from_right_u((uint32_t)v) | ((unsigned long long)from_right_u((uint32_t)(v >> 32)) << 32);
 }
 
-__device__ __forceinline__ void wave_flood_128x64(const ChainArgs &a, int frame, uint32_t *flags, uint32_t *n_clusters,
-                                                  const uint32_t *mask, uint32_t p, int lane)
+__device__ __forceinline__ uint32_t wave_flood_128x64(const ChainArgs &a, int frame, uint32_t *flags, uint32_t *n_clusters,
+                                                      const uint32_t *mask, uint32_t p, int lane)
 {
     const uint32_t W = (uint32_t)a.W;
     const uint32_t sx = p % W, sy = p / W;
@@ -1010,10 +1010,10 @@ __device__ __forceinline__ void wave_flood_128x64(const ChainArgs &a, int frame,
     // not the canonical seed: a pixel of the component precedes it in raster order
     const bool earlier = (both & 1ull) != 0ull || (lane < 32 && (both & 2ull) != 0ull);
     const bool edge = (lane == 0 && comp[0] != 0ull) || (lane == 63 && comp[1] != 0ull) || (both >> 63) != 0ull;
-    if (__any(earlier)) return;
+    if (__any(earlier)) return 0xffffffffu;
     if (__any(edge)) {
         if (lane == 0) atomicOr(flags, FLAG_BIG_CLUSTER);
-        return;
+        return 0xffffffffu;
     }
     const uint32_t n0 = (uint32_t)__popcll(comp[0]), n1 = (uint32_t)__popcll(comp[1]);
     const uint32_t x0 = sx - 64u + 2u * (uint32_t)lane;
@@ -1024,8 +1024,9 @@ __device__ __forceinline__ void wave_flood_128x64(const ChainArgs &a, int frame,
         s_x += __shfl_xor(s_x, off, 64);
         s_y += __shfl_xor(s_y, off, 64);
     }
+    uint32_t o = 0xffffffffu;
     if (lane == 0) {
-        const uint32_t o = atomicAdd(n_clusters, 1u);
+        o = atomicAdd(n_clusters, 1u);
         if (o < a.cap_roots) {
             const size_t q = (size_t)frame * a.cap_roots + o;
             a.clu_key[q] = p;
@@ -1034,8 +1035,10 @@ __device__ __forceinline__ void wave_flood_128x64(const ChainArgs &a, int frame,
             a.clu_sy[q] = s_y;
         } else {
             atomicOr(flags, FLAG_ROOT_OVERFLOW);
+            o = 0xffffffffu;
         }
     }
+    return __shfl(o, 0, 64);  // index of the cluster record, or ~0: not a cluster of its own / no room
 }
 
 // First flood tier for one seed (one lane): 32 x 32 window.  Emits the cluster if the seed is the
@@ -1141,14 +1144,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
             p = a.seeds[(size_t)frame * a.cap_roots + i];
             big = flood_lane(a, frame, mask, W, p, &ctr.flags, &ctr.n_clusters);
         }
-        // oversized components (about 0.5 % of the seeds on real frames): the whole wave floods a
-        // 128 x 64 window for each of them in turn
-        unsigned long long bigm = __ballot(big);
-        if (bigm && lane == 0) atomicAdd(&ctr.n_big, (uint32_t)__popcll(bigm));
-        while (bigm) {
-            const int src = __ffsll((long long)bigm) - 1;
-            bigm &= bigm - 1ull;
-            wave_flood_128x64(a, frame, &ctr.flags, &ctr.n_clusters, mask, __shfl(p, src, 64), lane);
+        // Oversized components (about 0.5 % of the seeds on real frames) need the wave-wide 128 x 64
+        // window.  Doing them here, one after the other, made the few waves that found several the
+        // critical path of the launch (23 of 48 us); they go into the frame's list instead and are
+        // flooded by the first workgroups of k_refine, one wave each, all in parallel.
+        if (big) {
+            const uint32_t bi = atomicAdd(&ctr.n_big, 1u);
+            if (bi < a.cap_roots) a.roots[(size_t)frame * a.cap_roots + bi] = p;  // (the generic path's list, free until k_rare)
+            else atomicOr(&ctr.flags, FLAG_ROOT_OVERFLOW);
         }
     }
 }
@@ -1616,9 +1619,20 @@ __global__ void __launch_bounds__(64, 4) k_refine(ChainArgs a, RefineConsts rc)
     FrameCounters &ctr = a.ctr[frame];
     if (frame_is_generic(a, ctr)) return;  // whole frame: k_rare
     if (!(ctr.flags & (FLAG_CAND_OVERFLOW | FLAG_ROOT_OVERFLOW))) {
-        const uint32_t n = min(ctr.n_clusters, a.cap_roots);
+        const uint32_t n = min(ctr.n_clusters, a.cap_roots);  // the first flood tier's clusters
         const size_t cbase = (size_t)frame * a.cap_roots;
         const float *img = a.blur + (size_t)frame * (size_t)a.plane;
+        // second flood tier: the frame's oversized seeds, one per workgroup (= wave); the cluster it
+        // yields is refined right here by lane 0.  A component that leaves the 128 x 64 window too
+        // flags the frame for the generic path: whatever this launch does with the frame is then
+        // discarded and k_rare redoes it.
+        const uint32_t n_big = min(ctr.n_big, a.cap_roots);
+        const uint32_t *mask = a.mask + (size_t)frame * (size_t)a.mask_plane;
+        for (uint32_t b = fs.slot; b < n_big; b += fs.n_slots) {
+            const uint32_t o = wave_flood_128x64(a, frame, &ctr.flags, &ctr.n_clusters, mask, a.roots[cbase + b], (int)threadIdx.x);
+            if (o != 0xffffffffu && threadIdx.x == 0)
+                refine_cluster<VEC>(a, rc, frame, cbase, img, a.W, a.H, o, &ctr.n_refined, &ctr.max_k_bits);
+        }
         for (uint32_t i = fs.slot * blockDim.x + threadIdx.x; i < n; i += fs.n_slots * blockDim.x)
             refine_cluster<VEC>(a, rc, frame, cbase, img, a.W, a.H, i, &ctr.n_refined, &ctr.max_k_bits);
     }
@@ -1631,6 +1645,7 @@ __global__ void __launch_bounds__(64, 4) k_refine(ChainArgs a, RefineConsts rc)
     if (threadIdx.x == 0) s_last = atomicAdd(&ctr.refine_done, 1u) == fs.n_slots - 1u;
     __syncthreads();
     if (!s_last) return;
+    if (__hip_atomic_load(&ctr.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & FLAG_BIG_CLUSTER) return;  // flagged by a second-tier flood of this launch: k_rare
     const uint32_t n_ref = __hip_atomic_load(&ctr.n_refined, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const uint32_t maxk = __hip_atomic_load(&ctr.max_k_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     emit_small(a, frame, n_ref, maxk, s_keys, s_misc);
@@ -1652,6 +1667,10 @@ __global__ void __launch_bounds__(1024) k_rare(ChainArgs a, RefineConsts rc, uin
     if (!generic && !(ctr.flags & FLAG_LARGE_RESULT)) return;  // whole workgroup
     if (generic) {
         generic_frame(a, frame);
+        if (threadIdx.x == 0) {  // k_refine may have refined part of the frame before a second-tier flood flagged it
+            __hip_atomic_store(&ctr.n_refined, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ctr.max_k_bits, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         phase_barrier();
         const uint32_t flags = __hip_atomic_load(&ctr.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (!(flags & (FLAG_CAND_OVERFLOW | FLAG_ROOT_OVERFLOW))) {
