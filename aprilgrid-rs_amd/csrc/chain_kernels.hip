@@ -308,7 +308,14 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
     // wave-uniform; kept as bit patterns so that they live in scalar registers
     int thr_run_bits = 0, published_bits = 0;  // 0.0f
     int rows_to_sync = 0, sync_gap = 1;
-    uint32_t polled = 0u;  // ctr.min_key_inv as fetched at the previous sync point
+    // ctr.min_key_inv as fetched at the previous sync point.  The first fetch is issued right here, at
+    // the start of the wave, and awaited at the first sync point seven warm-up rows later: a wave that
+    // starts when other waves of its frame have already published (the later segments under the
+    // segment-major dispatch order) thresholds against the frame's running minimum from its first row
+    // on instead of against the minimum of that one row.
+    uint32_t polled;
+    asm volatile("s_load_dword %0, %1, 0x0 glc" : "=s"(polled) : "s"(&ctr.min_key_inv) : "memory");
+    bool polled_pending = true;
     float cmax = -__builtin_inff();  // weakest candidate response of this lane in the current 32-row block
     uint32_t mw[4] = {0u, 0u, 0u, 0u};  // this lane's 4 mask words (4 columns x 32 rows) in progress
     int y_pushed = 0;                    // last row whose bits were shifted into mw
@@ -579,6 +586,10 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
                         if (wmin < published) {  // any improvement: at most one atomic per sync point and wave
                             if (lane == 0) atomicMax(&ctr.min_key_inv, ~f32_order_key(wmin));
                             published_bits = wmin_bits;
+                        }
+                        if (polled_pending) {  // the fetch issued at the start of the wave
+                            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(polled) : : "memory");
+                            polled_pending = false;
                         }
                         const float gmin = polled ? f32_from_order_key(~polled) : 0.0f;  // 0 = nothing seen yet
                         // (asm: the builtin would be commuted with the multiply and leave a VGPR.  The
