@@ -719,7 +719,7 @@ __device__ __forceinline__ uint32_t retest_word(const float *blur, int W, int yb
 // 4-connected to an earlier one, so it cannot be the first pixel of its component, and dropping it
 // here saves a whole flood (2.1 -> 1.1 seeds per cluster).
 //
-// One wave owns 56 columns x up to 8 word rows (256 image rows): lane = column, lane 0 and lanes
+// One wave owns 56 columns x up to 4 word rows (128 image rows, the height of a K1 segment): lane = column, lane 0 and lanes
 // 57..63 are halo lanes (the left neighbour and the 7 columns of look-ahead), verified redundantly
 // (verification is idempotent, so it does not matter whether the owning wave has already rewritten
 // a word).  The kernel is a chain of memory round trips, so each of them is made wide: all of a
@@ -729,7 +729,7 @@ __device__ __forceinline__ uint32_t retest_word(const float *blur, int W, int yb
 // seeds of the tile are collected in LDS and appended to the frame's list with one atomic.
 // ------------------------------------------------------------------------------------------
 constexpr int VS_OWN = 56;         // owner lanes of a wave (1 left halo + 56 + 7 look-ahead = 64)
-constexpr int VS_ROWS = 8;         // word rows per tile
+constexpr int VS_ROWS = 4;         // word rows per tile
 constexpr uint32_t VS_LIST = 512;  // re-test work list entries per pass
 constexpr uint32_t VS_SEEDS = 256; // seeds buffered per tile
 
@@ -1792,10 +1792,10 @@ int launch_kernel(int which, const ChainArgs &a, const RefineConsts &rc, void *s
         if (a.fmt == 3) return launch_k1<3>(a, st);
         return launch_k1<2>(a, st);
     case K_THRESHOLD: {
-        // one workgroup (= one wave) per tile of 56 columns x 8 word rows, at most 256 per frame
+        // one workgroup (= one wave) per tile of VS_OWN columns x VS_ROWS word rows, at most 512 per frame
         const int n_yb = (a.H + 31) >> 5;
-        int tiles = ((n_yb + 7) / 8) * ((a.W + 55) / 56);
-        if (tiles > 256) tiles = 256;
+        int tiles = ((n_yb + VS_ROWS - 1) / VS_ROWS) * ((a.W + VS_OWN - 1) / VS_OWN);
+        if (tiles > 512) tiles = 512;
         const int per_frame = env_int("AGX_G_VERIFY", tiles);
         dim3 grid((unsigned)per_frame * (unsigned)a.n_frames), block(64);  // slot-major, see frame_slot
         hipLaunchKernelGGL(k_verify_seeds, grid, block, 0, st, a);
