@@ -191,7 +191,7 @@ enum {
     AGX_FRAME_CENTROID_INEXACT = 8, /* informational: a cluster's coordinate sum reached 2^24 */
     AGX_FRAME_GENERIC_PATH = 16,    /* informational: clustered by the generic kernels         */
     AGX_FRAME_DENSE_THRESHOLD = 32, /* (unused) */
-    AGX_FRAME_LARGE_RESULT = 64     /* informational: more than 512 saddles, emitted by the large-list kernel */
+    AGX_FRAME_LARGE_RESULT = 64     /* informational: more than 1024 refined candidates, emitted by the large-list path */
 };
 int agx_saddles_batch_enqueue_to(agx_detector *det, const void *d_frames, int n_frames, int width,
                                  int height, size_t row_stride_bytes, size_t frame_stride_bytes,
