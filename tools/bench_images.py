@@ -109,6 +109,21 @@ def main(argv=None):
         row["speedup_single_frame_fused"] = round(c / row["gpu_k1_fused_single_frame_ms_per_frame"], 1)
         row["speedup_batch_64_fused"] = round(c / row["gpu_k1_fused_batch_64_ms_per_frame"], 1)
         out["blur"][name] = row
+    # end-to-end detect() over a batch (agx_detect_batch): chain per chunk on the device, board search +
+    # decode on a pool of host threads -- frames per second by thread count (the host tail is the
+    # reference's exhaustive search: this rate is set by the host, never the bench's `value`)
+    from aprilgrid_rs_amd import synth
+    fr, _ = synth.render_batch(0, 256, 1280, 800, device="cuda")
+    host = fr.cpu().numpy()
+    out["detect_batch_256x1280x800_L8"] = {}
+    for thr in (1, 8, 32, 64):
+        n = 32 if thr == 1 else 256
+        det.detect_batch(host[:8], n_threads=thr)  # pool start-up outside the timed call
+        t0 = time.perf_counter()
+        tags = det.detect_batch(host[:n], n_threads=thr)
+        dt = time.perf_counter() - t0
+        out["detect_batch_256x1280x800_L8"]["threads_%d" % thr] = {
+            "frames": n, "frames_per_s": round(n / dt, 1), "tags_per_frame": round(sum(len(t) for t in tags) / n, 1)}
     det.close()
     print(json.dumps(out, indent=1))
     return out

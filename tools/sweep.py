@@ -8,8 +8,10 @@ F = int(os.environ.get("FRAMES", "256"))
 rows = [int(x) for x in (sys.argv[1:] or ["0"])]
 U = int(os.environ.get("UNIQUE", "32"))
 W, H = int(os.environ.get("WIDTH", "1280")), int(os.environ.get("HEIGHT", "800"))
-base, _ = synth.render_batch(0, U, W, H, device="cuda")
-frames = base.repeat((F // U + 1, 1, 1))[:F].contiguous()
+NOISE = os.environ.get("NOISE", "0") == "1"
+FMT = os.environ.get("FORMAT", "L8")
+base, _ = synth.render_batch(0, U, W, H, device="cuda", fmt=FMT, pure_noise=NOISE)
+frames = base.repeat((F // U + 1,) + (1,) * (base.dim() - 1))[:F].contiguous()
 det = A.TagDetector("t36h11")
 import time
 DBG = [int(x) for x in os.environ.get("DBG", "0").split(",")]
