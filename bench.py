@@ -309,14 +309,14 @@ def main():
     # setup, untimed: first call allocates the workspace; then run until the clocks have settled.
     # Every rank issues the SAME sequence of collectives: the number of settle rounds is fixed from the
     # first round's duration as rank 0 measured it (broadcast), never from a rank's own clock.
-    t_round = time.perf_counter()
     step()
     fence()
+    t_round = time.perf_counter()
     for _ in range(8):
         step()
     fence()
-    t_round = time.perf_counter() - t_round
-    rounds = int(min(64, max(0, args.settle_ms * 1e-3 / max(t_round, 1e-4))))
+    t_round = time.perf_counter() - t_round  # one round of 8 steps, workspace already allocated
+    rounds = int(min(128, max(0, args.settle_ms * 1e-3 / max(t_round, 1e-4))))
     if world > 1:
         rt = torch.tensor([rounds], dtype=torch.int64, device=dev)
         dist.broadcast(rt, src=0)
