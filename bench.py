@@ -194,6 +194,26 @@ def k1_roofline(px, in_b, k1_ms, k1_n, traffic=None, traffic_src=None):
             "avg_launch_ms": round(avg, 5), "launches_timed": k1_n}
 
 
+def box_copy_gbps(torch, dev):
+    """What a plain device-to-device copy of 1 GiB reaches on THIS box (read + write bytes per second,
+    best of 5): boxes of the pool differ, and the guide's 6.29 TB/s is not what every one of them gives."""
+    n = 1 << 28
+    a = torch.empty(n, dtype=torch.float32, device=dev)
+    b = torch.empty_like(a)
+    best = None
+    for _ in range(6):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        b.copy_(a)
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1)
+        best = ms if best is None else min(best, ms)
+    del a, b
+    torch.cuda.empty_cache()
+    return 2.0 * n * 4 / (best * 1e-3) / 1e9
+
+
 def recorded_traffic(key):
     """HBM bytes per K1 launch from rocprofv3 PMC passes (FETCH_SIZE x2 per the calibration +
     WRITE_SIZE), collected separately (tools/final_profile.sh) and kept under profiles/."""
@@ -442,6 +462,11 @@ def main():
         roof = k1_roofline(px_per_step_rank, in_b, k1_ms, k1_n, traffic, traffic_src)
         # the same kernel alone on the GPU (serial pass below the timed region): with
         # --pipeline > 1 the timed launches share the chip with another step's sparse kernels
+        if world == 1:  # the same box's plain copy rate, measured now: K1's HBM traffic against it
+            copy_gbps = box_copy_gbps(torch, dev)
+            roof["copy_GBps_this_box"] = round(copy_gbps, 1)
+            if traffic:
+                roof["traffic_frac_of_copy_this_box"] = round(traffic / (roof["avg_launch_ms"] * 1e-3) / 1e9 / copy_gbps, 4)
         roof["alone_avg_launch_ms"] = round(k1_alone_ms, 5)
         roof["alone_frac"] = round(roof["bytes_per_launch"] / (k1_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
         result = {
