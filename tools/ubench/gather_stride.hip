@@ -49,7 +49,17 @@ int main()
             float ms; hipEventElapsedTime(&ms, e0, e1);
             if (ms < best) best = ms;
         }
-        printf("row distance %6u floats (%6u B): %.1f us for %d windows\n", st, st * 4, best * 1e3f, waves * 64);
+        // the same windows again at once (same seed, nothing written in between): how much of the
+        // touched sectors is still in L2 / MALL (Infinity Cache)?
+        hipMemset(junk, 7, (size_t)512 << 20);
+        k<<<waves, 64>>>(plane, plane_floats, st, out, 777u);
+        hipDeviceSynchronize();
+        hipEventRecord(e0);
+        k<<<waves, 64>>>(plane, plane_floats, st, out, 777u);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float warm; hipEventElapsedTime(&warm, e0, e1);
+        printf("row distance %6u floats (%6u B): %.1f us for %d windows; repeated at once: %.1f us\n", st, st * 4, best * 1e3f, waves * 64, warm * 1e3f);
     }
     return 0;
 }
