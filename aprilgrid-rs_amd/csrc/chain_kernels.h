@@ -44,6 +44,7 @@ struct FrameCounters {
     uint32_t pad1;
     uint32_t stats[20];    // debug_ablation & 128: verify statistics by word row within a 128-row segment
 };
+static_assert(sizeof(FrameCounters) == 256, "FrameCounters is cleared as 64 dwords");
 enum : uint32_t {
     FLAG_CAND_OVERFLOW = 1u,   // seed list (fast path) or candidate list (generic path) full
     FLAG_ROOT_OVERFLOW = 2u,   // cluster list full
@@ -98,6 +99,7 @@ struct ChainArgs {
                              // region, 16 = no shared-min refresh
     // per-frame
     FrameCounters *ctr;
+    FrameCounters *ctr_next;  // the other counter set: k_rare clears records [0, n_frames] of it for the next batch (or null)
     uint32_t *total_out;  // single counter: compact output allocation
     uint32_t cap_cand, cap_roots, cap_out;
     uint32_t *seeds;      // [n_frames][cap_roots] pixel index of each flood seed

@@ -1673,6 +1673,12 @@ __global__ void __launch_bounds__(1024) k_rare(ChainArgs a, RefineConsts rc, uin
     extern __shared__ uint32_t lds_u[];
     __shared__ uint32_t s_count, s_offset, s_fits;
     const int frame = blockIdx.x;
+    // The last launch of the batch also clears the OTHER counter set for the next batch (the two sets
+    // alternate): a memset between the batches costs a fill kernel and two ~5 us gaps on the stream.
+    if (a.ctr_next && threadIdx.x < 64) {
+        reinterpret_cast<uint32_t *>(&a.ctr_next[frame])[threadIdx.x] = 0u;
+        if (frame == 0) reinterpret_cast<uint32_t *>(&a.ctr_next[a.n_frames])[threadIdx.x] = 0u;  // the output cursor's record
+    }
     FrameCounters &ctr = a.ctr[frame];
     const bool generic = frame_is_generic(a, ctr);
     if (!generic && !(ctr.flags & FLAG_LARGE_RESULT)) return;  // whole workgroup

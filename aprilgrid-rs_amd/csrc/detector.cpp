@@ -70,8 +70,16 @@ struct agx_detector {
     size_t mask_words = 0;
     bool external_out = false;       // last batch wrote into caller-owned device memory
 
+    // two counter sets used alternately: the last kernel of a batch clears the other set, so only a
+    // batch that finds its set not known to be clear pays a memset
+    FrameCounters *d_ctr[2] = {nullptr, nullptr};
+    size_t ctr_cleared[2] = {0, 0};  // records of the set known to be zero (0 = in use / unknown)
+    int ctr_cur = 0;
+
     bool enqueued = false;
     int profiling = 0;  // 0 off, 1 = K1 only, 2 = every kernel
+    int prof_stride = 1;        // level 1: time the blur kernel of every prof_stride-th batch only
+    uint64_t prof_batches = 0;  // batches enqueued while profiling
     std::vector<EventPair> pending_events;
     std::vector<hipEvent_t> free_events;
     double prof_ms[K_COUNT]{};
@@ -184,6 +192,8 @@ void free_workspace(agx_detector *d)
     d->device_allocs.clear();
     d->cap_frames = 0;
     d->cap_plane = 0;
+    d->d_ctr[0] = d->d_ctr[1] = nullptr;
+    d->ctr_cleared[0] = d->ctr_cleared[1] = 0;
     if (d->h_ctr) (void)hipHostFree(d->h_ctr);
     if (d->h_out) (void)hipHostFree(d->h_out);
     d->h_ctr = nullptr;
@@ -244,7 +254,11 @@ int ensure_workspace(agx_detector *d, int n_frames, int W, int H)
     if ((rc = dev_alloc(d, a.slot_plane, F * plane))) return rc;
     if ((rc = dev_alloc(d, a.mask, F * mask_plane))) return rc;
     d->mask_words = F * mask_plane;
-    if ((rc = dev_alloc(d, a.ctr, F + 1))) return rc;  // + one extra record: its first word is total_out
+    for (int p = 0; p < 2; ++p) {
+        if ((rc = dev_alloc(d, d->d_ctr[p], F + 1))) return rc;  // + one extra record: its first word is total_out
+        d->ctr_cleared[p] = 0;
+    }
+    a.ctr = d->d_ctr[0];
     a.total_out = &a.ctr[F].min_key_inv;
     if ((rc = dev_alloc(d, a.seeds, F * cap_roots))) return rc;
     if ((rc = dev_alloc(d, a.clu_key, F * cap_roots))) return rc;
@@ -314,6 +328,7 @@ int enqueue_chunk(agx_detector *d, int f0, int nf, hipStream_t st)
     a.cand_max += F0 * (size_t)(a.mask_plane / 4);
     a.mask += F0 * (size_t)a.mask_plane;
     a.ctr += F0;
+    if (a.ctr_next) a.ctr_next += F0;
     a.seeds += F0 * a.cap_roots;
     a.clu_key += F0 * a.cap_roots;
     a.clu_cnt += F0 * a.cap_roots;
@@ -330,7 +345,8 @@ int enqueue_chunk(agx_detector *d, int f0, int nf, hipStream_t st)
     if (a.frame_table) a.frame_table += F0 * 4;
     for (int k = 0; k < K_COUNT; ++k) {
         EventPair ev{nullptr, nullptr, k};
-        const bool timed = d->profiling >= 2 || (d->profiling == 1 && k == K_BLUR_HESSIAN);
+        // (an event pair costs the stream two ~5 us gaps around the kernel: level 1 can sample)
+        const bool timed = d->profiling >= 2 || (d->profiling == 1 && k == K_BLUR_HESSIAN && d->prof_batches % (uint64_t)d->prof_stride == 0);
         if (timed) {
             ev.a = get_event(d);
             ev.b = get_event(d);
@@ -344,19 +360,30 @@ int enqueue_chunk(agx_detector *d, int f0, int nf, hipStream_t st)
             d->pending_events.push_back(ev);
         }
     }
+    if (d->profiling) ++d->prof_batches;
     return AGX_OK;
 }
 
 int enqueue_chain(agx_detector *d)
 {
     ChainArgs &a = d->args;
-    // counters of the batch's frames and the compact-output cursor in one clear
+    // counters of the batch's frames and the compact-output cursor: the set the previous batch's last
+    // kernel cleared, or -- first batch, larger batch, after an error -- one memset
+    const int p = d->ctr_cur ^ 1;
+    const size_t need = (size_t)a.n_frames + 1;
+    if (d->ctr_cleared[p] < need)
+        HIP_TRY(d, hipMemsetAsync(d->d_ctr[p], 0, need * sizeof(FrameCounters), d->stream));
+    d->ctr_cleared[p] = 0;
+    a.ctr = d->d_ctr[p];
+    a.ctr_next = d->d_ctr[p ^ 1];
     a.total_out = &a.ctr[a.n_frames].min_key_inv;
-    HIP_TRY(d, hipMemsetAsync(a.ctr, 0, ((size_t)a.n_frames + 1) * sizeof(FrameCounters), d->stream));
+    d->ctr_cleared[p ^ 1] = 0;
     // (splitting a batch over several streams -- whole chain or sparse kernels only -- was measured
     // and lost every time: see DESIGN.md; batches in flight are separate detectors)
     const int rc = enqueue_chunk(d, 0, a.n_frames, d->stream);
     if (rc) return rc;
+    d->ctr_cleared[p ^ 1] = need;  // k_rare of this batch clears it, stream-ordered before the next batch
+    d->ctr_cur = p;
     d->enqueued = true;
     return AGX_OK;
 }
@@ -557,6 +584,7 @@ int agx_detector_set_option(agx_detector *det, const char *name, int value)
     else if (!std::strcmp(name, "k1_rows_per_segment")) det->k1_rows = value > 0 ? value : 0;
     else if (!std::strcmp(name, "debug_ablation")) det->dbg = value;  // timing only, results invalid
     else if (!std::strcmp(name, "store_response")) det->store_resp = value != 0;
+    else if (!std::strcmp(name, "profile_stride")) det->prof_stride = value > 1 ? value : 1;
     else return fail(det, AGX_ERR_ARG, std::string("unknown option ") + name);
     return AGX_OK;
 }
@@ -867,6 +895,7 @@ int agx_profile_reset(agx_detector *det)
         det->prof_ms[k] = 0.0;
         det->prof_launches[k] = 0;
     }
+    det->prof_batches = 0;
     return AGX_OK;
 }
 

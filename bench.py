@@ -16,7 +16,8 @@ Rank 0 prints ONE JSON line.  value = pixels of all ranks through the chain per 
 (Mpix/s), inputs resident in HBM, over the K timed steps (wall clock between two fences);
 ms_per_step_median = median of the K per-step device times (events between the steps).
 roofline = K1 (the dominant kernel): algorithmic bytes per launch / average launch duration from
-hipEvents recorded on the launch stream inside the timed region.  The timed region is strictly
+hipEvents recorded on the launch stream inside the timed region (every 5th step: the events
+themselves cost the stream ~10 us per timed launch).  The timed region is strictly
 serial (one batch at a time); at N = 1 a second pass with --extra-pipeline batches in flight
 (sharding.ChainPipeline) is reported as "pipelined".
 
@@ -236,6 +237,7 @@ def extra_leg(torch, A, dev, name, workload, n_frames, width, height, fmt, uniqu
         for _ in range(max(warmup, 1) + 2):
             det.saddles_batch_enqueue(frames)
         torch.cuda.synchronize(dev)
+        det.set_option("profile_stride", 5 if steps >= 20 else 1)
         det.profile_enable(1)
         det.profile_reset()
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
@@ -357,7 +359,9 @@ def main():
 
     # timed region: hipEvents (on the launch stream) around K1 only -- 2 records per step -- and one
     # event between the steps (strictly serial: the chain launches on the current stream)
+    # (an event pair costs the stream two ~5 us gaps around the kernel: K1 of every 5th step is timed)
     for d in pipe.dets:
+        d.set_option("profile_stride", 5 if args.steps >= 20 else 1)
         d.profile_enable(1)
         d.profile_reset()
     serial = pipe.depth == 1
@@ -378,6 +382,7 @@ def main():
         ms, n = d.profile_read()["k_blur_hessian"]
         k1_ms, k1_n = k1_ms + ms, k1_n + n
         d.profile_enable(0)
+        d.set_option("profile_stride", 1)
 
     # results of the last timed step: the gathered tables must be complete on rank 0 (every rank's
     # frames present, no blocking status) -- the first multi-GPU hardware run checks itself

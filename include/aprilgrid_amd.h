@@ -116,6 +116,8 @@ int agx_detector_set_limits(agx_detector *det, uint32_t max_candidates, uint32_t
  *   "k1_rows_per_segment"  rows one wave of the blur kernel walks (0 = automatic)
  *   "store_response"       1 = the blur kernel also stores the Hessian response it evaluates in
  *                          registers (parity tests: agx_debug_fetch AGX_DBG_RESP); slower
+ *   "profile_stride"       with agx_profile_enable(det, 1): time the blur kernel of every n-th batch
+ *                          only (an event pair costs the stream two ~5 us gaps around the kernel)
  *   "debug_ablation"       timing experiments only -- results are INVALID when non-zero */
 int agx_detector_set_option(agx_detector *det, const char *name, int value);
 /* Read an option back; additionally the tiling the blur kernel used for the last enqueued batch:
