@@ -583,15 +583,21 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
                         const int wmin_bits = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wmin));
                         wmin = __builtin_bit_cast(float, wmin_bits);
                         const float published = __builtin_bit_cast(float, published_bits);
-                        if (wmin < published) {  // any improvement: at most one atomic per sync point and wave
-                            if (lane == 0) atomicMax(&ctr.min_key_inv, ~f32_order_key(wmin));
-                            published_bits = wmin_bits;
-                        }
                         if (polled_pending) {  // the fetch issued at the start of the wave
                             asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(polled) : : "memory");
                             polled_pending = false;
                         }
                         const float gmin = polled ? f32_from_order_key(~polled) : 0.0f;  // 0 = nothing seen yet
+                        // Every wave of a frame publishes to ONE word, and atomics on one L2 line serialise
+                        // (~45 ns each: with one 1920x1080 frame on the chip, 272 waves x 6 sync points made
+                        // K1 106 us instead of 33).  Frames cut into many waves (few frames per batch:
+                        // plan_k1 sets publish_factor 1.5, else 1) publish only what improves on the frame's
+                        // known minimum by more than half.  A staler published value only widens the
+                        // candidate superset; the exact minimum is published unconditionally at the wave's end.
+                        if (wmin < published && wmin < gmin * a.publish_factor) {
+                            if (lane == 0) atomicMax(&ctr.min_key_inv, ~f32_order_key(wmin));
+                            published_bits = wmin_bits;
+                        }
                         // (asm: the builtin would be commuted with the multiply and leave a VGPR.  The
                         // assembler inserts no wait states inside asm: on gfx950 a readlane needs one
                         // after the VALU write of its source, a VALU read of the SGPR two after this)
@@ -1749,6 +1755,7 @@ bool plan_k1(ChainArgs &a, int override_rows_per_seg)
     if (rps > 128) rps = 128;
     a.rows_per_seg = rps;
     a.n_segs = (H + rps - 1) / rps;
+    a.publish_factor = a.n_strips * a.n_segs > 128 ? 1.5f : 1.0f;  // see the publish step of K1
     return true;
 }
 
