@@ -671,7 +671,15 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
     float run_min = lane_min();
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) run_min = fminf(run_min, __shfl_xor(run_min, off, 64));
-    if (lane == 0) atomicMax(&ctr.min_key_inv, ~f32_order_key(run_min));  // always: the word must end up valid
+    // The wave's exact minimum goes to the frame's word unless the word is known to hold something at
+    // least as small already (the last value polled from it; it only ever decreases).  A word never
+    // polled non-zero may still be unset: then the wave publishes in any case, so the word ends up valid.
+    if (polled_pending) {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(polled) : : "memory");
+        polled_pending = false;
+    }
+    const bool known_smaller = polled != 0u && !(run_min < f32_from_order_key(~polled));
+    if (lane == 0 && !known_smaller) atomicMax(&ctr.min_key_inv, ~f32_order_key(run_min));
 }
 
 // The Hessian determinant of pixel c[0] of the blur plane -- same expression, same operands as K1.
