@@ -45,16 +45,29 @@ float angle_degree(float v0x, float v0y, float v1x, float v1y)
     return std::atan2(v1y * v0x - v1x * v0y, v0x * v1x + v0y * v1y) * 180.0f / kPi;
 }
 
-bool is_valid_quad(const agx_saddle &s0, const agx_saddle &d0, const agx_saddle &s1, const agx_saddle &d1)
+// is_valid_quad (saddle.rs:17-67) in three parts, so that init_quads can hoist the two that do not
+// depend on all four saddles out of its inner loop: the conjunction is the same, every part
+// evaluates the reference's expressions unchanged.
+//   part 0 (:18-21)   d0 and d1 have the same orientation           -- depends on (d0, d1)
+//   part 1 (:26-38)   "filter white block": the diagonal s0 -> s1 is roughly perpendicular to s0's
+//                     saddle axis                                     -- depends on (s0, s1)
+//   rest   (:40-66)   winding, opposite angles, both d on s1's side  -- all four
+static inline bool quad_part0(const agx_saddle &d0, const agx_saddle &d1)
 {
-    if (theta_distance_degree(d0.theta, d1.theta) > 5.0f) return false;
+    return !(theta_distance_degree(d0.theta, d1.theta) > 5.0f);
+}
+static inline bool quad_part1(const agx_saddle &s0, const agx_saddle &s1)
+{
+    const float v02x = s1.x - s0.x, v02y = s1.y - s0.y;
+    const float th = s0.theta / 180.0f * kPi;
+    const float ang = std::fabs(angle_degree(v02x, v02y, std::cos(th), std::sin(th)));
+    return ang >= 60.0f && ang <= 120.0f;
+}
+static inline bool quad_rest(const agx_saddle &s0, const agx_saddle &d0, const agx_saddle &s1, const agx_saddle &d1)
+{
     const float v01x = d0.x - s0.x, v01y = d0.y - s0.y;
     const float v03x = d1.x - s0.x, v03y = d1.y - s0.y;
     const float v02x = s1.x - s0.x, v02y = s1.y - s0.y;
-    // the diagonal must be roughly perpendicular to s0's saddle axis ("filter white block")
-    const float th = s0.theta / 180.0f * kPi;
-    const float ang = std::fabs(angle_degree(v02x, v02y, std::cos(th), std::sin(th)));
-    if (!(ang >= 60.0f && ang <= 120.0f)) return false;
     if (cross2(v01x, v01y, v02x, v02y) * cross2(v02x, v02y, v03x, v03y) < 0.0f) return false;
     const float v12x = s1.x - d0.x, v12y = s1.y - d0.y;
     const float v23x = d1.x - s1.x, v23y = d1.y - s1.y;
@@ -67,6 +80,11 @@ bool is_valid_quad(const agx_saddle &s0, const agx_saddle &d0, const agx_saddle 
     if (std::fabs(a0 - a2) > 10.0f || std::fabs(a1 - a3) > 10.0f) return false;
     if (dot2(v01x, v01y, v02x, v02y) < 0.0f || dot2(v03x, v03y, v02x, v02y) < 0.0f) return false;
     return true;
+}
+
+bool is_valid_quad(const agx_saddle &s0, const agx_saddle &d0, const agx_saddle &s1, const agx_saddle &d1)
+{
+    return quad_part0(d0, d1) && quad_part1(s0, s1) && quad_rest(s0, d0, s1, d1);
 }
 
 namespace {
@@ -437,30 +455,80 @@ private:
     std::vector<int16_t> grid_ = std::vector<int16_t>((size_t)kGridN * kGridN, (int16_t)-1);
 };
 
-// init_quads, src/detector.rs:543-586
+// init_quads, src/detector.rs:543-586.  The reference tests every (s1, d0, d1) combination with
+// is_valid_quad; here the same conjunction is evaluated from tables, because most of its terms do
+// not depend on all of s1, d0, d1 (s0 is fixed):
+//   (d0, d1)   orientation test (part 0), angle a3 = angle(v30, v01)
+//   (s1)       white-block test (part 1)
+//   (s1, d)    cross(v0d, v02), cross(v02, v0d), dot(v0d, v02) >= 0, cross(v01, v12), a0 = angle(v01, v12)
+//              for d as d0, a2 = angle(v23, v30) for d as d1
+//   all four   cross(v12, v23), a1 = angle(v12, v23)
+// Every entry is computed by the reference's expression on the reference's operands, so each test
+// sees the same floats; only the order of the (side-effect free) tests differs, and three of the
+// four atan2 per combination become table look-ups.  Quads are emitted in the reference's order.
 void init_quads(const std::vector<agx_saddle> &refined, SaddleIndex &index, int s0_idx, std::vector<Quad> &out)
 {
     out.clear();
     const agx_saddle &s0 = refined[s0_idx];
     SaddleIndex::Hit near[50];
     const int m = index.nearest(s0.x, s0.y, 50, near);
-    std::vector<int> same, diff;
+    int same[50], diff[50];
+    int ns = 0, nd = 0;
     for (int i = 1; i < m; ++i) {
         const int idx = near[i].idx;
         const float td = theta_distance_degree(s0.theta, refined[idx].theta);
-        if (td < 5.0f) same.push_back(idx);
-        else if (td > 80.0f) diff.push_back(idx);
+        if (td < 5.0f) same[ns++] = idx;
+        else if (td > 80.0f) diff[nd++] = idx;
     }
-    for (int s1_idx : same) {
+    if (!ns || nd < 2) return;
+    // (d): v0d = d - s0 (v01 / v03), v30 = s0 - d;  (d0, d1): part 0, a3 on demand
+    float v0x[50], v0y[50], v30x[50], v30y[50];
+    for (int d = 0; d < nd; ++d) {
+        const agx_saddle &p = refined[diff[d]];
+        v0x[d] = p.x - s0.x; v0y[d] = p.y - s0.y;
+        v30x[d] = s0.x - p.x; v30y[d] = s0.y - p.y;
+    }
+    uint8_t pair_ok[50 * 50];
+    float a3v[50 * 50];
+    uint8_t a3_set[50 * 50];
+    for (int a = 0; a < nd; ++a)
+        for (int b = a + 1; b < nd; ++b) {
+            pair_ok[a * 50 + b] = quad_part0(refined[diff[a]], refined[diff[b]]);
+            a3_set[a * 50 + b] = 0;
+        }
+    for (int si = 0; si < ns; ++si) {
+        const int s1_idx = same[si];
         const agx_saddle &s1 = refined[s1_idx];
-        for (size_t a = 0; a < diff.size(); ++a)
-            for (size_t b = a + 1; b < diff.size(); ++b) {
-                const agx_saddle &d0 = refined[diff[a]], &d1 = refined[diff[b]];
-                if (!is_valid_quad(s0, d0, s1, d1)) continue;
-                const float c0 = cross2(d0.x - s0.x, d0.y - s0.y, s1.x - s0.x, s1.y - s0.y);
-                if (c0 > 0.0f) out.push_back({s0_idx, diff[a], s1_idx, diff[b]});
+        if (!quad_part1(s0, s1)) continue;
+        const float v02x = s1.x - s0.x, v02y = s1.y - s0.y;
+        float cA[50], cB[50], c01[50], v12x[50], v12y[50], v23x[50], v23y[50], a0v[50], a2v[50];
+        uint8_t dok[50], a0_set[50], a2_set[50];
+        for (int d = 0; d < nd; ++d) {
+            const agx_saddle &p = refined[diff[d]];
+            cA[d] = cross2(v0x[d], v0y[d], v02x, v02y);   // c0 with d as d0 (also the winding test)
+            cB[d] = cross2(v02x, v02y, v0x[d], v0y[d]);   // c1 with d as d1
+            dok[d] = !(dot2(v0x[d], v0y[d], v02x, v02y) < 0.0f);
+            v12x[d] = s1.x - p.x; v12y[d] = s1.y - p.y;   // d as d0
+            v23x[d] = p.x - s1.x; v23y[d] = p.y - s1.y;   // d as d1
+            c01[d] = cross2(v0x[d], v0y[d], v12x[d], v12y[d]);
+            a0_set[d] = a2_set[d] = 0;
+        }
+        for (int a = 0; a < nd; ++a) {
+            if (!dok[a]) continue;
+            for (int b = a + 1; b < nd; ++b) {
+                if (!pair_ok[a * 50 + b] || !dok[b]) continue;
+                if (cA[a] * cB[b] < 0.0f) continue;
+                if (c01[a] * cross2(v12x[a], v12y[a], v23x[b], v23y[b]) < 0.0f) continue;
+                if (!a0_set[a]) { a0v[a] = angle_degree(v0x[a], v0y[a], v12x[a], v12y[a]); a0_set[a] = 1; }
+                if (!a2_set[b]) { a2v[b] = angle_degree(v23x[b], v23y[b], v30x[b], v30y[b]); a2_set[b] = 1; }
+                if (std::fabs(a0v[a] - a2v[b]) > 10.0f) continue;
+                if (!a3_set[a * 50 + b]) { a3v[a * 50 + b] = angle_degree(v30x[b], v30y[b], v0x[a], v0y[a]); a3_set[a * 50 + b] = 1; }
+                const float a1 = angle_degree(v12x[a], v12y[a], v23x[b], v23y[b]);
+                if (std::fabs(a1 - a3v[a * 50 + b]) > 10.0f) continue;
+                if (cA[a] > 0.0f) out.push_back({s0_idx, diff[a], s1_idx, diff[b]});
                 else out.push_back({s0_idx, diff[b], s1_idx, diff[a]});
             }
+        }
     }
 }
 

@@ -127,6 +127,41 @@ def test_host_tail_matches_oracle_tail_on_synthetic_and_other_families():
     assert A.TagDetector.detect_tail("t36h11", s2[:0], g2) == {}
 
 
+def test_host_tail_matches_oracle_tail_on_many_and_perturbed_saddle_sets():
+    """The product's board search evaluates is_valid_quad from per-pair / per-diagonal tables and
+    memoised neighbour queries; the oracle restates the reference's loops literally.  Both must give
+    the same tags on many frames and on saddle sets the chain would never produce: random subsets,
+    jittered positions, shuffled orientations (many rejected quads, ties, partial boards)."""
+    import aprilgrid_rs_amd as A
+    from oracle import oracle as O
+    synth = synth_module()
+    rng = np.random.default_rng(12)
+    n_tags = 0
+    for i in range(48):
+        w, h = [(640, 400), (800, 600), (1280, 800)][i % 3]
+        img = synth.render_frame(1000 + i, w, h)[0].numpy()
+        base = O.refined_saddle_points(img)
+        variants = [base]
+        keep = rng.random(len(base)) < 0.8
+        variants.append(base[keep])                                    # missing corners
+        j = base.copy()
+        j["x"] += rng.normal(0, 0.7, len(j)).astype(np.float32)        # geometry off by a fraction of a pixel
+        j["y"] += rng.normal(0, 0.7, len(j)).astype(np.float32)
+        variants.append(j)
+        t = base.copy()
+        flip = rng.random(len(t)) < 0.15
+        t["theta"][flip] = rng.uniform(-90, 90, int(flip.sum())).astype(np.float32)  # wrong orientations
+        variants.append(t)
+        for v, sad in enumerate(variants):
+            got = A.TagDetector.detect_tail("t36h11", sad, img)
+            ref = O.detect_tail(img, sad)
+            assert sorted(got) == sorted(ref), (i, v, len(got), len(ref))
+            for tid in ref:
+                assert bits_equal(got[tid], ref[tid]), (i, v, tid)
+            n_tags += len(ref)
+    assert n_tags > 3000
+
+
 def test_host_tail_library_entry_points_via_cpu_handle(lib):
     """The host tail itself is CPU code; exercise it here through the exported helpers that do
     not need a handle."""
