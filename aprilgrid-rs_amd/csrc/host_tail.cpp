@@ -267,44 +267,6 @@ public:
         }
     }
 
-    // try_expand_one (board.rs:153-176) as a whole: with every candidate saddle of the two pairs
-    // still unused by the board -- the usual case -- its answer is a function of the ordered quad
-    // alone, and boards grown from different seed quads ask it again and again (one table look-up
-    // instead of two pair look-ups and up to 81 quad look-ups).  An entry lists the candidates it
-    // was computed from; a board that has used one of them takes the long way.
-    struct ExpandMemo {
-        uint64_t key = 0;    // 0 = empty slot
-        int16_t cand[12];    // the candidates consulted (-1 = none)
-        int16_t out[4];
-        uint8_t found = 0;
-    };
-    ExpandMemo *expand_memo_find(uint64_t key, bool insert)
-    {
-        if (exp_tab_.empty()) exp_tab_.resize(1u << 12);
-        for (;;) {
-            const size_t mask = exp_tab_.size() - 1;
-            size_t h = (size_t)((key * 0x9E3779B97F4A7C15ull) >> 32) & mask;
-            while (exp_tab_[h].key != 0ull && exp_tab_[h].key != key) h = (h + 1) & mask;
-            if (exp_tab_[h].key == key) return &exp_tab_[h];
-            if (!insert) return nullptr;
-            if (exp_used_ * 2 >= exp_tab_.size()) {
-                std::vector<ExpandMemo> bigger(exp_tab_.size() * 2);
-                for (const ExpandMemo &e : exp_tab_)
-                    if (e.key) {
-                        size_t g = (size_t)((e.key * 0x9E3779B97F4A7C15ull) >> 32) & (bigger.size() - 1);
-                        while (bigger[g].key) g = (g + 1) & (bigger.size() - 1);
-                        bigger[g] = e;
-                    }
-                exp_tab_.swap(bigger);
-                continue;
-            }
-            exp_tab_[h].key = key;
-            ++exp_used_;
-            return &exp_tab_[h];
-        }
-    }
-    bool memo_usable() const { return pts_.size() < 32767u; }
-
 private:
     int cell_x(float x) const { return std::min(nx_ - 1, std::max(0, (int)std::floor(((double)x - ox_) / cell_))); }
     int cell_y(float y) const { return std::min(ny_ - 1, std::max(0, (int)std::floor(((double)y - oy_) / cell_))); }
@@ -331,8 +293,6 @@ private:
     std::vector<uint64_t> quad_keys_;
     std::vector<uint8_t> quad_vals_;
     size_t quad_used_ = 0;
-    std::vector<ExpandMemo> exp_tab_;
-    size_t exp_used_ = 0;
 };
 
 struct CellKey {
@@ -431,50 +391,32 @@ private:
         }
     }
 
-    // try_expand_one with find_closest_potential_saddle_idxs (board.rs:153-233): the memoised
-    // candidates of the two pairs, minus the saddles this board has already used
+    // find_closest_potential_saddle_idxs, board.rs:177-233: the memoised candidates of the pair,
+    // minus the saddles this board has already used
+    void closest_pair(int i0, int i1, int o0[3], int &n0, int o1[3], int &n1)
+    {
+        const SaddleIndex::PairCands &pc = index_.pair_candidates(i0, i1, spacing_ratio_);
+        n0 = n1 = 0;
+        for (int i = 0; i < pc.n[0]; ++i)
+            if (active_[pc.idx[0][i]]) o0[n0++] = pc.idx[0][i];
+        for (int i = 0; i < pc.n[1]; ++i)
+            if (active_[pc.idx[1][i]]) o1[n1++] = pc.idx[1][i];
+    }
+
     bool expand_one(const Quad &q, Quad &out)  // try_expand_one, board.rs:153-176
     {
-        const bool memo = index_.memo_usable();
-        const uint64_t key = 1ull + ((uint64_t)q[0] | ((uint64_t)q[1] << 16) | ((uint64_t)q[2] << 32) | ((uint64_t)q[3] << 48));
-        if (memo) {
-            if (const SaddleIndex::ExpandMemo *e = index_.expand_memo_find(key, false)) {
-                bool all_active = true;
-                for (int i = 0; i < 12 && e->cand[i] >= 0; ++i) all_active &= active_[e->cand[i]] != 0;
-                if (all_active) {  // the answer computed with all candidates available is the answer here
-                    for (int j = 0; j < 4; ++j) out[j] = e->out[j];
-                    return e->found != 0;
-                }
-            }
-        }
-        const SaddleIndex::PairCands pa = index_.pair_candidates(q[0], q[1], spacing_ratio_);  // (by value: the next call may grow the table)
-        const SaddleIndex::PairCands pb = index_.pair_candidates(q[3], q[2], spacing_ratio_);
-        int c0[3], c1[3], c2[3], c3[3], n0 = 0, n1 = 0, n2 = 0, n3 = 0;
-        for (int i = 0; i < pa.n[0]; ++i) if (active_[pa.idx[0][i]]) c0[n0++] = pa.idx[0][i];
-        for (int i = 0; i < pa.n[1]; ++i) if (active_[pa.idx[1][i]]) c1[n1++] = pa.idx[1][i];
-        for (int i = 0; i < pb.n[0]; ++i) if (active_[pb.idx[0][i]]) c3[n3++] = pb.idx[0][i];
-        for (int i = 0; i < pb.n[1]; ++i) if (active_[pb.idx[1][i]]) c2[n2++] = pb.idx[1][i];
-        bool found = false;
-        for (int i0 = 0; i0 < n0 && !found; ++i0)
-            for (int i1 = 0; i1 < n1 && !found; ++i1)
-                for (int i2 = 0; i2 < n2 && !found; ++i2)
-                    for (int i3 = 0; i3 < n3 && !found; ++i3)
+        int c0[3], c1[3], c2[3], c3[3], n0, n1, n2, n3;
+        closest_pair(q[0], q[1], c0, n0, c1, n1);
+        closest_pair(q[3], q[2], c3, n3, c2, n2);
+        for (int i0 = 0; i0 < n0; ++i0)
+            for (int i1 = 0; i1 < n1; ++i1)
+                for (int i2 = 0; i2 < n2; ++i2)
+                    for (int i3 = 0; i3 < n3; ++i3)
                         if (index_.valid_quad(c0[i0], c1[i1], c2[i2], c3[i3])) {
                             out = {c0[i0], c1[i1], c2[i2], c3[i3]};
-                            found = true;
+                            return true;
                         }
-        if (memo && n0 == pa.n[0] && n1 == pa.n[1] && n3 == pb.n[0] && n2 == pb.n[1]) {  // nothing was filtered out
-            SaddleIndex::ExpandMemo *e = index_.expand_memo_find(key, true);
-            int k = 0;
-            for (int i = 0; i < n0; ++i) e->cand[k++] = (int16_t)c0[i];
-            for (int i = 0; i < n1; ++i) e->cand[k++] = (int16_t)c1[i];
-            for (int i = 0; i < n2; ++i) e->cand[k++] = (int16_t)c2[i];
-            for (int i = 0; i < n3; ++i) e->cand[k++] = (int16_t)c3[i];
-            for (; k < 12; ++k) e->cand[k] = -1;
-            for (int j = 0; j < 4; ++j) e->out[j] = found ? (int16_t)out[j] : (int16_t)0;
-            e->found = found ? 1 : 0;
-        }
-        return found;
+        return false;
     }
 
     void expand(const CellKey &at)  // try_expand, board.rs:114-152
