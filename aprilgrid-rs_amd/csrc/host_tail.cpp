@@ -5,6 +5,10 @@
 // the reference's operand order and this file is compiled with -ffp-contract=off.
 #include "host_tail.hpp"
 
+#ifdef AGX_TAIL_PROFILE
+#include <chrono>
+#endif
+
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -12,6 +16,20 @@
 #include <unordered_map>
 
 namespace agx {
+
+#ifdef AGX_TAIL_PROFILE  // tools/tail_profile: phase timers, compiled in only for that tool
+double g_tail_prof[8] = {0};
+long g_tail_cnt[8] = {0};
+struct TailTimer {
+    int slot;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    explicit TailTimer(int s, long n = 1) : slot(s) { g_tail_cnt[s] += n; }
+    ~TailTimer() { g_tail_prof[slot] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
+#define AGX_TAIL_TIME(slot) TailTimer agx_tail_timer_##slot(slot)
+#else
+#define AGX_TAIL_TIME(slot) do { } while (0)
+#endif
 
 #include "tag_families_data.inc"
 
@@ -545,7 +563,12 @@ bool try_find_best_board(const std::vector<agx_saddle> &refined, std::vector<Qua
 {
     quads.clear();
     if (refined.empty()) return false;
-    SaddleIndex index(refined);
+    std::unique_ptr<SaddleIndex> index_holder;
+    {
+        AGX_TAIL_TIME(0);
+        index_holder.reset(new SaddleIndex(refined));
+    }
+    SaddleIndex &index = *index_holder;
     // seeds: the most populated round(theta) bin (ties -> smallest angle; the reference's
     // HashMap order makes its own tie-break arbitrary), popped from the back
     std::unordered_map<int, int> hist;
@@ -567,7 +590,11 @@ bool try_find_best_board(const std::vector<agx_saddle> &refined, std::vector<Qua
     while (!seeds.empty() && count < 30) {
         const int s0 = seeds.back();
         seeds.pop_back();
-        init_quads(refined, index, s0, cand);
+        {
+            AGX_TAIL_TIME(1);
+            init_quads(refined, index, s0, cand);
+        }
+        AGX_TAIL_TIME(2);
         for (const Quad &q : cand) {
             std::unique_ptr<Board> b(new Board(refined, index, q, 0.3f));
             if (b->score() > best_score) {
@@ -579,6 +606,7 @@ bool try_find_best_board(const std::vector<agx_saddle> &refined, std::vector<Qua
         ++count;
     }
     if (!best) return false;
+    AGX_TAIL_TIME(3);
     best->fix_missing();
     best->collect(quads);
     return true;
@@ -707,6 +735,7 @@ void detect_tail(const FamilyInfo &fam, int max_num_of_boards, std::vector<agx_s
             }
             int id;
             float corners[8];
+            AGX_TAIL_TIME(4);
             if (!decode_quad(fam, luma8, (uint32_t)width, (uint32_t)height, row_stride, qxy, id, corners)) continue;
             auto it = std::find_if(tags.begin(), tags.end(), [&](const agx_tag &t) { return t.id == (uint32_t)id; });
             if (it == tags.end()) {
