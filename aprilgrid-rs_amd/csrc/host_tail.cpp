@@ -155,6 +155,7 @@ public:
         const int n = (int)pts_.size();
         const int want = std::min(k, n);
         if (want <= 0) return 0;
+        if (want <= 3) return nearest_small(qx, qy, want, out);  // the board search's 1- and 3-NN queries
         const int cx = cell_x(qx), cy = cell_y(qy);
         cand_.clear();
         int xlo = cx, xhi = cx, ylo = cy, yhi = cy;  // examined block of cells (inclusive)
@@ -286,6 +287,61 @@ public:
     }
 
 private:
+    // nearest() for want <= 3 without the candidate vector and its sorts: the same blocks of cells are
+    // examined in the same order under the same stopping rule, the best `want` hits are kept in order
+    // (ascending distance, ties by index) while scanning -- the result is the one partial_sort gives.
+    int nearest_small(float qx, float qy, int want, Hit *out)
+    {
+        Hit best[3];
+        int nb = 0;
+        long seen = 0;
+        auto scan_small = [&](int xa, int xb, int ya, int yb) {
+            for (int y = ya; y <= yb; ++y)
+                for (int x = xa; x <= xb; ++x) {
+                    const size_t c = (size_t)y * nx_ + x;
+                    for (int t = start_[c]; t < start_[c + 1]; ++t) {
+                        const int i = items_[t];
+                        const float dx = qx - pts_[i].x, dy = qy - pts_[i].y;
+                        const Hit h{(0.0f + dx * dx) + dy * dy, i};
+                        ++seen;
+                        if (nb == want && !(h < best[nb - 1])) continue;
+                        int p = nb < want ? nb++ : nb - 1;  // slot that falls off / is appended
+                        while (p > 0 && h < best[p - 1]) {
+                            best[p] = best[p - 1];
+                            --p;
+                        }
+                        best[p] = h;
+                    }
+                }
+        };
+        const int cx = cell_x(qx), cy = cell_y(qy);
+        int xlo = cx, xhi = cx, ylo = cy, yhi = cy;  // examined block of cells (inclusive)
+        scan_small(xlo, xhi, ylo, yhi);
+        for (;;) {
+            const bool all = xlo == 0 && ylo == 0 && xhi == nx_ - 1 && yhi == ny_ - 1;
+            if (seen >= want) {
+                if (all) break;
+                double gap = 1e300;
+                if (xlo > 0) gap = std::min(gap, (double)qx - (ox_ + xlo * cell_));
+                if (xhi < nx_ - 1) gap = std::min(gap, (ox_ + (xhi + 1) * cell_) - (double)qx);
+                if (ylo > 0) gap = std::min(gap, (double)qy - (oy_ + ylo * cell_));
+                if (yhi < ny_ - 1) gap = std::min(gap, (oy_ + (yhi + 1) * cell_) - (double)qy);
+                if (gap > 0 && (double)best[want - 1].d2 < gap * gap * (1.0 - 1e-6)) break;
+            } else if (all) {
+                break;
+            }
+            const int nxlo = std::max(0, xlo - 1), nxhi = std::min(nx_ - 1, xhi + 1);
+            const int nylo = std::max(0, ylo - 1), nyhi = std::min(ny_ - 1, yhi + 1);
+            if (nylo < ylo) scan_small(nxlo, nxhi, nylo, nylo);
+            if (nyhi > yhi) scan_small(nxlo, nxhi, nyhi, nyhi);
+            if (nxlo < xlo) scan_small(nxlo, nxlo, ylo, yhi);
+            if (nxhi > xhi) scan_small(nxhi, nxhi, ylo, yhi);
+            xlo = nxlo; xhi = nxhi; ylo = nylo; yhi = nyhi;
+        }
+        for (int i = 0; i < nb; ++i) out[i] = best[i];
+        return nb;
+    }
+
     int cell_x(float x) const { return std::min(nx_ - 1, std::max(0, (int)std::floor(((double)x - ox_) / cell_))); }
     int cell_y(float y) const { return std::min(ny_ - 1, std::max(0, (int)std::floor(((double)y - oy_) / cell_))); }
     void scan(int xa, int xb, int ya, int yb, float qx, float qy)
