@@ -815,6 +815,17 @@ __global__ void __launch_bounds__(64) k_verify_seeds(ChainArgs a)
                     }
                 }
         }
+        if (a.dbg & 2048) {  // where the re-tested bits sit: by image row inside a segment's first word row, by segment
+            const bool own = lane >= 1 && lane <= VS_OWN && x < W;
+#pragma unroll
+            for (int r = 0; r < VS_ROWS; ++r)
+                if (own && (needmask & (1u << r))) {
+                    const int q = (yb0 + r) & 3, sg = (yb0 + r) >> 2;
+                    atomicAdd(&ctr.stats[16 + (sg < 3 ? sg : 3)], (uint32_t)__popc(m[r]));
+                    if (q == 0)
+                        for (int h = 0; h < 16; ++h) atomicAdd(&ctr.stats[h], (uint32_t)__popc(m[r] & (3u << (2 * h))));
+                }
+        }
         // Work list in ROW-MAJOR order (image row, then column): neighbouring lanes then re-test
         // neighbouring columns of one row, so their nine loads each fall into one or two cache lines
         // (a list in lane order -- every lane's bits one after the other -- put 64 different rows

@@ -118,7 +118,7 @@ extern "C" int agx_detect_batch(agx_detector *det, const void *frames, const voi
     std::vector<std::vector<agx_saddle>> saddles(2);  // per chunk parity: [chunk frames][cap]
     std::vector<std::vector<uint32_t>> ns(2);
     std::vector<std::vector<int>> fst(2);
-    const uint32_t cap_s = 16384;
+    uint32_t cap_s = 16384;  // saddles per frame the staging holds; grown when a chunk has a longer list
     std::atomic<int> first_bad{AGX_OK};
     int rc = AGX_OK;
     for (int c0 = 0, ci = 0; c0 < n_frames; c0 += chunk, ++ci) {
@@ -141,6 +141,17 @@ extern "C" int agx_detect_batch(agx_detector *det, const void *frames, const voi
         ns[par].assign(nf, 0);
         fst[par].assign(nf, 0);
         rc = agx_saddles_batch_fetch(det, saddles[par].data(), cap_s, ns[par].data(), fst[par].data());  // waits for the device
+        if (rc == AGX_ERR_CAPACITY) {
+            // a list longer than the staging (pure-noise frames of several megapixels; the reference's
+            // Vec has no limit): the batch is still fetchable -- make room and fetch again
+            uint32_t longest = 0;
+            for (int f = 0; f < nf; ++f) longest = std::max(longest, ns[par][f]);
+            if (longest > cap_s) {
+                cap_s = longest;
+                saddles[par].resize((size_t)nf * cap_s);
+                rc = agx_saddles_batch_fetch(det, saddles[par].data(), cap_s, ns[par].data(), fst[par].data());
+            }
+        }
         if (rc && rc != AGX_ERR_CAPACITY) break;
         rc = AGX_OK;
         for (int f = 0; f < nf; ++f) {

@@ -530,6 +530,7 @@ def test_more_than_16384_saddles_per_frame(det, oracle):
     one = det.refined_saddle_points(host[1], as_array=True)
     check_saddles(one, refs[1], "single-frame API")
     assert det.detect(host[0]) == {}  # no board in noise; the tail runs on > 16384 saddles without overflow
+    assert det.detect_batch(host, n_threads=2) == [{}, {}]  # the batch call grows its saddle staging likewise
 
 
 def test_4k_pure_noise_frame(det, oracle):
