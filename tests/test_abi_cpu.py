@@ -218,3 +218,13 @@ def test_c_client_builds_and_fails_loudly_without_a_device(tmp_path):
     else:  # the product path has no CPU fallback
         assert r.returncode == 1 and "no usable gfx950 device" in r.stderr, (r.stdout, r.stderr)
 
+
+
+def test_compiled_blur_kernel_keeps_its_pending_poll_register_alone():
+    """tools/check_isa.py on the gfx950 image inside the built library: the register that receives the
+    asynchronous scalar poll of K1 is not touched before the wait that follows it, in any variant."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_isa
+    n, problems = check_isa.check(os.path.join(ROOT, "aprilgrid-rs_amd", "libaprilgrid_amd.so"))
+    assert n == 16 and not problems, problems

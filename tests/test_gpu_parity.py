@@ -340,6 +340,40 @@ def test_unaligned_width_device_batches(det, oracle, fmt, width):
         check_saddles(res[i], ref, "%s width %d frame %d" % (fmt, width, i))
 
 
+@pytest.mark.parametrize("fmt,width,pad_bytes,gap_rows", [("L8", 300, 20, 3), ("L8", 301, 2, 0), ("L16", 250, 12, 1),
+                                                          ("RGB8", 100, 4, 2), ("RGB8", 203, 7, 0), ("L8", 1280, 256, 5)])
+def test_padded_row_and_frame_strides_on_the_device(det, oracle, fmt, width, pad_bytes, gap_rows):
+    """agx_saddles_batch_enqueue takes row_stride_bytes / frame_stride_bytes like the host entry: frames
+    cut out of a larger device allocation (padding after every row, unused rows between frames;
+    4-byte aligned pitches take the buffer-load path, odd ones the byte-gathering one) give the lists
+    of the same frames packed tightly."""
+    import torch
+    from aprilgrid_rs_amd import _ffi
+    synth = synth_module()
+    n, h = 3, 72
+    fr, _ = synth.render_batch(41, n, (width + 3) // 4 * 4, h, device="cuda", fmt=fmt)
+    tight = fr[:, :, :width].contiguous()
+    host = tight.cpu().numpy()
+    if fmt == "L16":
+        host = host.view(np.uint16)
+    bpp = {"L8": 1, "L16": 2, "RGB8": 3}[fmt]
+    row_bytes = width * bpp
+    pitch = row_bytes + pad_bytes
+    frame_stride = pitch * (h + gap_rows)
+    big = torch.full((n * frame_stride + 64,), 0xA5, dtype=torch.uint8, device="cuda")  # padding holds garbage
+    src = tight.view(torch.uint8).reshape(n, h, row_bytes)
+    for i in range(n):
+        dst = big[i * frame_stride: i * frame_stride + h * pitch].view(h, pitch)
+        dst[:, :row_bytes] = src[i]
+    torch.cuda.synchronize()
+    det.saddles_batch_enqueue_ptr(big.data_ptr(), n, width, h, pitch, frame_stride,
+                                  {"L8": _ffi.AGX_L8, "L16": _ffi.AGX_L16, "RGB8": _ffi.AGX_RGB8}[fmt])
+    res, status = det.saddles_batch_fetch()
+    assert (status == 0).all()
+    for i in range(n):
+        check_saddles(res[i], oracle.refined_saddle_points(host[i]), "%s %d pitch %d frame %d" % (fmt, width, pitch, i))
+
+
 def test_plain_c_client_of_the_abi(oracle, tmp_path):
     """examples/c_client.c (C99, no Python / torch in the process) on a synthetic board frame:
     the same counts and first saddle as the oracle."""
