@@ -57,6 +57,11 @@ struct agx_detector {
     long long cap_plane = 0;      // pixels per frame the dense planes hold
     uint32_t alloc_cand = 0, alloc_roots = 0, alloc_out = 0;
     std::vector<void *> device_allocs;
+    // AGX_REDZONE_BYTES (environment, read when the handle is created; tests only): every workspace
+    // buffer gets this many guard bytes in front and behind, filled with 0xA5; agx_debug_fetch
+    // (AGX_DBG_REDZONES) reports the guard bytes that no longer hold the pattern
+    size_t redzone = 0;
+    std::vector<size_t> alloc_bytes;  // payload bytes per entry of device_allocs
     // staging for the single-frame host API
     uint8_t *d_stage = nullptr;
     size_t stage_bytes = 0;
@@ -180,9 +185,15 @@ template <typename T>
 int dev_alloc(agx_detector *d, T *&ptr, size_t count)
 {
     void *p = nullptr;
-    HIP_TRY(d, hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)));
+    const size_t bytes = std::max<size_t>(count, 1) * sizeof(T), rz = d->redzone;
+    HIP_TRY(d, hipMalloc(&p, bytes + 2 * rz));
     d->device_allocs.push_back(p);
-    ptr = (T *)p;
+    d->alloc_bytes.push_back(bytes);
+    if (rz) {
+        HIP_TRY(d, hipMemset(p, 0xA5, rz));
+        HIP_TRY(d, hipMemset((char *)p + rz + bytes, 0xA5, rz));
+    }
+    ptr = (T *)((char *)p + rz);
     return AGX_OK;
 }
 
@@ -190,6 +201,7 @@ void free_workspace(agx_detector *d)
 {
     for (void *p : d->device_allocs) (void)hipFree(p);
     d->device_allocs.clear();
+    d->alloc_bytes.clear();
     d->cap_frames = 0;
     d->cap_plane = 0;
     d->d_ctr[0] = d->d_ctr[1] = nullptr;
@@ -511,6 +523,10 @@ int agx_detector_create(int family, const agx_params *params, int device, agx_de
     if (params) d->params = *params;
     else agx_default_params(&d->params);
     d->device = device;
+    if (const char *rz = std::getenv("AGX_REDZONE_BYTES")) {  // tests: guard bytes around every workspace buffer
+        const long v = std::atol(rz);
+        if (v > 0 && v <= (1 << 24)) d->redzone = ((size_t)v + 255) & ~(size_t)255;  // keeps the buffers' alignment
+    }
     e = hipStreamCreateWithFlags(&d->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         g_create_error = std::string("hipStreamCreateWithFlags: ") + hipGetErrorString(e);
@@ -980,6 +996,29 @@ int agx_debug_fetch(agx_detector *det, int frame, int what, void *host_out, size
         *n_items = 8;
         if (cap_bytes < 8 * sizeof(uint32_t)) return AGX_ERR_CAPACITY;
         const uint32_t v[8] = {c.flags, c.n_seeds, c.n_big, c.n_clusters, c.n_cand, c.n_roots, c.n_refined, c.n_out};
+        std::memcpy(host_out, v, sizeof v);
+        return AGX_OK;
+    }
+    case 8: {  // AGX_DBG_REDZONES: {buffers, damaged guard bytes, first damaged buffer, its offset (from the payload
+               // start, as int32), device address of buffer 0's payload (lo, hi)}
+        *n_items = 6;
+        if (cap_bytes < 6 * sizeof(uint32_t)) return AGX_ERR_CAPACITY;
+        const size_t rz = det->redzone;
+        const uint64_t first_payload = det->device_allocs.empty() ? 0ull : (uint64_t)(uintptr_t)((char *)det->device_allocs[0] + rz);
+        uint32_t v[6] = {(uint32_t)det->device_allocs.size(), 0u, 0xffffffffu, 0u, (uint32_t)first_payload, (uint32_t)(first_payload >> 32)};
+        std::vector<uint8_t> zone(rz);
+        for (size_t i = 0; rz && i < det->device_allocs.size(); ++i)
+            for (int side = 0; side < 2; ++side) {
+                const char *src = (const char *)det->device_allocs[i] + (side ? rz + det->alloc_bytes[i] : 0);
+                HIP_TRY(det, hipMemcpy(zone.data(), src, rz, hipMemcpyDeviceToHost));
+                for (size_t b = 0; b < rz; ++b)
+                    if (zone[b] != 0xA5) {
+                        if (v[1]++ == 0) {
+                            v[2] = (uint32_t)i;
+                            v[3] = (uint32_t)(int32_t)(side ? (long long)(det->alloc_bytes[i] + b) : (long long)b - (long long)rz);
+                        }
+                    }
+            }
         std::memcpy(host_out, v, sizeof v);
         return AGX_OK;
     }

@@ -354,7 +354,7 @@ class TagDetector:
         """Intermediate product of the last batch: 'blur', 'resp' (HxW f32; K1's in-register response,
         needs set_option("store_response", 1) before the batch), 'resp_recomputed', 'min' (f32),
         'centers' (cluster table sorted by first pixel), 'refined' (unfiltered saddles)."""
-        code = {"blur": 0, "resp": 1, "min": 2, "centers": 3, "refined": 4, "counters": 5, "resp_recomputed": 6, "verify_stats": 7}[what]
+        code = {"blur": 0, "resp": 1, "min": 2, "centers": 3, "refined": 4, "counters": 5, "resp_recomputed": 6, "verify_stats": 7, "redzones": 8}[what]
         n = C.c_size_t(0)
         if code in (0, 1, 6):
             assert shape is not None
@@ -365,6 +365,8 @@ class TagDetector:
             buf = np.empty(8, np.uint32)
         elif code == 7:
             buf = np.empty(20, np.uint32)
+        elif code == 8:
+            buf = np.empty(6, np.uint32)
         elif code == 3:
             buf = np.empty(1 << 20, _CLUSTER_DTYPE)
         else:
@@ -377,6 +379,9 @@ class TagDetector:
                              "refined", "saddles"], [int(v) for v in buf]))
         if code == 7:
             return buf
+        if code == 8:  # AGX_REDZONE_BYTES set when the handle was created: guard bytes around the workspace buffers
+            return {"buffers": int(buf[0]), "damaged_bytes": int(buf[1]), "first_buffer": int(np.int32(buf[2])),
+                    "first_offset": int(buf[3:4].view(np.int32)[0]), "buffer0_address": int(buf[4]) | (int(buf[5]) << 32)}
         if code in (3, 4):
             return buf[: n.value].copy()
         return buf

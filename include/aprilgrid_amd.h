@@ -288,8 +288,13 @@ int agx_profile_read(agx_detector *det, const char **names, double *ms_total, ui
 enum { AGX_DBG_BLUR = 0, AGX_DBG_RESP = 1, AGX_DBG_MIN = 2, AGX_DBG_CENTERS = 3, AGX_DBG_REFINED = 4,
        AGX_DBG_COUNTERS = 5, /* 8 x uint32: status flags (AGX_FRAME_*), flood seeds, second-tier seeds,
                                 clusters, generic-path candidates, generic-path roots, refined, saddles */
-       AGX_DBG_RESP_RECOMPUTED = 6 /* width*height floats: the response recomputed from the stored blur
-                                      plane by a separate kernel (cross-check of AGX_DBG_RESP) */ };
+       AGX_DBG_RESP_RECOMPUTED = 6, /* width*height floats: the response recomputed from the stored blur
+                                       plane by a separate kernel (cross-check of AGX_DBG_RESP) */
+       AGX_DBG_VERIFY_STATS = 7,    /* 20 x uint32: re-test statistics of K2 (debug_ablation bits 128 / 2048) */
+       AGX_DBG_REDZONES = 8 /* 6 x uint32: workspace buffers, damaged guard bytes, first damaged buffer, its byte
+                               offset from the payload start (int32), device address of buffer 0 (lo, hi: for the
+                               check of the check).  Guard bytes exist only in handles created with
+                               AGX_REDZONE_BYTES=<n> in the environment (memory-safety tests of the kernels) */ };
 typedef struct agx_cluster_info {
     uint32_t first_index, size;
     float cx, cy;
