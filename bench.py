@@ -28,7 +28,9 @@ N = 1 additionally reports, in the same line:
                  (outside the timed region; the run aborts on a mismatch);
   extra_configs  BASELINE.json configs[3] (3840x2160 x32), configs[4] (RGB8 x256, the kornia
                  front-end layout), L16 x256 and the pure-noise sensitivity row, each with its own
-                 K1 roofline and oracle check.
+                 K1 roofline and oracle check;
+  host_boundary  the PCIe-inclusive rate: the same batch handed over in pinned HOST memory, saddle
+                 lists back in host memory, batch after batch -- never `value`.
 """
 import argparse
 import json
@@ -274,6 +276,45 @@ def extra_leg(torch, A, dev, name, workload, n_frames, width, height, fmt, uniqu
     finally:
         det.close()
         del frames
+        torch.cuda.empty_cache()
+
+
+def host_boundary_leg(torch, A, dev, n_frames, width, height, steps):
+    """What the boundary delivers when it is handed HOST buffers (the reference's own call shape): the
+    batch in pinned host memory -> HBM (PCIe) -> chain -> saddle lists back in host memory, one batch
+    after the other.  Never `value`.  (Keeping a second batch's upload in flight does not help here:
+    the small result copies then queue behind that 262 MB upload on the copy engine -- 8.3 ms per batch
+    instead of 6.0.)"""
+    frames, _ = make_workload(0, n_frames, width, height, "L8", 0, False, dev)
+    host = torch.empty(frames.shape, dtype=frames.dtype, pin_memory=True)
+    host.copy_(frames)
+    det = A.TagDetector(A.TagFamily.T36H11, None, device=dev.index)
+    stage = torch.empty_like(frames)
+    try:
+        det.saddles_batch_enqueue(frames)  # workspace
+        det.saddles_batch_fetch(cap_per_frame=1024, raise_on_overflow=False)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            stage.copy_(host, non_blocking=True)
+        torch.cuda.synchronize(dev)
+        t_h2d = (time.perf_counter() - t0) / steps
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            stage.copy_(host, non_blocking=True)
+            det.saddles_batch_enqueue(stage)
+            res, status = det.saddles_batch_fetch(cap_per_frame=1024, raise_on_overflow=False)
+        t_serial = (time.perf_counter() - t0) / steps
+        assert (status == 0).all() and all(len(r) > 0 for r in res)
+        nbytes = frames.numel() * frames.element_size()
+        return {"workload": "%d frames %dx%d L8 in pinned host memory -> saddle lists in host memory" % (n_frames, width, height),
+                "h2d_GBps": round(nbytes / t_h2d / 1e9, 1), "ms_upload_alone": round(1e3 * t_h2d, 3),
+                "ms_per_batch": round(1e3 * t_serial, 3), "frames_per_s": round(n_frames / t_serial, 1),
+                "Mpix_per_s": round(n_frames * width * height / t_serial / 1e6, 1),
+                "note": "PCIe-inclusive: the upload is most of it (1 B/px over PCIe against 5.1 B/px of HBM traffic); never `value`"}
+    finally:
+        det.close()
+        del frames, stage, host
         torch.cuda.empty_cache()
 
 
@@ -547,6 +588,7 @@ def main():
                                     "tiled; ~7000 saddles per frame: worst case for the sparse stages)", 64, 1280, 800, "L8",
                                     16, True, st, args.warmup, 4 * vf),
         }
+        result["host_boundary"] = host_boundary_leg(torch, A, dev, F, W, H, 10)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
