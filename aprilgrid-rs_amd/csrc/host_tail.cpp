@@ -18,8 +18,8 @@
 namespace agx {
 
 #ifdef AGX_TAIL_PROFILE  // tools/tail_profile: phase timers, compiled in only for that tool
-double g_tail_prof[8] = {0};
-long g_tail_cnt[8] = {0};
+double g_tail_prof[12] = {0};
+long g_tail_cnt[12] = {0};
 struct TailTimer {
     int slot;
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
@@ -27,8 +27,10 @@ struct TailTimer {
     ~TailTimer() { g_tail_prof[slot] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
 };
 #define AGX_TAIL_TIME(slot) TailTimer agx_tail_timer_##slot(slot)
+#define AGX_TAIL_COUNT(slot, n) (g_tail_cnt[slot] += (long)(n))
 #else
 #define AGX_TAIL_TIME(slot) do { } while (0)
+#define AGX_TAIL_COUNT(slot, n) do { } while (0)
 #endif
 
 #include "tag_families_data.inc"
@@ -204,6 +206,7 @@ public:
     };
     const PairCands &pair_candidates(int i0, int i1, float spacing_ratio)
     {
+        AGX_TAIL_COUNT(7, 1);
         const uint64_t key = 1ull + ((uint64_t)(uint32_t)i0 << 32 | (uint64_t)(uint32_t)i1);
         if (pair_tab_.empty()) pair_tab_.resize(1u << 12);
         for (;;) {
@@ -222,6 +225,7 @@ public:
                 pair_tab_.swap(bigger);
                 continue;
             }
+            AGX_TAIL_COUNT(8, 1);
             PairCands e;
             e.key = key;
             const agx_saddle &s0 = pts_[i0], &s1 = pts_[i1];
@@ -232,7 +236,7 @@ public:
             for (int side = 0; side < 2; ++side) {
                 const agx_saddle &anchor = side ? s1 : s0;
                 Hit hits[3];
-                const int m = nearest(anchor.x + v10x * ratio0, anchor.y + v10y * ratio0, 3, hits);
+                const int m = nearest_small(anchor.x + v10x * ratio0, anchor.y + v10y * ratio0, std::min(3, (int)pts_.size()), hits, radius_sq);
                 e.n[side] = 0;
                 for (int i = 0; i < m; ++i)
                     if (hits[i].d2 <= radius_sq && theta_distance_degree(anchor.theta, pts_[hits[i].idx].theta) < 5.0f)
@@ -249,6 +253,7 @@ public:
     // keyed by the four indices (16 bits each; larger sets are evaluated directly).
     bool valid_quad(int i0, int i1, int i2, int i3)
     {
+        AGX_TAIL_COUNT(6, 1);
         if (pts_.size() >= 65535u) return is_valid_quad(pts_[i0], pts_[i1], pts_[i2], pts_[i3]);
         const uint64_t key = 1ull + ((uint64_t)i0 | ((uint64_t)i1 << 16) | ((uint64_t)i2 << 32) | ((uint64_t)i3 << 48));  // != 0
         if (quad_keys_.empty()) {
@@ -278,6 +283,7 @@ public:
                 quad_vals_.swap(ov);
                 continue;
             }
+            AGX_TAIL_COUNT(9, 1);
             const bool v = is_valid_quad(pts_[i0], pts_[i1], pts_[i2], pts_[i3]);
             quad_keys_[h] = key;
             quad_vals_[h] = v ? 1 : 0;
@@ -290,7 +296,10 @@ private:
     // nearest() for want <= 3 without the candidate vector and its sorts: the same blocks of cells are
     // examined in the same order under the same stopping rule, the best `want` hits are kept in order
     // (ascending distance, ties by index) while scanning -- the result is the one partial_sort gives.
-    int nearest_small(float qx, float qy, int want, Hit *out)
+    // max_d2 >= 0: the caller keeps only hits with d2 <= max_d2 (find_closest_potential_saddle_idxs,
+    // board.rs:207-213), so the search also stops once everything unexamined lies beyond that radius --
+    // the hits within the radius, and their order, are the same as those of the unbounded search.
+    int nearest_small(float qx, float qy, int want, Hit *out, float max_d2 = -1.0f)
     {
         Hit best[3];
         int nb = 0;
@@ -319,16 +328,15 @@ private:
         scan_small(xlo, xhi, ylo, yhi);
         for (;;) {
             const bool all = xlo == 0 && ylo == 0 && xhi == nx_ - 1 && yhi == ny_ - 1;
-            if (seen >= want) {
-                if (all) break;
+            if (all) break;
+            if (seen >= want || max_d2 >= 0.0f) {
                 double gap = 1e300;
                 if (xlo > 0) gap = std::min(gap, (double)qx - (ox_ + xlo * cell_));
                 if (xhi < nx_ - 1) gap = std::min(gap, (ox_ + (xhi + 1) * cell_) - (double)qx);
                 if (ylo > 0) gap = std::min(gap, (double)qy - (oy_ + ylo * cell_));
                 if (yhi < ny_ - 1) gap = std::min(gap, (oy_ + (yhi + 1) * cell_) - (double)qy);
-                if (gap > 0 && (double)best[want - 1].d2 < gap * gap * (1.0 - 1e-6)) break;
-            } else if (all) {
-                break;
+                if (seen >= want && gap > 0 && (double)best[want - 1].d2 < gap * gap * (1.0 - 1e-6)) break;
+                if (max_d2 >= 0.0f && gap > 0 && (double)max_d2 < gap * gap * (1.0 - 1e-6)) break;  // nothing left within the radius
             }
             const int nxlo = std::max(0, xlo - 1), nxhi = std::min(nx_ - 1, xhi + 1);
             const int nylo = std::max(0, ylo - 1), nyhi = std::min(ny_ - 1, yhi + 1);
@@ -338,6 +346,8 @@ private:
             if (nxhi > xhi) scan_small(nxhi, nxhi, ylo, yhi);
             xlo = nxlo; xhi = nxhi; ylo = nylo; yhi = nyhi;
         }
+        AGX_TAIL_COUNT(10, seen);
+        AGX_TAIL_COUNT(11, (xhi - xlo + 1) * (yhi - ylo + 1));
         for (int i = 0; i < nb; ++i) out[i] = best[i];
         return nb;
     }
@@ -380,22 +390,68 @@ struct CellKeyHash {
     }
 };
 
+struct BoardCell {
+    CellKey key;
+    bool found;
+    Quad quad;
+};
+
+// What a board owns.  try_find_best_board builds a board for every candidate quad of up to 30 seeds
+// (several hundred per frame, most of them dead after a step or two), so the storage is recycled: a
+// board undoes exactly what the previous user of the storage touched instead of allocating and
+// clearing the used-saddle mask and the cell grid again.
+struct BoardStorage {
+    static constexpr int kGridR = 24, kGridN = 2 * kGridR + 1;
+    std::vector<uint8_t> active;    // board.rs:30-37 active_idxs: 1 = saddle not used by this board yet
+    std::vector<int> deactivated;   // indices cleared in `active`
+    std::vector<int16_t> grid;      // cell coordinates near the seed -> index into cells (-1 = none)
+    std::vector<BoardCell> cells;   // insertion order
+    std::unordered_map<CellKey, size_t, CellKeyHash> lookup;  // cells farther than kGridR from the seed
+
+    static bool in_grid(const CellKey &k) { return k.x >= -kGridR && k.x <= kGridR && k.y >= -kGridR && k.y <= kGridR; }
+    static size_t grid_at(const CellKey &k) { return (size_t)((k.y + kGridR) * kGridN + (k.x + kGridR)); }
+    void begin(size_t n_saddles)
+    {
+        if (active.size() != n_saddles) active.assign(n_saddles, 1);
+        else
+            for (int i : deactivated) active[i] = 1;
+        deactivated.clear();
+        if (grid.empty()) grid.assign((size_t)kGridN * kGridN, (int16_t)-1);
+        else
+            for (const BoardCell &c : cells)
+                if (in_grid(c.key)) grid[grid_at(c.key)] = (int16_t)-1;
+        cells.clear();
+        if (!lookup.empty()) lookup.clear();
+    }
+    void use(int saddle)
+    {
+        active[saddle] = 0;
+        deactivated.push_back(saddle);
+    }
+};
+
 // board::Board, src/board.rs:18-235.  Cells are kept in insertion order (the reference's
 // HashMap iteration order is unspecified).
 class Board {
 public:
-    Board(const std::vector<agx_saddle> &refined, SaddleIndex &index, const Quad &seed, float spacing_ratio)
-        : refined_(refined), index_(index), active_(refined.size(), 1), spacing_ratio_(spacing_ratio)
+    Board(const std::vector<agx_saddle> &refined, SaddleIndex &index, const Quad &seed, float spacing_ratio, BoardStorage &st)
+        : refined_(refined), index_(index), st_(st), spacing_ratio_(spacing_ratio)
     {
-        for (int i = 1; i < 4; ++i) active_[seed[i]] = 0;  // board.rs:35-37
+        st_.begin(refined.size());
+        for (int i = 1; i < 4; ++i) st_.use(seed[i]);  // board.rs:35-37
         put({0, 0}, true, seed);
         expand({0, 0});
+    }
+    // a finished board again, from the storage it was built in (for try_fix_missing / all_tag_indexes)
+    Board(const std::vector<agx_saddle> &refined, SaddleIndex &index, BoardStorage &st, unsigned score)
+        : refined_(refined), index_(index), st_(st), spacing_ratio_(0.0f), score_(score)
+    {
     }
     unsigned score() const { return score_; }
 
     void collect(std::vector<Quad> &out) const  // all_tag_indexes, board.rs:49-51
     {
-        for (const Cell &c : cells_)
+        for (const Cell &c : st_.cells)
             if (c.found) out.push_back(c.quad);
     }
 
@@ -403,7 +459,7 @@ public:
     {
         struct Fix { CellKey a, b; };
         std::vector<Fix> fixes;
-        for (const Cell &c : cells_) {
+        for (const Cell &c : st_.cells) {
             if (c.found) continue;
             const CellKey b0{c.key.x + 1, c.key.y}, b1{c.key.x - 1, c.key.y};
             const CellKey b2{c.key.x, c.key.y + 1}, b3{c.key.x, c.key.y - 1};
@@ -431,37 +487,30 @@ public:
     }
 
 private:
-    struct Cell {
-        CellKey key;
-        bool found;
-        Quad quad;
-    };
+    typedef BoardCell Cell;
 
     // cell coordinates near the seed live in a direct-mapped grid, anything farther in the map
-    static constexpr int kGridR = 24, kGridN = 2 * kGridR + 1;
     int find_cell(const CellKey &k) const
     {
-        if (k.x >= -kGridR && k.x <= kGridR && k.y >= -kGridR && k.y <= kGridR)
-            return grid_[(k.y + kGridR) * kGridN + (k.x + kGridR)];
-        auto it = lookup_.find(k);
-        return it == lookup_.end() ? -1 : (int)it->second;
+        if (BoardStorage::in_grid(k)) return st_.grid[BoardStorage::grid_at(k)];
+        auto it = st_.lookup.find(k);
+        return it == st_.lookup.end() ? -1 : (int)it->second;
     }
     const Cell *get(const CellKey &k) const
     {
         const int i = find_cell(k);
-        return i < 0 ? nullptr : &cells_[i];
+        return i < 0 ? nullptr : &st_.cells[i];
     }
     void put(const CellKey &k, bool found, const Quad &q)
     {
         const int i = find_cell(k);
         if (i < 0) {
-            if (k.x >= -kGridR && k.x <= kGridR && k.y >= -kGridR && k.y <= kGridR)
-                grid_[(k.y + kGridR) * kGridN + (k.x + kGridR)] = (int16_t)cells_.size();
-            else lookup_.emplace(k, cells_.size());
-            cells_.push_back({k, found, q});
+            if (BoardStorage::in_grid(k)) st_.grid[BoardStorage::grid_at(k)] = (int16_t)st_.cells.size();
+            else st_.lookup.emplace(k, st_.cells.size());
+            st_.cells.push_back({k, found, q});
         } else {
-            cells_[i].found = found;
-            cells_[i].quad = q;
+            st_.cells[i].found = found;
+            st_.cells[i].quad = q;
         }
     }
 
@@ -472,9 +521,9 @@ private:
         const SaddleIndex::PairCands &pc = index_.pair_candidates(i0, i1, spacing_ratio_);
         n0 = n1 = 0;
         for (int i = 0; i < pc.n[0]; ++i)
-            if (active_[pc.idx[0][i]]) o0[n0++] = pc.idx[0][i];
+            if (st_.active[pc.idx[0][i]]) o0[n0++] = pc.idx[0][i];
         for (int i = 0; i < pc.n[1]; ++i)
-            if (active_[pc.idx[1][i]]) o1[n1++] = pc.idx[1][i];
+            if (st_.active[pc.idx[1][i]]) o1[n1++] = pc.idx[1][i];
     }
 
     bool expand_one(const Quad &q, Quad &out)  // try_expand_one, board.rs:153-176
@@ -509,7 +558,7 @@ private:
             if (expand_one(qs, nq)) {
                 Quad v;
                 for (int j = 0; j < 4; ++j) v[(j + i) & 3] = nq[j];
-                for (int j = 0; j < 4; ++j) active_[v[j]] = 0;
+                for (int j = 0; j < 4; ++j) st_.use(v[j]);
                 score_ += 1;
                 put(next, true, v);
                 expand(next);
@@ -521,12 +570,9 @@ private:
 
     const std::vector<agx_saddle> &refined_;
     SaddleIndex &index_;
-    std::vector<uint8_t> active_;
+    BoardStorage &st_;
     float spacing_ratio_;
     unsigned score_ = 1;
-    std::vector<Cell> cells_;
-    std::unordered_map<CellKey, size_t, CellKeyHash> lookup_;
-    std::vector<int16_t> grid_ = std::vector<int16_t>((size_t)kGridN * kGridN, (int16_t)-1);
 };
 
 // init_quads, src/detector.rs:543-586.  The reference tests every (s1, d0, d1) combination with
@@ -640,7 +686,8 @@ bool try_find_best_board(const std::vector<agx_saddle> &refined, std::vector<Qua
         if ((int)std::round(refined[i].theta) == best_angle) seeds.push_back((int)i);
 
     unsigned best_score = 0;
-    std::unique_ptr<Board> best;
+    BoardStorage storage[2];  // the best board so far keeps one, the next candidate is built in the other
+    int cur = 0, best_at = -1;
     std::vector<Quad> cand;
     int count = 0;
     while (!seeds.empty() && count < 30) {
@@ -651,20 +698,23 @@ bool try_find_best_board(const std::vector<agx_saddle> &refined, std::vector<Qua
             init_quads(refined, index, s0, cand);
         }
         AGX_TAIL_TIME(2);
+        AGX_TAIL_COUNT(5, cand.size());
         for (const Quad &q : cand) {
-            std::unique_ptr<Board> b(new Board(refined, index, q, 0.3f));
-            if (b->score() > best_score) {
-                best_score = b->score();
-                best = std::move(b);
+            const Board b(refined, index, q, 0.3f, storage[cur]);
+            if (b.score() > best_score) {
+                best_score = b.score();
+                best_at = cur;
+                cur ^= 1;
             }
         }
         if (best_score >= 36) break;
         ++count;
     }
-    if (!best) return false;
+    if (best_at < 0) return false;
     AGX_TAIL_TIME(3);
-    best->fix_missing();
-    best->collect(quads);
+    Board best(refined, index, storage[best_at], best_score);
+    best.fix_missing();
+    best.collect(quads);
     return true;
 }
 

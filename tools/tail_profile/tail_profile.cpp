@@ -6,13 +6,14 @@
 //   /tmp/tail_profile /tmp/case.bin
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "aprilgrid-rs_amd/csrc/host_tail.hpp"
 
 namespace agx {
-extern double g_tail_prof[8];
-extern long g_tail_cnt[8];
+extern double g_tail_prof[12];
+extern long g_tail_cnt[12];
 }
 using namespace agx;
 
@@ -30,16 +31,16 @@ int main(int argc, char **argv)
     FamilyInfo fam;
     family_info(AGX_T36H11, fam);
     std::vector<agx_tag> tags;
-    const int reps = 20;
+    const int reps = getenv("REPS") ? atoi(getenv("REPS")) : 20;
     double best = 1e9;
     for (int rep = 0; rep < reps; ++rep) {
         const auto t0 = std::chrono::steady_clock::now();
-        detect_tail(fam, 2, s, g.data(), w, h, (size_t)w, tags);
+        detect_tail(fam, getenv("BOARDS") ? atoi(getenv("BOARDS")) : 2, s, g.data(), w, h, (size_t)w, tags);
         best = std::min(best, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3);
     }
     printf("%d saddles -> %zu tags; best %.3f ms per call\n", n, tags.size(), best);
-    const char *names[8] = {"index build", "init_quads", "boards (expand)", "fix_missing + collect", "decode", "", "", ""};
-    for (int i = 0; i < 5; ++i)
+    const char *names[12] = {"index build", "init_quads", "boards (expand)", "fix_missing + collect", "decode", "boards built", "valid_quad look-ups", "pair look-ups", "pair misses (2 x 3-NN each)", "valid_quad misses", "points scanned by small k-NN", "cells scanned by small k-NN"};
+    for (int i = 0; i < 12; ++i)
         printf("  %-22s %8.3f ms per call   (%ld per call)\n", names[i], g_tail_prof[i] * 1e3 / reps, g_tail_cnt[i] / reps);
     return 0;
 }
