@@ -70,6 +70,7 @@ SYMBOLS = {
     "agx_detect_tail": (C.c_int, [C.c_int, C.POINTER(Params), _P, C.c_uint32, _P, C.c_int, C.c_int, C.c_size_t, _P,
                                   C.c_uint32, C.POINTER(C.c_uint32)]),
     "agx_luma8": (C.c_int, [_P, C.c_int, C.c_int, C.c_size_t, C.c_int, _P]),
+    "agx_debug_angle_pairs": (C.c_int, [_P, C.c_size_t, _P, _P, _P]),
     "agx_profile_enable": (C.c_int, [_P, C.c_int]),
     "agx_profile_reset": (C.c_int, [_P]),
     "agx_profile_read": (C.c_int, [_P, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),

@@ -809,6 +809,13 @@ static int refetch_single(agx_detector *det, agx_saddle *out, uint32_t cap, uint
     return AGX_OK;
 }
 
+int agx_debug_angle_pairs(const float *vectors, size_t n, float *exact, float *approx, uint8_t *has_approx)
+{
+    if (!vectors || !exact || !approx || !has_approx) return AGX_ERR_ARG;
+    debug_angle_pairs(vectors, n, exact, approx, has_approx);
+    return AGX_OK;
+}
+
 int agx_luma8(const void *pixels, int width, int height, size_t row_stride_bytes, int format, uint8_t *out)
 {
     if (!pixels || !out || width <= 0 || height <= 0) return AGX_ERR_ARG;

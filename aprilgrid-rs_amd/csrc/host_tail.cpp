@@ -62,7 +62,73 @@ static inline float dot2(float ax, float ay, float bx, float by) { return ax * b
 
 float angle_degree(float v0x, float v0y, float v1x, float v1y)
 {
+    AGX_TAIL_COUNT(10, 1);
     return std::atan2(v1y * v0x - v1x * v0y, v0x * v1x + v0y * v1y) * 180.0f / kPi;
+}
+
+// The board search compares angles with fixed thresholds (|a0 - a2| > 10, 60 <= |a| <= 120) tens of
+// thousands of times per frame, and atan2f is a third of its time.  Almost every comparison is far
+// from its threshold, so it is decided from an approximation with a KNOWN error bound; only inside the
+// guard band around the threshold is the reference's own expression (angle_degree) evaluated, and it
+// alone decides there.  The decisions are therefore exactly the reference's.
+//   approximation: atan(z) on [0, 1] by an odd polynomial of degree 13 in binary64 (max error 1.5e-5
+//   degrees, tools/fit_atan.py), octant reduction, one rounding to f32;  angle_degree itself is within
+//   1e-4 degrees of the true angle (atan2f <= 1 ulp, two f32 roundings, kPi);  so |approximation -
+//   angle_degree| < 2e-4 degrees.  kAngleBand is 25 times that; agx_debug_angle_pair + the CPU suite
+//   check the bound on millions of inputs.
+constexpr float kAngleBand = 0.005f;
+struct LazyAngle {
+    float ax, ay, bx, by;  // angle_degree(ax, ay, bx, by)
+    float approx = 0.0f, exact_v = 0.0f;
+    uint8_t has_approx = 0, has_exact = 0, is_set = 0;
+    void set(float v0x, float v0y, float v1x, float v1y)
+    {
+        ax = v0x; ay = v0y; bx = v1x; by = v1y;
+        is_set = 1;
+        has_exact = 0;
+        const float yf = v1y * v0x - v1x * v0y, xf = v0x * v1x + v0y * v1y;  // what angle_degree hands to atan2f
+        const double ya = std::fabs((double)yf), xa = std::fabs((double)xf);
+        const double mx = xa > ya ? xa : ya, mn = xa > ya ? ya : xa;
+        // zero, infinite or NaN operands and the sign-of-zero cases of atan2: the exact expression only
+        has_approx = (mx > 0.0 && mx < 1e300 && yf != 0.0f) ? 1 : 0;
+        if (!has_approx) return;
+        const double z = mn / mx, z2 = z * z;
+        double a = z * (0.9999961115936159 + z2 * (-0.3331736811416821 + z2 * (0.19807815786497726 + z2 * (-0.13233342317278815 +
+                   z2 * (0.07962366987276416 + z2 * (-0.03360421491419842 + z2 * 0.006811790682567682))))));
+        if (ya > xa) a = 1.5707963267948966 - a;
+        if (xf < 0.0f) a = 3.141592653589793 - a;
+        if (yf < 0.0f) a = -a;
+        approx = (float)(a * 57.29577951308232);
+    }
+    float exact()
+    {
+        if (!has_exact) {
+            exact_v = angle_degree(ax, ay, bx, by);
+            has_exact = 1;
+        }
+        return exact_v;
+    }
+};
+// fabs(p - q) > limit, p and q being angle_degree values
+static inline bool angles_differ_by_more_than(LazyAngle &p, LazyAngle &q, float limit)
+{
+    if (p.has_approx && q.has_approx) {
+        const float d = std::fabs(p.approx - q.approx);
+        if (d > limit + 2.0f * kAngleBand) return true;
+        if (d < limit - 2.0f * kAngleBand) return false;
+    }
+    return std::fabs(p.exact() - q.exact()) > limit;
+}
+// lo <= fabs(p) <= hi
+static inline bool abs_angle_within(LazyAngle &p, float lo, float hi)
+{
+    if (p.has_approx) {
+        const float a = std::fabs(p.approx);
+        if (a > lo + kAngleBand && a < hi - kAngleBand) return true;
+        if (a < lo - kAngleBand || a > hi + kAngleBand) return false;
+    }
+    const float a = std::fabs(p.exact());
+    return a >= lo && a <= hi;
 }
 
 // is_valid_quad (saddle.rs:17-67) in three parts, so that init_quads can hoist the two that do not
@@ -76,12 +142,16 @@ static inline bool quad_part0(const agx_saddle &d0, const agx_saddle &d1)
 {
     return !(theta_distance_degree(d0.theta, d1.theta) > 5.0f);
 }
+static inline bool quad_part1_dir(const agx_saddle &s0, const agx_saddle &s1, float cos_th, float sin_th)
+{
+    LazyAngle ang;  // (cos_th, sin_th) = (cos, sin)(s0.theta / 180 * pi), the same floats for every s1
+    ang.set(s1.x - s0.x, s1.y - s0.y, cos_th, sin_th);
+    return abs_angle_within(ang, 60.0f, 120.0f);
+}
 static inline bool quad_part1(const agx_saddle &s0, const agx_saddle &s1)
 {
-    const float v02x = s1.x - s0.x, v02y = s1.y - s0.y;
     const float th = s0.theta / 180.0f * kPi;
-    const float ang = std::fabs(angle_degree(v02x, v02y, std::cos(th), std::sin(th)));
-    return ang >= 60.0f && ang <= 120.0f;
+    return quad_part1_dir(s0, s1, std::cos(th), std::sin(th));
 }
 static inline bool quad_rest(const agx_saddle &s0, const agx_saddle &d0, const agx_saddle &s1, const agx_saddle &d1)
 {
@@ -93,13 +163,26 @@ static inline bool quad_rest(const agx_saddle &s0, const agx_saddle &d0, const a
     const float v23x = d1.x - s1.x, v23y = d1.y - s1.y;
     if (cross2(v01x, v01y, v12x, v12y) * cross2(v12x, v12y, v23x, v23y) < 0.0f) return false;
     const float v30x = s0.x - d1.x, v30y = s0.y - d1.y;
-    const float a0 = angle_degree(v01x, v01y, v12x, v12y);
-    const float a1 = angle_degree(v12x, v12y, v23x, v23y);
-    const float a2 = angle_degree(v23x, v23y, v30x, v30y);
-    const float a3 = angle_degree(v30x, v30y, v01x, v01y);
-    if (std::fabs(a0 - a2) > 10.0f || std::fabs(a1 - a3) > 10.0f) return false;
+    LazyAngle a0, a1, a2, a3;
+    a0.set(v01x, v01y, v12x, v12y);
+    a2.set(v23x, v23y, v30x, v30y);
+    if (angles_differ_by_more_than(a0, a2, 10.0f)) return false;
+    a1.set(v12x, v12y, v23x, v23y);
+    a3.set(v30x, v30y, v01x, v01y);
+    if (angles_differ_by_more_than(a1, a3, 10.0f)) return false;
     if (dot2(v01x, v01y, v02x, v02y) < 0.0f || dot2(v03x, v03y, v02x, v02y) < 0.0f) return false;
     return true;
+}
+
+void debug_angle_pairs(const float *v, size_t n, float *exact, float *approx, uint8_t *has_approx)
+{
+    for (size_t i = 0; i < n; ++i) {
+        LazyAngle a;
+        a.set(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+        exact[i] = a.exact();
+        approx[i] = a.approx;
+        has_approx[i] = a.has_approx;
+    }
 }
 
 bool is_valid_quad(const agx_saddle &s0, const agx_saddle &d0, const agx_saddle &s1, const agx_saddle &d1)
@@ -253,7 +336,6 @@ public:
     // keyed by the four indices (16 bits each; larger sets are evaluated directly).
     bool valid_quad(int i0, int i1, int i2, int i3)
     {
-        AGX_TAIL_COUNT(6, 1);
         if (pts_.size() >= 65535u) return is_valid_quad(pts_[i0], pts_[i1], pts_[i2], pts_[i3]);
         const uint64_t key = 1ull + ((uint64_t)i0 | ((uint64_t)i1 << 16) | ((uint64_t)i2 << 32) | ((uint64_t)i3 << 48));  // != 0
         if (quad_keys_.empty()) {
@@ -346,8 +428,7 @@ private:
             if (nxhi > xhi) scan_small(nxhi, nxhi, ylo, yhi);
             xlo = nxlo; xhi = nxhi; ylo = nylo; yhi = nyhi;
         }
-        AGX_TAIL_COUNT(10, seen);
-        AGX_TAIL_COUNT(11, (xhi - xlo + 1) * (yhi - ylo + 1));
+        AGX_TAIL_COUNT(11, seen);
         for (int i = 0; i < nb; ++i) out[i] = best[i];
         return nb;
     }
@@ -591,7 +672,11 @@ void init_quads(const std::vector<agx_saddle> &refined, SaddleIndex &index, int 
     out.clear();
     const agx_saddle &s0 = refined[s0_idx];
     SaddleIndex::Hit near[50];
-    const int m = index.nearest(s0.x, s0.y, 50, near);
+    int m;
+    {
+        AGX_TAIL_TIME(6);
+        m = index.nearest(s0.x, s0.y, 50, near);
+    }
     int same[50], diff[50];
     int ns = 0, nd = 0;
     for (int i = 1; i < m; ++i) {
@@ -608,21 +693,31 @@ void init_quads(const std::vector<agx_saddle> &refined, SaddleIndex &index, int 
         v0x[d] = p.x - s0.x; v0y[d] = p.y - s0.y;
         v30x[d] = s0.x - p.x; v30y[d] = s0.y - p.y;
     }
-    uint8_t pair_ok[50 * 50];
-    float a3v[50 * 50];
-    uint8_t a3_set[50 * 50];
+    // the (d0, d1) combinations that pass part 0, in the reference's order (a < b, a ascending, then b):
+    // the loops over s1 below walk this list instead of all nd * (nd - 1) / 2 pairs
+    uint8_t pa[50 * 49 / 2], pb[50 * 49 / 2];
+    static thread_local std::vector<LazyAngle> a3_store;  // a3 = angle(v30, v01) per listed pair, on demand
+    int n_pairs = 0;
     for (int a = 0; a < nd; ++a)
-        for (int b = a + 1; b < nd; ++b) {
-            pair_ok[a * 50 + b] = quad_part0(refined[diff[a]], refined[diff[b]]);
-            a3_set[a * 50 + b] = 0;
-        }
+        for (int b = a + 1; b < nd; ++b)
+            if (quad_part0(refined[diff[a]], refined[diff[b]])) {
+                pa[n_pairs] = (uint8_t)a;
+                pb[n_pairs] = (uint8_t)b;
+                ++n_pairs;
+            }
+    if (!n_pairs) return;
+    a3_store.assign((size_t)n_pairs, LazyAngle());
+    LazyAngle *a3v = a3_store.data();
+    const float th0 = s0.theta / 180.0f * kPi;
+    const float cos0 = std::cos(th0), sin0 = std::sin(th0);  // part 1's direction of s0, once instead of per s1
     for (int si = 0; si < ns; ++si) {
         const int s1_idx = same[si];
         const agx_saddle &s1 = refined[s1_idx];
-        if (!quad_part1(s0, s1)) continue;
+        if (!quad_part1_dir(s0, s1, cos0, sin0)) continue;
         const float v02x = s1.x - s0.x, v02y = s1.y - s0.y;
-        float cA[50], cB[50], c01[50], v12x[50], v12y[50], v23x[50], v23y[50], a0v[50], a2v[50];
-        uint8_t dok[50], a0_set[50], a2_set[50];
+        float cA[50], cB[50], c01[50], v12x[50], v12y[50], v23x[50], v23y[50];
+        LazyAngle a0v[50], a2v[50];
+        uint8_t dok[50];
         for (int d = 0; d < nd; ++d) {
             const agx_saddle &p = refined[diff[d]];
             cA[d] = cross2(v0x[d], v0y[d], v02x, v02y);   // c0 with d as d0 (also the winding test)
@@ -631,23 +726,21 @@ void init_quads(const std::vector<agx_saddle> &refined, SaddleIndex &index, int 
             v12x[d] = s1.x - p.x; v12y[d] = s1.y - p.y;   // d as d0
             v23x[d] = p.x - s1.x; v23y[d] = p.y - s1.y;   // d as d1
             c01[d] = cross2(v0x[d], v0y[d], v12x[d], v12y[d]);
-            a0_set[d] = a2_set[d] = 0;
         }
-        for (int a = 0; a < nd; ++a) {
-            if (!dok[a]) continue;
-            for (int b = a + 1; b < nd; ++b) {
-                if (!pair_ok[a * 50 + b] || !dok[b]) continue;
-                if (cA[a] * cB[b] < 0.0f) continue;
-                if (c01[a] * cross2(v12x[a], v12y[a], v23x[b], v23y[b]) < 0.0f) continue;
-                if (!a0_set[a]) { a0v[a] = angle_degree(v0x[a], v0y[a], v12x[a], v12y[a]); a0_set[a] = 1; }
-                if (!a2_set[b]) { a2v[b] = angle_degree(v23x[b], v23y[b], v30x[b], v30y[b]); a2_set[b] = 1; }
-                if (std::fabs(a0v[a] - a2v[b]) > 10.0f) continue;
-                if (!a3_set[a * 50 + b]) { a3v[a * 50 + b] = angle_degree(v30x[b], v30y[b], v0x[a], v0y[a]); a3_set[a * 50 + b] = 1; }
-                const float a1 = angle_degree(v12x[a], v12y[a], v23x[b], v23y[b]);
-                if (std::fabs(a1 - a3v[a * 50 + b]) > 10.0f) continue;
-                if (cA[a] > 0.0f) out.push_back({s0_idx, diff[a], s1_idx, diff[b]});
-                else out.push_back({s0_idx, diff[b], s1_idx, diff[a]});
-            }
+        for (int pi = 0; pi < n_pairs; ++pi) {
+            const int a = pa[pi], b = pb[pi];
+            if (!dok[a] || !dok[b]) continue;
+            if (cA[a] * cB[b] < 0.0f) continue;
+            if (c01[a] * cross2(v12x[a], v12y[a], v23x[b], v23y[b]) < 0.0f) continue;
+            if (!a0v[a].is_set) a0v[a].set(v0x[a], v0y[a], v12x[a], v12y[a]);
+            if (!a2v[b].is_set) a2v[b].set(v23x[b], v23y[b], v30x[b], v30y[b]);
+            if (angles_differ_by_more_than(a0v[a], a2v[b], 10.0f)) continue;
+            if (!a3v[pi].is_set) a3v[pi].set(v30x[b], v30y[b], v0x[a], v0y[a]);
+            LazyAngle a1;
+            a1.set(v12x[a], v12y[a], v23x[b], v23y[b]);
+            if (angles_differ_by_more_than(a1, a3v[pi], 10.0f)) continue;
+            if (cA[a] > 0.0f) out.push_back({s0_idx, diff[a], s1_idx, diff[b]});
+            else out.push_back({s0_idx, diff[b], s1_idx, diff[a]});
         }
     }
 }

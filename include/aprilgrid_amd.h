@@ -299,6 +299,11 @@ typedef struct agx_cluster_info {
     uint32_t first_index, size;
     float cx, cy;
 } agx_cluster_info;
+/* Test hook of the host tail: for n pairs of vectors (v0x, v0y, v1x, v1y) the reference's
+ * angle(v0, v1) in degrees (math_util.rs:27-33) and the bounded approximation the board search uses
+ * to decide threshold comparisons that are not close (csrc/host_tail.cpp, LazyAngle); has_approx[i] = 0
+ * where the approximation is not used (zero / non-finite operands).  The CPU suite checks the bound. */
+int agx_debug_angle_pairs(const float *vectors, size_t n, float *exact, float *approx, uint8_t *has_approx);
 int agx_debug_fetch(agx_detector *det, int frame, int what, void *host_out, size_t cap_bytes,
                     size_t *n_items);
 

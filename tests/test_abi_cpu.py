@@ -228,3 +228,36 @@ def test_compiled_blur_kernel_keeps_its_pending_poll_register_alone():
     import check_isa
     n, problems = check_isa.check(os.path.join(ROOT, "aprilgrid-rs_amd", "libaprilgrid_amd.so"))
     assert n == 16 and not problems, problems
+
+
+def test_bounded_angle_approximation_of_the_board_search(lib):
+    """The host tail decides `|a0 - a2| > 10` and `60 <= |a| <= 120` from a polynomial approximation
+    of atan2 wherever the value is farther than its guard band (0.005 degrees per angle) from the
+    threshold, and from the reference's expression inside the band.  That is exact as long as the
+    approximation stays within the band of angle_degree: checked here on random, axis-aligned, nearly
+    parallel / antiparallel, tiny and huge vectors."""
+    rng = np.random.default_rng(4)
+    n = 1 << 20
+    parts = [rng.normal(0, 100, (n, 4)), rng.uniform(-2000, 2000, (n, 4)),
+             rng.normal(0, 1, (n, 4)) * 10.0 ** rng.uniform(-18, 18, (n, 1))]
+    a = rng.uniform(-np.pi, np.pi, n)
+    eps = rng.normal(0, 1e-4, n) * rng.integers(0, 2, n)
+    flip = rng.integers(0, 2, n) * np.pi
+    r0, r1 = rng.uniform(0.1, 500, n), rng.uniform(0.1, 500, n)
+    parts.append(np.stack([r0 * np.cos(a), r0 * np.sin(a), r1 * np.cos(a + eps + flip), r1 * np.sin(a + eps + flip)], 1))
+    q = rng.integers(-3, 4, (n, 4)).astype(np.float64)  # lattice vectors: exact 0 / 45 / 90 / 180 degrees, zero vectors
+    parts.append(q)
+    v = np.ascontiguousarray(np.concatenate(parts), np.float32)
+    m = len(v)
+    exact, approx, has = np.zeros(m, np.float32), np.zeros(m, np.float32), np.zeros(m, np.uint8)
+    assert lib.agx_debug_angle_pairs(v.ctypes.data, m, exact.ctypes.data, approx.ctypes.data, has.ctypes.data) == 0
+    ref = np.degrees(np.arctan2((v[:, 3] * v[:, 0] - v[:, 2] * v[:, 1]).astype(np.float32).astype(np.float64),
+                                (v[:, 0] * v[:, 2] + v[:, 1] * v[:, 3]).astype(np.float32).astype(np.float64)))
+    used = has != 0
+    assert used.mean() > 0.9
+    assert np.abs(exact[used].astype(np.float64) - ref[used]).max() < 2e-4      # angle_degree vs binary64
+    err = np.abs(approx[used].astype(np.float64) - exact[used].astype(np.float64))
+    assert err.max() < 5e-4, err.max()                                           # a tenth of the guard band
+    # operands the approximation refuses: zero cross product (sign of zero decides 0 / +-180) and zero vectors
+    y = (v[:, 3] * v[:, 0] - v[:, 2] * v[:, 1]).astype(np.float32)
+    assert not used[y == 0].any()

@@ -39,7 +39,7 @@ int main(int argc, char **argv)
         best = std::min(best, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3);
     }
     printf("%d saddles -> %zu tags; best %.3f ms per call\n", n, tags.size(), best);
-    const char *names[12] = {"index build", "init_quads", "boards (expand)", "fix_missing + collect", "decode", "boards built", "valid_quad look-ups", "pair look-ups", "pair misses (2 x 3-NN each)", "valid_quad misses", "points scanned by small k-NN", "cells scanned by small k-NN"};
+    const char *names[12] = {"index build", "init_quads", "boards (expand)", "fix_missing + collect", "decode", "boards built", "50-NN of init_quads", "pair look-ups", "pair misses (2 x 3-NN each)", "valid_quad misses", "angle_degree (atan2f) calls", "points scanned by the 1- / 3-NN queries"};
     for (int i = 0; i < 12; ++i)
         printf("  %-22s %8.3f ms per call   (%ld per call)\n", names[i], g_tail_prof[i] * 1e3 / reps, g_tail_cnt[i] / reps);
     return 0;
