@@ -167,6 +167,7 @@ extern "C" int agx_detect_batch(agx_detector *det, const void *frames, const voi
             const uint32_t n_s = ns[par][f];
             const uint8_t *img = h_chunk + (size_t)f * frame_stride_bytes;
             pool->submit([=, &first_bad] {
+              try {  // nothing unwinds out of a worker thread: host memory exhaustion becomes the frame's status
                 // detector.rs:507: u8 luma for the decode (a copy for L8 too: the tail reads rows at a tight pitch)
                 std::vector<uint8_t> grey;
                 const uint8_t *g = img;
@@ -190,6 +191,12 @@ extern "C" int agx_detect_batch(agx_detector *det, const void *frames, const voi
                     if (!tags.empty()) std::memcpy(out + (size_t)gf * cap_per_frame, tags.data(), tags.size() * sizeof(agx_tag));
                 }
                 if (frame_status) frame_status[gf] = stf;
+              } catch (...) {
+                counts[gf] = 0;
+                if (frame_status) frame_status[gf] = AGX_ERR_CAPACITY;
+                int exp = AGX_OK;
+                first_bad.compare_exchange_strong(exp, AGX_ERR_CAPACITY);
+              }
             });
         }
     }
