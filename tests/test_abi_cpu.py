@@ -125,6 +125,10 @@ def test_host_tail_matches_oracle_tail_on_synthetic_and_other_families():
     a1 = A.TagDetector.detect_tail("t36h11", s2, g2, p1)
     assert sorted(a1) == sorted(O.detect_tail(g2, s2, params=op)) and 30 <= len(a1) <= 36
     assert A.TagDetector.detect_tail("t36h11", s2[:0], g2) == {}
+    for nb in (0, 3, 5):  # detector.rs:510: the loop runs max_num_of_boards times, found or not
+        op.max_num_of_boards = nb
+        got = A.TagDetector.detect_tail("t36h11", s2, g2, A.DetectorParams(0.3, 30.0, 60.0, nb))
+        assert sorted(got) == sorted(O.detect_tail(g2, s2, params=op)) and len(got) == (0 if nb == 0 else 72)
 
 
 def test_host_tail_matches_oracle_tail_on_many_and_perturbed_saddle_sets():
