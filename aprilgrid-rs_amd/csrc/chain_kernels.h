@@ -31,7 +31,7 @@ struct FrameCounters {
     uint32_t min_key_inv;  // ~order_preserving(min response); atomicMax
     uint32_t pad0[31];
     uint32_t n_seeds;      // flood seeds
-    uint32_t n_clusters;   // cluster records
+    uint32_t n_clusters;   // cluster records of the first flood tier (k_flood) or of the generic path
     uint32_t n_refined;    // rochade_refine survivors
     uint32_t max_k_bits;   // max k (k >= 0 so the raw bits order correctly)
     uint32_t flags;        // FLAG_* below
@@ -41,7 +41,8 @@ struct FrameCounters {
     uint32_t n_roots;      // generic path: union-find roots
     uint32_t n_big;        // seeds handed to the wave-wide second flood tier
     uint32_t refine_done;  // workgroups of k_refine that have finished this frame
-    uint32_t pad1;
+    uint32_t n_clusters2;  // cluster records the second flood tier appends behind them (k_refine); its own counter:
+                           // k_refine's workgroups take n_clusters as the bound of their first-tier loop while others append
     uint32_t stats[20];    // debug_ablation & 128: verify statistics by word row within a 128-row segment
 };
 static_assert(sizeof(FrameCounters) == 256, "FrameCounters is cleared as 64 dwords");

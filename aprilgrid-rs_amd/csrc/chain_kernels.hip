@@ -1016,8 +1016,8 @@ __device__ __forceinline__ unsigned long long from_right_u64(unsigned long long 
     return (unsigned long long)from_right_u((uint32_t)v) | ((unsigned long long)from_right_u((uint32_t)(v >> 32)) << 32);
 }
 
-__device__ __forceinline__ uint32_t wave_flood_128x64(const ChainArgs &a, int frame, uint32_t *flags, uint32_t *n_clusters,
-                                                      const uint32_t *mask, uint32_t p, int lane)
+__device__ __forceinline__ uint32_t wave_flood_128x64(const ChainArgs &a, int frame, uint32_t *flags, uint32_t n_first,
+                                                      uint32_t *n_clusters2, const uint32_t *mask, uint32_t p, int lane)
 {
     const uint32_t W = (uint32_t)a.W;
     const uint32_t sx = p % W, sy = p / W;
@@ -1062,7 +1062,10 @@ __device__ __forceinline__ uint32_t wave_flood_128x64(const ChainArgs &a, int fr
     }
     uint32_t o = 0xffffffffu;
     if (lane == 0) {
-        o = atomicAdd(n_clusters, 1u);
+        // behind the first tier's records, counted separately: the first tier's count is the loop bound of
+        // every workgroup of this launch and must not move while they start (a workgroup that started
+        // late used to see this cluster in "the first tier's" range and refine it a second time)
+        o = n_first + atomicAdd(n_clusters2, 1u);
         if (o < a.cap_roots) {
             const size_t q = (size_t)frame * a.cap_roots + o;
             a.clu_key[q] = p;
@@ -1283,7 +1286,7 @@ __device__ __forceinline__ void generic_frame(const ChainArgs &a, int frame)
     phase_barrier();
     const uint32_t n = __hip_atomic_load(&ctr.n_cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (n > a.cap_cand) {  // overflow: slot_plane is incomplete; the frame is reported, not processed
-        if (t == 0) ctr.n_clusters = 0u;
+        if (t == 0) ctr.n_clusters = ctr.n_clusters2 = 0u;
         return;
     }
     // phase 2: lock-free union-find; links go from the larger slot to the smaller
@@ -1322,7 +1325,10 @@ __device__ __forceinline__ void generic_frame(const ChainArgs &a, int frame)
         a.clu_sx[q] = sx64 > 0xffffffffull ? 0xffffffffu : (uint32_t)sx64;
         a.clu_sy[q] = sy64 > 0xffffffffull ? 0xffffffffu : (uint32_t)sy64;
     }
-    if (t == 0) ctr.n_clusters = nr;
+    if (t == 0) {
+        ctr.n_clusters = nr;
+        ctr.n_clusters2 = 0u;  // whatever the fast path's second tier appended is void
+    }
 }
 
 
@@ -1537,7 +1543,8 @@ __device__ __forceinline__ void filter_sort_emit(const ChainArgs &a, int frame, 
             row[0] = bad ? 0u : nf;
             row[1] = off;
             row[2] = flags;
-            row[3] = __hip_atomic_load(&ctr.n_clusters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            row[3] = __hip_atomic_load(&ctr.n_clusters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) +
+                     __hip_atomic_load(&ctr.n_clusters2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     __syncthreads();
@@ -1617,7 +1624,8 @@ __device__ __forceinline__ bool emit_small(const ChainArgs &a, int frame, uint32
             row[0] = bad ? 0u : nf;
             row[1] = off;
             row[2] = flags;
-            row[3] = __hip_atomic_load(&ctr.n_clusters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            row[3] = __hip_atomic_load(&ctr.n_clusters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) +
+                     __hip_atomic_load(&ctr.n_clusters2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     __syncthreads();
@@ -1665,7 +1673,7 @@ __global__ void __launch_bounds__(64, 4) k_refine(ChainArgs a, RefineConsts rc)
         const uint32_t n_big = min(ctr.n_big, a.cap_roots);
         const uint32_t *mask = a.mask + (size_t)frame * (size_t)a.mask_plane;
         for (uint32_t b = fs.slot; b < n_big; b += fs.n_slots) {
-            const uint32_t o = wave_flood_128x64(a, frame, &ctr.flags, &ctr.n_clusters, mask, a.roots[cbase + b], (int)threadIdx.x);
+            const uint32_t o = wave_flood_128x64(a, frame, &ctr.flags, n, &ctr.n_clusters2, mask, a.roots[cbase + b], (int)threadIdx.x);
             if (o != 0xffffffffu && threadIdx.x == 0)
                 refine_cluster<VEC>(a, rc, frame, cbase, img, a.W, a.H, o, &ctr.n_refined, &ctr.max_k_bits);
         }

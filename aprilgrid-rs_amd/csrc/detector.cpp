@@ -747,7 +747,7 @@ int agx_saddles_batch_fetch(agx_detector *det, agx_saddle *out, uint32_t cap_per
                 char buf[160];
                 std::snprintf(buf, sizeof buf,
                               "frame %zu: capacity exceeded (flags=0x%x seeds=%u clusters=%u candidates=%u saddles=%u)", f,
-                              c.flags, c.n_seeds, c.n_clusters, c.n_cand, c.n_out);
+                              c.flags, c.n_seeds, c.n_clusters + c.n_clusters2, c.n_cand, c.n_out);
                 det->last_error = buf;
             }
             continue;
@@ -1002,7 +1002,7 @@ int agx_debug_fetch(agx_detector *det, int frame, int what, void *host_out, size
         // flags, seeds, second-tier seeds, clusters, generic candidates, generic roots, refined, out
         *n_items = 8;
         if (cap_bytes < 8 * sizeof(uint32_t)) return AGX_ERR_CAPACITY;
-        const uint32_t v[8] = {c.flags, c.n_seeds, c.n_big, c.n_clusters, c.n_cand, c.n_roots, c.n_refined, c.n_out};
+        const uint32_t v[8] = {c.flags, c.n_seeds, c.n_big, c.n_clusters + c.n_clusters2, c.n_cand, c.n_roots, c.n_refined, c.n_out};
         std::memcpy(host_out, v, sizeof v);
         return AGX_OK;
     }
@@ -1044,7 +1044,7 @@ int agx_debug_fetch(agx_detector *det, int frame, int what, void *host_out, size
         return AGX_OK;
     }
     case AGX_DBG_CENTERS: {
-        const uint32_t n = std::min(c.n_clusters, a.cap_roots);
+        const uint32_t n = std::min(c.n_clusters + c.n_clusters2, a.cap_roots);
         *n_items = n;
         if (cap_bytes < (size_t)n * sizeof(agx_cluster_info)) return AGX_ERR_CAPACITY;
         std::vector<uint32_t> key(n), cnt(n), sx(n), sy(n);

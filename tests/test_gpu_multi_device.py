@@ -3,6 +3,7 @@ C ABI, handles driven from threads, and the C-level detector groups with their r
 Every test is parametrised by what the box has and passes with a single GPU (two ranks may share
 device 0 with the peer-copy transport; the RCCL transport needs distinct devices and runs where
 there are at least two)."""
+import os
 import threading
 
 import numpy as np
@@ -147,3 +148,16 @@ def test_plain_c_group_client(oracle, tmp_path):
         for i, ref in enumerate(refs):
             assert "frame %d: %d\n" % (i, len(ref)) in r.stdout, (i, len(ref), r.stdout)
         assert "%d saddles in %d frames" % (sum(len(x) for x in refs), ranks * fpr) in r.stdout
+
+
+def test_batches_in_flight_are_bitwise_reproducible():
+    """tools/stress_concurrency.py, short: three detectors on three streams take batches of different
+    size / format in turn; every result (records, counts, status flags, cluster counts) must equal the
+    result of the same batch computed alone.  Found in round 2: k_refine's workgroups took the cluster
+    count as their loop bound while others were appending second-tier clusters to it."""
+    import subprocess
+    import sys
+    from tests.util import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stress_concurrency.py"), "700", "3"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "0 mismatches" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -68,6 +68,12 @@ def check_frame(det, O, img, frame=0, what="", params=None):
     assert np.array_equal(c["size"], d["sizes"]), what + ": cluster sizes"
     assert bits_equal(c["cx"], d["centers"][:, 0]) and bits_equal(c["cy"], d["centers"][:, 1]), what + ": centroids"
     check_saddles(det.debug_fetch(frame, "refined"), d["refined"], what + " (unfiltered)")
+    # informational flags: AGX_FRAME_CENTROID_INEXACT (8) only where a coordinate sum can reach 2^24 (a cluster
+    # refined twice -- a race between k_refine's workgroups that round 2 fixed -- used to raise it spuriously)
+    flags = det.debug_fetch(frame, "counters")["flags"]
+    assert not (flags & 7), what + ": overflow flags %d" % flags
+    if len(d["sizes"]) == 0 or float(d["sizes"].max()) * max(h, w) < 2.0 ** 24:
+        assert not (flags & 8), what + ": AGX_FRAME_CENTROID_INEXACT set without cause"
     return ref
 
 
