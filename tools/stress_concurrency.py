@@ -2,7 +2,7 @@
 batches of different content, size and format in turn (the dense kernel of one overlaps the sparse
 kernels of another); every result must equal, bit for bit, the result of the same batch computed
 alone.  Catches rare ordering bugs (hand-over of records between workgroups, counter sets, stream
-order) that a single pass cannot.   usage: python tools/stress_concurrency.py [rounds]"""
+order) that a single pass cannot.   usage: python tools/stress_concurrency.py [rounds] [detectors] [big]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -14,6 +14,8 @@ n_dets = int(sys.argv[2]) if len(sys.argv) > 2 else 3  # 1: no concurrency (cont
 dev = torch.device("cuda", 0)
 specs = [(24, 640, 400, "L8", False), (8, 1280, 800, "L8", False), (6, 1280, 800, "RGB8", False), (12, 644, 402, "L16", False),
          (4, 640, 400, "L8", True), (3, 1920, 1080, "L8", False), (40, 320, 240, "L8", False)]
+if len(sys.argv) > 3 and sys.argv[3] == "big":  # the benchmarked geometry: many rounds of workgroups per launch
+    specs = [(256, 1280, 800, "L8", False), (64, 1280, 800, "RGB8", False), (32, 3840, 2160, "L8", False)]
 batches = []
 ref = A.TagDetector("t36h11", None, device=0)
 for i, (n, w, h, fmt, noise) in enumerate(specs):
