@@ -552,6 +552,9 @@ def main():
                 "design_GBps": round(px_per_step_rank * a_design / (chain_ms * 1e-3) / 1e9, 1),
                 "design_frac_of_peak": round(px_per_step_rank * a_design / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                 "frames_on_generic_path": generic_frames,
+                "note": "kernel_ms_per_step: hipEvent pairs around every launch in a separate untimed pass -- each figure "
+                        "includes the idle gap its own event pair opens in front of the kernel (5-35 us), so the sum exceeds "
+                        "ms_per_step; the kernels' own durations (rocprofv3 --kernel-trace --stats) are under profiles/",
             },
             "gather_check": gather_check,
         }
