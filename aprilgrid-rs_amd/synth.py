@@ -43,12 +43,21 @@ class _Rng:
         return a + (b - a) * self.u()
 
 
-def t36h11_codes():
-    """T36H11 code words: read from the table compiled into the product (tag_families_data.inc)."""
+# family -> (code table in tag_families_data.inc, edge bits, border bits); src/detector.rs:369-405
+FAMILY_LAYOUT = {"T16H5": ("kT16H5", 4, 2), "T25H7": ("kT25H7", 5, 2), "T25H9": ("kT25H9", 5, 2),
+                 "T36H11": ("kT36H11", 6, 2), "T36H11B1": ("kT36H11", 6, 1)}
+
+
+def family_codes(family="T36H11"):
+    """Code words of a tag family: read from the table compiled into the product (tag_families_data.inc)."""
     import re
     txt = open(os.path.join(_HERE, "csrc", "tag_families_data.inc")).read()
-    m = re.search(r"kT36H11\[587\] = \{(.*?)\};", txt, re.S)
+    m = re.search(FAMILY_LAYOUT[family][0] + r"\[\d+\] = \{(.*?)\};", txt, re.S)
     return [int(t, 16) for t in re.findall(r"0x([0-9A-Fa-f]+)ULL", m.group(1))]
+
+
+def t36h11_codes():
+    return family_codes("T36H11")
 
 
 def _homography(src, dst):
@@ -130,10 +139,13 @@ def _gauss_blur(img, sigma):
 
 
 def render_frame(frame_index, width, height, device="cpu", spec=None, codes=None, pure_noise=False,
-                 supersample=3):
-    """-> (uint8 tensor [H,W] on `device`, ground truth {tag_id: 4x2 float64 corner array TL,TR,BR,BL})."""
+                 supersample=3, family="T36H11"):
+    """-> (uint8 tensor [H,W] on `device`, ground truth {tag_id: 4x2 float64 corner array TL,TR,BR,BL}).
+    family: the tags' code table and cell layout (edge x edge code bits inside a black border)."""
     spec = spec or BoardSpec()
-    codes = codes or t36h11_codes()
+    codes = codes or family_codes(family)
+    _, edge, border = FAMILY_LAYOUT[family]
+    cells, nbits = edge + 2 * border, edge * edge
     seed = splitmix64(0xA9121D ^ frame_index)
     rng = _Rng(seed)
     black = rng.uniform(15.0, 50.0)
@@ -158,13 +170,13 @@ def render_frame(frame_index, width, height, device="cpu", spec=None, codes=None
                     p = H @ np.array([x, y, 1.0])
                     pts.append((p[0] / p[2], p[1] / p[2]))
                 gt[spec.tag_id(ix, iy)] = np.asarray(pts, np.float64)
-        # bit lookup table [rows*cols tags][36]: 1.0 = white
-        bits = torch.zeros((spec.rows * spec.cols, 36), dtype=torch.float32)
+        # bit lookup table [rows*cols tags][edge*edge]: 1.0 = white
+        bits = torch.zeros((spec.rows * spec.cols, nbits), dtype=torch.float32)
         for iy in range(spec.rows):
             for ix in range(spec.cols):
                 code = codes[spec.tag_id(ix, iy)]
-                for c in range(36):
-                    bits[iy * spec.cols + ix, c] = float((code >> (35 - c)) & 1)
+                for c in range(nbits):
+                    bits[iy * spec.cols + ix, c] = float((code >> (nbits - 1 - c)) & 1)
         bits = bits.to(dev).reshape(-1)
         hi = torch.tensor(Hinv, dtype=torch.float64, device=dev)
         off = (torch.arange(S, device=dev, dtype=torch.float64) + 0.5) / S - 0.5
@@ -187,12 +199,12 @@ def render_frame(frame_index, width, height, device="cpu", spec=None, codes=None
                 fy = Y - iyf * spec.period
                 small = in_board & (fx < spec.spacing) & (fy < spec.spacing)
                 in_tag = in_board & (fx >= spec.spacing) & (fy >= spec.spacing) & (ixf < spec.cols) & (iyf < spec.rows)
-                cx = torch.clamp(torch.floor((fx - spec.spacing) * 10.0), 0, 9).to(torch.int64)
-                cy = torch.clamp(torch.floor((fy - spec.spacing) * 10.0), 0, 9).to(torch.int64)
-                inner = (cx >= 2) & (cx < 8) & (cy >= 2) & (cy < 8)
+                cx = torch.clamp(torch.floor((fx - spec.spacing) * float(cells)), 0, cells - 1).to(torch.int64)
+                cy = torch.clamp(torch.floor((fy - spec.spacing) * float(cells)), 0, cells - 1).to(torch.int64)
+                inner = (cx >= border) & (cx < border + edge) & (cy >= border) & (cy < border + edge)
                 tag_lin = (torch.clamp(iyf, 0, spec.rows - 1).to(torch.int64) * spec.cols +
                            torch.clamp(ixf, 0, spec.cols - 1).to(torch.int64))
-                bit_idx = tag_lin * 36 + torch.clamp(cy - 2, 0, 5) * 6 + torch.clamp(cx - 2, 0, 5)
+                bit_idx = tag_lin * nbits + torch.clamp(cy - border, 0, edge - 1) * edge + torch.clamp(cx - border, 0, edge - 1)
                 bitv = bits[bit_idx]
                 tag_val = torch.where(inner & (bitv > 0.5), torch.tensor(white, device=dev), torch.tensor(black, device=dev))
                 val = torch.full_like(X, white)

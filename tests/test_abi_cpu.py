@@ -265,3 +265,24 @@ def test_bounded_angle_approximation_of_the_board_search(lib):
     # operands the approximation refuses: zero cross product (sign of zero decides 0 / +-180) and zero vectors
     y = (v[:, 3] * v[:, 0] - v[:, 2] * v[:, 1]).astype(np.float32)
     assert not used[y == 0].any()
+
+
+@pytest.mark.parametrize("family", ["T16H5", "T25H7", "T25H9", "T36H11B1"])
+def test_host_tail_decodes_every_family_on_rendered_boards(family):
+    """Boards drawn with the other families' code tables and cell layouts (4x4 / 5x5 code bits, border of
+    1 or 2 cells; src/detector.rs:369-405): the product's tail and the oracle's decode the same tags with
+    bit-identical corners, and those are the 25 drawn ids at the drawn positions."""
+    import aprilgrid_rs_amd as A
+    from oracle import oracle as O
+    synth = synth_module()
+    for seed in (11, 12):
+        img, gt = synth.render_frame(seed, 800, 600, spec=synth.BoardSpec(rows=5, cols=5), family=family)
+        img = img.numpy()
+        saddles = O.refined_saddle_points(img)
+        got = A.TagDetector.detect_tail(family, saddles, img)
+        ref = O.detect_tail(img, saddles, family=family)
+        assert sorted(got) == sorted(ref) == sorted(gt), (family, seed, sorted(got), sorted(ref))
+        for tid in ref:
+            assert bits_equal(got[tid], ref[tid])
+            err = np.abs(np.sort(got[tid], axis=0) - np.sort(gt[tid].astype(np.float32), axis=0)).max()
+            assert err < 0.5, (family, tid, err)

@@ -82,6 +82,22 @@ def test_fixture_images_detect(det, oracle, name, expected):
         assert bits_equal(tags[tid], ref[tid]), "corners of tag %d" % tid
 
 
+@pytest.mark.parametrize("family", ["T16H5", "T25H7", "T25H9", "T36H11B1"])
+def test_detect_other_tag_families(oracle, family):
+    """TagDetector::new with the other families (src/detector.rs:369-405) on boards rendered with their
+    code tables: detect() through the GPU chain equals the oracle's and finds the 25 drawn tags."""
+    import aprilgrid_rs_amd as A
+    synth = synth_module()
+    d = A.TagDetector(family, None, device=0)
+    img, gt = synth.render_frame(21, 800, 600, spec=synth.BoardSpec(rows=5, cols=5), family=family)
+    img = img.numpy()
+    got, ref = d.detect(img), oracle.detect(img, family=family)
+    assert sorted(got) == sorted(ref) == sorted(gt)
+    for tid in ref:
+        assert bits_equal(got[tid], ref[tid])
+    d.close()
+
+
 def test_detect_kornia_front_end(det, oracle):
     """tests/test_detector.rs:35-43: Image<u8,3> -> 66 tags; u8c1 works; other N is refused."""
     import aprilgrid_rs_amd as A
