@@ -161,3 +161,16 @@ def test_batches_in_flight_are_bitwise_reproducible():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stress_concurrency.py"), "700", "3"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "0 mismatches" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_chain_can_be_captured_into_a_hip_graph():
+    """tools/graph_capture_probe.py: two consecutive batches captured with torch.cuda.CUDAGraph on a side
+    stream and replayed give the eager results (in its own process: a failed capture would leave the
+    stream in an error state)."""
+    import subprocess
+    import sys
+    from tests.util import ROOT
+    env = dict(os.environ, FRAMES="12")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "graph_capture_probe.py")], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert r.returncode == 0 and r.stdout.count("graph replay equals eager: True") == 2, r.stdout[-2000:] + r.stderr[-2000:]
