@@ -69,6 +69,8 @@ SYMBOLS = {
                                           C.POINTER(C.c_uint32)]),
     "agx_detect_tail": (C.c_int, [C.c_int, C.POINTER(Params), _P, C.c_uint32, _P, C.c_int, C.c_int, C.c_size_t, _P,
                                   C.c_uint32, C.POINTER(C.c_uint32)]),
+    "agx_detect_tail_threads": (C.c_int, [C.c_int, C.POINTER(Params), _P, C.c_uint32, _P, C.c_int, C.c_int, C.c_size_t, _P,
+                                          C.c_uint32, C.POINTER(C.c_uint32), C.c_int]),
     "agx_luma8": (C.c_int, [_P, C.c_int, C.c_int, C.c_size_t, C.c_int, _P]),
     "agx_debug_angle_pairs": (C.c_int, [_P, C.c_size_t, _P, _P, _P]),
     "agx_profile_enable": (C.c_int, [_P, C.c_int]),

@@ -85,6 +85,25 @@ private:
 void destroy_worker_pool(void *p) { delete static_cast<WorkerPool *>(p); }
 void *create_worker_pool(int n_threads) { return new WorkerPool(n_threads); }
 
+// Workers of one frame's board search (option "tail_threads"): n - 1 pool threads plus the caller.
+class PoolTailWorkers : public TailWorkers {
+public:
+    explicit PoolTailWorkers(int n) : n_(n), pool_(n - 1) {}
+    int size() const override { return n_; }
+    void run(int n, const std::function<void(int)> &f) override
+    {
+        for (int t = 1; t < n; ++t) pool_.submit([&f, t] { f(t); });
+        if (n > 0) f(0);
+        pool_.wait();
+    }
+
+private:
+    int n_;
+    WorkerPool pool_;
+};
+TailWorkers *create_tail_workers(int n_threads) { return n_threads > 1 ? new PoolTailWorkers(std::min(n_threads, 64)) : nullptr; }
+void destroy_tail_workers(TailWorkers *w) { delete w; }
+
 }  // namespace agx
 
 using namespace agx;

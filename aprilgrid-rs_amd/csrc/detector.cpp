@@ -90,6 +90,8 @@ struct agx_detector {
     double prof_ms[K_COUNT]{};
     uint64_t prof_launches[K_COUNT]{};
 
+    TailWorkers *tail_workers = nullptr;  // option "tail_threads" > 1: one frame's board search on several threads
+    int tail_threads = 1;
     void *pool = nullptr;  // agx_detect_batch: worker threads of the host tail
     int pool_threads = 0;
     std::vector<agx_saddle> scratch_saddles;  // host staging of agx_detect / agx_detect_planes (reused)
@@ -554,6 +556,7 @@ void agx_detector_destroy(agx_detector *det)
     for (hipEvent_t e : det->free_events) (void)hipEventDestroy(e);
     free_workspace(det);
     if (det->pool) destroy_worker_pool(det->pool);
+    if (det->tail_workers) destroy_tail_workers(det->tail_workers);
     if (det->d_stage) (void)hipFree(det->d_stage);
     if (det->d_dbg_resp) (void)hipFree(det->d_dbg_resp);
     if (det->d_resp_store) (void)hipFree(det->d_resp_store);
@@ -601,7 +604,14 @@ int agx_detector_set_option(agx_detector *det, const char *name, int value)
     else if (!std::strcmp(name, "debug_ablation")) det->dbg = value;  // timing only, results invalid
     else if (!std::strcmp(name, "store_response")) det->store_resp = value != 0;
     else if (!std::strcmp(name, "profile_stride")) det->prof_stride = value > 1 ? value : 1;
-    else return fail(det, AGX_ERR_ARG, std::string("unknown option ") + name);
+    else if (!std::strcmp(name, "tail_threads")) {
+        const int n = value < 1 ? 1 : (value > 64 ? 64 : value);
+        if (n != det->tail_threads) {
+            if (det->tail_workers) destroy_tail_workers(det->tail_workers);
+            det->tail_workers = create_tail_workers(n);
+            det->tail_threads = n;
+        }
+    } else return fail(det, AGX_ERR_ARG, std::string("unknown option ") + name);
     return AGX_OK;
 }
 
@@ -612,6 +622,7 @@ int agx_detector_get_option(const agx_detector *det, const char *name, int *valu
     if (!std::strcmp(name, "force_generic")) *value = det->force_generic;
     else if (!std::strcmp(name, "store_response")) *value = det->store_resp;
     else if (!std::strcmp(name, "debug_ablation")) *value = det->dbg;
+    else if (!std::strcmp(name, "tail_threads")) *value = det->tail_threads;
     // the blur kernel's tiling of the last enqueued batch (0 before the first one)
     else if (!std::strcmp(name, "k1_rows_per_segment")) *value = a.rows_per_seg;
     else if (!std::strcmp(name, "k1_segments")) *value = a.n_segs;
@@ -830,7 +841,7 @@ int agx_detect_from_saddles(const agx_detector *det, const agx_saddle *saddles, 
     std::vector<agx_saddle> refined(saddles, saddles + n_saddles);
     std::vector<agx_tag> tags;
     detect_tail(det->fam, det->params.max_num_of_boards, std::move(refined), luma, width, height, row_stride_bytes,
-                tags);
+                tags, det->tail_workers);
     *n_out = (uint32_t)tags.size();
     if (tags.size() > cap) return AGX_ERR_CAPACITY;
     if (!tags.empty()) std::memcpy(out, tags.data(), tags.size() * sizeof(agx_tag));
@@ -841,6 +852,14 @@ int agx_detect_tail(int family, const agx_params *params, const agx_saddle *sadd
                     const uint8_t *luma, int width, int height, size_t row_stride_bytes, agx_tag *out, uint32_t cap,
                     uint32_t *n_out)
 {
+    return agx_detect_tail_threads(family, params, saddles, n_saddles, luma, width, height, row_stride_bytes, out, cap,
+                                   n_out, 1);
+}
+
+int agx_detect_tail_threads(int family, const agx_params *params, const agx_saddle *saddles, uint32_t n_saddles,
+                            const uint8_t *luma, int width, int height, size_t row_stride_bytes, agx_tag *out,
+                            uint32_t cap, uint32_t *n_out, int n_threads)
+{
     if (!luma || !n_out || (!saddles && n_saddles) || (!out && cap) || width < 1 || height < 1) return AGX_ERR_ARG;
     FamilyInfo fam;
     if (!family_info(family, fam)) return AGX_ERR_FAMILY;
@@ -849,7 +868,9 @@ int agx_detect_tail(int family, const agx_params *params, const agx_saddle *sadd
     else agx_default_params(&prm);
     std::vector<agx_saddle> refined(saddles, saddles + n_saddles);
     std::vector<agx_tag> tags;
-    detect_tail(fam, prm.max_num_of_boards, std::move(refined), luma, width, height, row_stride_bytes, tags);
+    TailWorkers *workers = create_tail_workers(n_threads);  // threads of this call only (nullptr for <= 1)
+    detect_tail(fam, prm.max_num_of_boards, std::move(refined), luma, width, height, row_stride_bytes, tags, workers);
+    destroy_tail_workers(workers);
     *n_out = (uint32_t)tags.size();
     if (tags.size() > cap) return AGX_ERR_CAPACITY;
     if (!tags.empty()) std::memcpy(out, tags.data(), tags.size() * sizeof(agx_tag));

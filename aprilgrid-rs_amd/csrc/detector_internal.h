@@ -18,4 +18,7 @@ void *agx_internal_stage(agx_detector *det, size_t bytes);
 namespace agx {
 void destroy_worker_pool(void *pool);
 void *create_worker_pool(int n_threads);
+struct TailWorkers;  // host_tail.hpp
+TailWorkers *create_tail_workers(int n_threads);  // nullptr for n_threads <= 1
+void destroy_tail_workers(TailWorkers *w);
 }

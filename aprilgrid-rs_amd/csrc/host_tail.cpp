@@ -754,7 +754,77 @@ inline uint32_t f32_as_u32(float v)  // Rust `as u32`: saturating, NaN -> 0
 
 }  // namespace
 
-bool try_find_best_board(const std::vector<agx_saddle> &refined, std::vector<Quad> &quads)
+namespace {
+
+// The seeds' boards on several workers.  Seeds are independent given the running best score: within a
+// seed the sequential loop ends up with the FIRST quad that reaches the seed's maximum score if that
+// beats the best so far (strictly), so a worker returns (maximum, first quad reaching it) per seed and
+// the merge walks the seeds in the reference's order with the reference's rules (strict improvement,
+// stop after the first seed that leaves the best at >= 36, at most 30 seeds).  The first seed is taken
+// alone -- a board found by it, the common case, then costs what it costs the sequential loop -- and the
+// rest in waves of `workers`.  The chosen board is rebuilt from its seed quad for try_fix_missing (a board is a
+// deterministic function of the saddles and its seed quad).
+bool find_best_board_parallel(const std::vector<agx_saddle> &refined, std::vector<int> &seeds, SaddleIndex &index,
+                              std::vector<Quad> &quads, TailWorkers &workers)
+{
+    struct Ctx {
+        SaddleIndex index;
+        BoardStorage storage;
+        std::vector<Quad> cand;
+        explicit Ctx(const std::vector<agx_saddle> &r) : index(r) {}
+    };
+    struct SeedResult {
+        unsigned score = 0;
+        Quad quad{};
+    };
+    const int W = std::max(1, workers.size());
+    std::vector<std::unique_ptr<Ctx>> ctx((size_t)W);
+    const int n_seeds = (int)std::min<size_t>(seeds.size(), 30);  // popped from the back, at most 30
+    unsigned best_score = 0;
+    Quad best_quad{};
+    bool have = false, stop = false;
+    // the first seed alone (on the calling thread): it usually settles the search
+    for (int base = 0, width = 1; base < n_seeds && !stop; base += width, width = W) {
+        const int n = std::min(width, n_seeds - base);
+        std::vector<SeedResult> res((size_t)n);
+        workers.run(n, [&](int t) {
+            if (!ctx[(size_t)t]) ctx[(size_t)t].reset(new Ctx(refined));
+            Ctx &c = *ctx[(size_t)t];
+            const int s0 = seeds[seeds.size() - 1 - (size_t)(base + t)];
+            init_quads(refined, c.index, s0, c.cand);
+            SeedResult r;
+            for (const Quad &q : c.cand) {
+                const Board b(refined, c.index, q, 0.3f, c.storage);
+                if (b.score() > r.score) {
+                    r.score = b.score();
+                    r.quad = q;
+                }
+            }
+            res[(size_t)t] = r;
+        });
+        for (int t = 0; t < n; ++t) {  // the reference's order
+            if (res[(size_t)t].score > best_score) {
+                best_score = res[(size_t)t].score;
+                best_quad = res[(size_t)t].quad;
+                have = true;
+            }
+            if (best_score >= 36) {
+                stop = true;
+                break;
+            }
+        }
+    }
+    if (!have) return false;
+    BoardStorage storage;
+    Board best(refined, index, best_quad, 0.3f, storage);
+    best.fix_missing();
+    best.collect(quads);
+    return true;
+}
+
+}  // namespace
+
+bool try_find_best_board(const std::vector<agx_saddle> &refined, std::vector<Quad> &quads, TailWorkers *workers)
 {
     quads.clear();
     if (refined.empty()) return false;
@@ -777,6 +847,8 @@ bool try_find_best_board(const std::vector<agx_saddle> &refined, std::vector<Qua
     std::vector<int> seeds;
     for (size_t i = 0; i < refined.size(); ++i)
         if ((int)std::round(refined[i].theta) == best_angle) seeds.push_back((int)i);
+
+    if (workers && workers->size() > 1 && seeds.size() > 1) return find_best_board_parallel(refined, seeds, index, quads, *workers);
 
     unsigned best_score = 0;
     BoardStorage storage[2];  // the best board so far keeps one, the next candidate is built in the other
@@ -919,12 +991,13 @@ bool decode_quad(const FamilyInfo &fam, const uint8_t *luma8, uint32_t w, uint32
 }  // namespace
 
 void detect_tail(const FamilyInfo &fam, int max_num_of_boards, std::vector<agx_saddle> refined,
-                 const uint8_t *luma8, int width, int height, size_t row_stride, std::vector<agx_tag> &tags)
+                 const uint8_t *luma8, int width, int height, size_t row_stride, std::vector<agx_tag> &tags,
+                 TailWorkers *workers)
 {
     tags.clear();
     std::vector<Quad> quads;
     for (int round = 0; round < max_num_of_boards; ++round) {
-        if (!try_find_best_board(refined, quads)) continue;
+        if (!try_find_best_board(refined, quads, workers)) continue;
         std::vector<uint8_t> used(refined.size(), 0);
         for (const Quad &q : quads) {
             float qxy[8];

@@ -3,6 +3,7 @@
 // decode (src/detector.rs:42-169,448-476, src/image_util.rs:39-70).
 #pragma once
 #include <array>
+#include <functional>
 #include <cstdint>
 #include <vector>
 
@@ -30,8 +31,18 @@ void debug_angle_pairs(const float *v, size_t n, float *exact, float *approx, ui
 // saddle.rs:17-67
 bool is_valid_quad(const agx_saddle &s0, const agx_saddle &d0, const agx_saddle &s1, const agx_saddle &d1);
 
-// detector.rs:588-639: quads (saddle indices) of the best board, or false (None).
-bool try_find_best_board(const std::vector<agx_saddle> &refined, std::vector<Quad> &quads);
+// Workers for the board search of ONE frame (option "tail_threads"; agx_detect_batch parallelises over
+// frames instead).  run(n, f) calls f(task) for task = 0..n-1 on the workers and returns when all are done.
+struct TailWorkers {
+    virtual ~TailWorkers() {}
+    virtual int size() const = 0;
+    virtual void run(int n, const std::function<void(int)> &f) = 0;
+};
+
+// detector.rs:588-639: quads (saddle indices) of the best board, or false (None).  With workers, the
+// seeds are taken in waves of size() in the reference's order and merged in that order, so the board
+// chosen is the one the sequential loop chooses.
+bool try_find_best_board(const std::vector<agx_saddle> &refined, std::vector<Quad> &quads, TailWorkers *workers = nullptr);
 
 // image_util.rs:39-70 (h = 2x3 affine, row-major)
 void tag_affine(const float quad_xy[8], int side_bits, float margin, float h[6]);
@@ -42,7 +53,8 @@ bool best_tag(uint64_t bits, int thres, const uint64_t *codes, int n_codes, int 
 // detector.rs:510-539: board search + decode over a saddle list and the u8 luma plane.
 // Tags in first-insertion order; a repeated id replaces the earlier corners.
 void detect_tail(const FamilyInfo &fam, int max_num_of_boards, std::vector<agx_saddle> refined,
-                 const uint8_t *luma8, int width, int height, size_t row_stride, std::vector<agx_tag> &tags);
+                 const uint8_t *luma8, int width, int height, size_t row_stride, std::vector<agx_tag> &tags,
+                 TailWorkers *workers = nullptr);
 
 // image 0.25.9 to_luma8 (call site detector.rs:507)
 int luma8(const void *pixels, int width, int height, size_t row_stride, int format, uint8_t *out);

@@ -207,8 +207,9 @@ class TagDetector:
         return {int(out[i].id): np.array(out[i].xy, np.float32).reshape(4, 2) for i in range(n.value)}
 
     @staticmethod
-    def detect_tail(tag_family, saddles, luma8, optional_detector_params=None, cap=4096):
-        """Host tail without a device: board search + decode from a SADDLE_DTYPE array."""
+    def detect_tail(tag_family, saddles, luma8, optional_detector_params=None, cap=4096, n_threads=1):
+        """Host tail without a device: board search + decode from a SADDLE_DTYPE array (n_threads > 1: the
+        frame's board search on several host threads, same result)."""
         fam = TagFamily.from_str(tag_family) if isinstance(tag_family, str) else TagFamily(tag_family)
         prm = optional_detector_params._c() if optional_detector_params is not None else None
         s = np.ascontiguousarray(saddles, SADDLE_DTYPE)
@@ -216,8 +217,8 @@ class TagDetector:
         h, w = g.shape
         out = (_ffi.TagC * cap)()
         n = C.c_uint32(0)
-        st = _ffi.lib().agx_detect_tail(int(fam), C.byref(prm) if prm is not None else None, s.ctypes.data, len(s),
-                                        g.ctypes.data, w, h, w, out, cap, C.byref(n))
+        st = _ffi.lib().agx_detect_tail_threads(int(fam), C.byref(prm) if prm is not None else None, s.ctypes.data, len(s),
+                                                g.ctypes.data, w, h, w, out, cap, C.byref(n), int(n_threads))
         if st != _ffi.AGX_OK:
             raise AgxError(st)
         return {int(out[i].id): np.array(out[i].xy, np.float32).reshape(4, 2) for i in range(n.value)}

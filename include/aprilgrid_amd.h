@@ -118,6 +118,11 @@ int agx_detector_set_limits(agx_detector *det, uint32_t max_candidates, uint32_t
  *                          registers (parity tests: agx_debug_fetch AGX_DBG_RESP); slower
  *   "profile_stride"       with agx_profile_enable(det, 1): time the blur kernel of every n-th batch
  *                          only (an event pair costs the stream two ~5 us gaps around the kernel)
+ *   "tail_threads"         n > 1: agx_detect / agx_detect_planes / agx_detect_from_saddles search the boards of
+ *                          ONE frame on n host threads (the up-to-30 seed saddles of try_find_best_board,
+ *                          detector.rs:611-625, in waves of n, merged in the reference's order: same result;
+ *                          latency of a single detect, at the price of host cores).  Default 1, like the
+ *                          reference; agx_detect_batch parallelises over frames instead
  *   "debug_ablation"       timing experiments only -- results are INVALID when non-zero */
 int agx_detector_set_option(agx_detector *det, const char *name, int value);
 /* Read an option back; additionally the tiling the blur kernel used for the last enqueued batch:
@@ -262,6 +267,12 @@ int agx_detect_from_saddles(const agx_detector *det, const agx_saddle *saddles, 
 int agx_detect_tail(int family, const agx_params *params, const agx_saddle *saddles, uint32_t n_saddles,
                     const uint8_t *luma8, int width, int height, size_t row_stride_bytes, agx_tag *out,
                     uint32_t cap, uint32_t *n_out);
+
+/* The same with the board search of the frame on n_threads host threads (created for this call; a
+ * detector handle keeps its own: option "tail_threads").  Same result as n_threads = 1. */
+int agx_detect_tail_threads(int family, const agx_params *params, const agx_saddle *saddles, uint32_t n_saddles,
+                            const uint8_t *luma8, int width, int height, size_t row_stride_bytes, agx_tag *out,
+                            uint32_t cap, uint32_t *n_out, int n_threads);
 
 /* to_luma8 (src/detector.rs:507) of a host image into a tightly packed host plane. */
 int agx_luma8(const void *pixels, int width, int height, size_t row_stride_bytes, int format,

@@ -160,6 +160,9 @@ def test_host_tail_matches_oracle_tail_on_many_and_perturbed_saddle_sets():
             got = A.TagDetector.detect_tail("t36h11", sad, img)
             ref = O.detect_tail(img, sad)
             assert sorted(got) == sorted(ref), (i, v, len(got), len(ref))
+            # the same frame's board search on several threads (option "tail_threads"): same tags, same order
+            par = A.TagDetector.detect_tail("t36h11", sad, img, n_threads=2 + (i + v) % 5)
+            assert list(par) == list(got) and all(bits_equal(par[t], got[t]) for t in got), (i, v, "threads")
             for tid in ref:
                 assert bits_equal(got[tid], ref[tid]), (i, v, tid)
             n_tags += len(ref)

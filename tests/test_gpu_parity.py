@@ -98,6 +98,23 @@ def test_detect_other_tag_families(oracle, family):
     d.close()
 
 
+def test_detect_with_tail_threads(oracle):
+    """Option "tail_threads": one frame's board search on several host threads gives the tags of the
+    sequential search, in the same order, on every fixture image."""
+    import aprilgrid_rs_amd as A
+    d = A.TagDetector("t36h11", None, device=0)
+    for name in ALL_IMAGES:
+        img = load_image(name)
+        d.set_option("tail_threads", 1)
+        one = d.detect(img)
+        for n in (2, 5, 16):
+            d.set_option("tail_threads", n)
+            assert d.get_option("tail_threads") == n
+            par = d.detect(img)
+            assert list(par) == list(one) and all(bits_equal(par[t], one[t]) for t in one), (name, n)
+    d.close()
+
+
 def test_detect_kornia_front_end(det, oracle):
     """tests/test_detector.rs:35-43: Image<u8,3> -> 66 tags; u8c1 works; other N is refused."""
     import aprilgrid_rs_amd as A
