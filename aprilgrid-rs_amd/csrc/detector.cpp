@@ -65,6 +65,9 @@ struct agx_detector {
     // staging for the single-frame host API
     uint8_t *d_stage = nullptr;
     size_t stage_bytes = 0;
+    // agx_detect on L16 / RGB8: the u8 luma of the staged frame, computed on the device
+    uint8_t *d_luma = nullptr, *h_luma = nullptr;
+    size_t luma_bytes = 0;
     // pinned host mirrors
     FrameCounters *h_ctr = nullptr;
     size_t h_ctr_frames = 0;
@@ -558,6 +561,8 @@ void agx_detector_destroy(agx_detector *det)
     if (det->pool) destroy_worker_pool(det->pool);
     if (det->tail_workers) destroy_tail_workers(det->tail_workers);
     if (det->d_stage) (void)hipFree(det->d_stage);
+    if (det->d_luma) (void)hipFree(det->d_luma);
+    if (det->h_luma) (void)hipHostFree(det->h_luma);
     if (det->d_dbg_resp) (void)hipFree(det->d_dbg_resp);
     if (det->d_resp_store) (void)hipFree(det->d_resp_store);
     if (det->own_stream) (void)hipStreamDestroy(det->own_stream);
@@ -770,8 +775,13 @@ int agx_saddles_batch_fetch(agx_detector *det, agx_saddle *out, uint32_t cap_per
     return first_bad;
 }
 
-int agx_refined_saddle_points(agx_detector *det, const void *pixels, int width, int height, size_t row_stride_bytes,
-                              int format, agx_saddle *out, uint32_t cap, uint32_t *n_out)
+}  // extern "C"
+
+namespace {
+// agx_refined_saddle_points; with want_luma8 (L16 / RGB8 only) the u8 luma of the frame is computed on the
+// device behind the chain and is in det->h_luma (tight [H][W]) when this returns.
+int refined_saddle_points_impl(agx_detector *det, const void *pixels, int width, int height, size_t row_stride_bytes,
+                               int format, agx_saddle *out, uint32_t cap, uint32_t *n_out, bool want_luma8)
 {
     if (!det || !pixels || !n_out) return fail(det, AGX_ERR_ARG, "null argument");
     if (!valid_format(format)) return fail(det, AGX_ERR_FORMAT, kFormatMsg);
@@ -793,6 +803,22 @@ int agx_refined_saddle_points(agx_detector *det, const void *pixels, int width, 
                                   hipMemcpyHostToDevice, det->stream));
     int rc = agx_saddles_batch_enqueue(det, det->d_stage, 1, width, height, pitch, need, format);
     if (rc) return rc;
+    if (want_luma8) {  // stream-ordered behind the chain; the fetch below waits for the stream
+        const size_t lb = (size_t)width * (size_t)height;
+        if (lb > det->luma_bytes) {
+            HIP_TRY(det, hipStreamSynchronize(det->stream));
+            if (det->d_luma) (void)hipFree(det->d_luma);
+            if (det->h_luma) (void)hipHostFree(det->h_luma);
+            det->d_luma = det->h_luma = nullptr;
+            det->luma_bytes = 0;
+            HIP_TRY(det, hipMalloc((void **)&det->d_luma, lb));
+            HIP_TRY(det, hipHostMalloc((void **)&det->h_luma, lb, hipHostMallocDefault));
+            det->luma_bytes = lb;
+        }
+        hipError_t e = (hipError_t)launch_luma8(det->d_stage, pitch, format, det->d_luma, width, height, det->stream);
+        if (e != hipSuccess) return fail(det, AGX_ERR_HIP, std::string("k_luma8: ") + hipGetErrorString(e));
+        HIP_TRY(det, hipMemcpyAsync(det->h_luma, det->d_luma, lb, hipMemcpyDeviceToHost, det->stream));
+    }
     // one frame: the pinned host mirror of the batch fetch holds the list; a too-small `cap` reports
     // the needed size
     uint32_t count = 0;
@@ -806,6 +832,15 @@ int agx_refined_saddle_points(agx_detector *det, const void *pixels, int width, 
     if (c.n_out) std::memcpy(out, det->h_out + (size_t)c.out_offset * 5, (size_t)c.n_out * sizeof(agx_saddle));
     det->last_error.clear();
     return AGX_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int agx_refined_saddle_points(agx_detector *det, const void *pixels, int width, int height, size_t row_stride_bytes,
+                              int format, agx_saddle *out, uint32_t cap, uint32_t *n_out)
+{
+    return refined_saddle_points_impl(det, pixels, width, height, row_stride_bytes, format, out, cap, n_out, false);
 }
 
 // The single frame of the last agx_refined_saddle_points call again, into a larger buffer (its
@@ -884,23 +919,23 @@ int agx_detect(agx_detector *det, const void *pixels, int width, int height, siz
     if (!valid_format(format)) return fail(det, AGX_ERR_FORMAT, kFormatMsg);
     if (width < 2 || height < 2) return fail(det, AGX_ERR_ARG, "width and height must be >= 2");
     if (format == AGX_LF32) return fail(det, AGX_ERR_FORMAT, "an f32 luma plane carries no u8 luma for the decode: use agx_detect_planes");
-    // detector.rs:507-508: u8 luma for the decode, saddle chain on the device
-    std::vector<uint8_t> &grey = det->scratch_grey;
-    grey.resize((size_t)width * height);
-    int rc = luma8(pixels, width, height, row_stride_bytes, format, grey.data());
-    if (rc) return rc;
+    // detector.rs:507-508: u8 luma for the decode, saddle chain on the device.  L8 is its own luma; for
+    // L16 / RGB8 the conversion (the integer formulas of luma8()) runs on the device behind the chain -- the
+    // frame is there anyway -- and comes back with the saddles
+    const bool device_luma = format != AGX_L8;
     std::vector<agx_saddle> &saddles = det->scratch_saddles;
     if (saddles.size() < 16384) saddles.resize(16384);
     uint32_t ns = 0;
-    rc = agx_refined_saddle_points(det, pixels, width, height, row_stride_bytes, format, saddles.data(),
-                                   (uint32_t)saddles.size(), &ns);
+    int rc = refined_saddle_points_impl(det, pixels, width, height, row_stride_bytes, format, saddles.data(),
+                                        (uint32_t)saddles.size(), &ns, device_luma);
     if (rc == AGX_ERR_CAPACITY && ns > saddles.size()) {  // longer list than ever before: the batch is still fetchable
         saddles.resize(ns);
         rc = refetch_single(det, saddles.data(), (uint32_t)saddles.size(), &ns);
     }
     if (rc) return rc;
-    return agx_detect_from_saddles(det, saddles.data(), ns, grey.data(), width, height, (size_t)width, out, cap,
-                                   n_out);
+    const uint8_t *grey = device_luma ? det->h_luma : (const uint8_t *)pixels;
+    const size_t grey_stride = device_luma ? (size_t)width : row_stride_bytes;
+    return agx_detect_from_saddles(det, saddles.data(), ns, grey, width, height, grey_stride, out, cap, n_out);
 }
 
 int agx_detect_planes(agx_detector *det, const float *luma32f, size_t stride32f_bytes, const uint8_t *luma8,
@@ -1025,6 +1060,14 @@ int agx_debug_fetch(agx_detector *det, int frame, int what, void *host_out, size
         if (cap_bytes < 8 * sizeof(uint32_t)) return AGX_ERR_CAPACITY;
         const uint32_t v[8] = {c.flags, c.n_seeds, c.n_big, c.n_clusters + c.n_clusters2, c.n_cand, c.n_roots, c.n_refined, c.n_out};
         std::memcpy(host_out, v, sizeof v);
+        return AGX_OK;
+    }
+    case 9: {  // AGX_DBG_LUMA8: the u8 luma the device computed for the last agx_detect on an L16 / RGB8 image
+        const size_t lb = (size_t)a.W * (size_t)a.H;
+        *n_items = lb;
+        if (!det->h_luma || det->luma_bytes < lb) return fail(det, AGX_ERR_STATE, "no device luma: agx_detect on an L16 / RGB8 image first");
+        if (cap_bytes < lb) return AGX_ERR_CAPACITY;
+        std::memcpy(host_out, det->h_luma, lb);
         return AGX_OK;
     }
     case 8: {  // AGX_DBG_REDZONES: {buffers, damaged guard bytes, first damaged buffer, its offset (from the payload

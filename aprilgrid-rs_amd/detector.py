@@ -355,7 +355,7 @@ class TagDetector:
         """Intermediate product of the last batch: 'blur', 'resp' (HxW f32; K1's in-register response,
         needs set_option("store_response", 1) before the batch), 'resp_recomputed', 'min' (f32),
         'centers' (cluster table sorted by first pixel), 'refined' (unfiltered saddles)."""
-        code = {"blur": 0, "resp": 1, "min": 2, "centers": 3, "refined": 4, "counters": 5, "resp_recomputed": 6, "verify_stats": 7, "redzones": 8}[what]
+        code = {"blur": 0, "resp": 1, "min": 2, "centers": 3, "refined": 4, "counters": 5, "resp_recomputed": 6, "verify_stats": 7, "redzones": 8, "luma8": 9}[what]
         n = C.c_size_t(0)
         if code in (0, 1, 6):
             assert shape is not None
@@ -368,6 +368,9 @@ class TagDetector:
             buf = np.empty(20, np.uint32)
         elif code == 8:
             buf = np.empty(6, np.uint32)
+        elif code == 9:
+            assert shape is not None
+            buf = np.empty(shape, np.uint8)
         elif code == 3:
             buf = np.empty(1 << 20, _CLUSTER_DTYPE)
         else:

@@ -302,6 +302,8 @@ enum { AGX_DBG_BLUR = 0, AGX_DBG_RESP = 1, AGX_DBG_MIN = 2, AGX_DBG_CENTERS = 3,
        AGX_DBG_RESP_RECOMPUTED = 6, /* width*height floats: the response recomputed from the stored blur
                                        plane by a separate kernel (cross-check of AGX_DBG_RESP) */
        AGX_DBG_VERIFY_STATS = 7,    /* 20 x uint32: re-test statistics of K2 (debug_ablation bits 128 / 2048) */
+       AGX_DBG_LUMA8 = 9,   /* width*height bytes: to_luma8 as the device computed it for the last agx_detect on an
+                               L16 / RGB8 image (agx_detect converts on the device; agx_luma8 is the host's) */
        AGX_DBG_REDZONES = 8 /* 6 x uint32: workspace buffers, damaged guard bytes, first damaged buffer, its byte
                                offset from the payload start (int32), device address of buffer 0 (lo, hi: for the
                                check of the check).  Guard bytes exist only in handles created with

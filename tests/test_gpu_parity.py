@@ -98,6 +98,22 @@ def test_detect_other_tag_families(oracle, family):
     d.close()
 
 
+def test_device_luma8_of_detect_equals_the_hosts(det, oracle):
+    """agx_detect converts L16 / RGB8 frames to the u8 luma of the decode (detector.rs:507) on the device:
+    every u16 value, random RGB triples and the grey axis must give the bytes of the host's agx_luma8 and
+    of the oracle's restatement of image 0.25.9."""
+    import aprilgrid_rs_amd as A
+    rng = np.random.default_rng(21)
+    l16 = np.arange(65536, dtype=np.uint16).reshape(256, 256)
+    rgb = rng.integers(0, 256, (300, 401, 3), dtype=np.uint8)
+    grey = np.repeat(np.arange(256, dtype=np.uint8), 3).reshape(16, 16, 3)
+    sat = np.array([[[255, 255, 255], [255, 0, 0], [0, 255, 0], [0, 0, 255], [0, 0, 0], [1, 1, 1], [254, 255, 255], [13, 200, 77]]] * 4, np.uint8)
+    for img in (l16, rgb, grey, sat, load_image("iphone.png"), load_image("TUM_VI.png")):
+        det.detect(img)
+        got = det.debug_fetch(0, "luma8", img.shape[:2])
+        assert np.array_equal(got, A.TagDetector.luma8(img)) and np.array_equal(got, oracle.luma_u8(img)), img.shape
+
+
 def test_detect_with_tail_threads(oracle):
     """Option "tail_threads": one frame's board search on several host threads gives the tags of the
     sequential search, in the same order, on every fixture image."""
