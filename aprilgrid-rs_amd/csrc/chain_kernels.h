@@ -138,7 +138,9 @@ constexpr int MASK_PAD_X = 64;  // zero columns on each side of the transposed m
 int init_device_kernels();
 
 int launch_debug_resp(const ChainArgs &a, int frame, float *dst, void *stream);
-// u8 luma (to_luma8) of one staged L16 (format 1) / RGB8 (format 2) frame: [H][pitch] -> tight [H][W]
-int launch_luma8(const void *src, size_t pitch, int format, uint8_t *dst, int W, int H, void *stream);
+// u8 luma (to_luma8) of n_frames L16 (format 1) / RGB8 (format 2) frames in device memory: rows `pitch`
+// bytes apart, frames `frame_stride` bytes apart -> tight [n_frames][H][W]
+int launch_luma8(const void *src, size_t pitch, size_t frame_stride, int n_frames, int format, uint8_t *dst, int W, int H,
+                 void *stream);
 
 }  // namespace agx

@@ -1875,12 +1875,14 @@ int init_device_kernels()
 // agx_detect on L16 / RGB8 images: the frame is in device memory anyway, and the host spends 1-2 ms on a
 // 1920x1080 RGB frame where this kernel and the copy back take 0.05 ms.
 template <int FMT>
-__global__ void __launch_bounds__(256) k_luma8(const uint8_t *src, size_t pitch, uint8_t *dst, int W, int H)
+__global__ void __launch_bounds__(256) k_luma8(const uint8_t *src, size_t pitch, size_t frame_stride, uint8_t *dst, int W, int H,
+                                               int n_frames)
 {
-    const size_t n = (size_t)W * (size_t)H;
+    const size_t plane = (size_t)W * (size_t)H, n = plane * (size_t)n_frames;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t y = i / (size_t)W, x = i - y * (size_t)W;
-        const uint8_t *row = src + y * pitch;
+        const size_t f = i / plane, r = i - f * plane;
+        const size_t y = r / (size_t)W, x = r - y * (size_t)W;
+        const uint8_t *row = src + f * frame_stride + y * pitch;
         uint32_t v;
         if (FMT == 1) {
             v = ((uint32_t)reinterpret_cast<const uint16_t *>(row)[x] + 128u) / 257u;
@@ -1891,12 +1893,14 @@ __global__ void __launch_bounds__(256) k_luma8(const uint8_t *src, size_t pitch,
     }
 }
 
-int launch_luma8(const void *src, size_t pitch, int format, uint8_t *dst, int W, int H, void *stream)
+int launch_luma8(const void *src, size_t pitch, size_t frame_stride, int n_frames, int format, uint8_t *dst, int W, int H, void *stream)
 {
-    const size_t n = (size_t)W * (size_t)H;
-    const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 4096);
-    if (format == 1) hipLaunchKernelGGL((k_luma8<1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint8_t *)src, pitch, dst, W, H);
-    else if (format == 2) hipLaunchKernelGGL((k_luma8<2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint8_t *)src, pitch, dst, W, H);
+    const size_t n = (size_t)W * (size_t)H * (size_t)n_frames;
+    const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 16384);
+    if (format == 1)
+        hipLaunchKernelGGL((k_luma8<1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint8_t *)src, pitch, frame_stride, dst, W, H, n_frames);
+    else if (format == 2)
+        hipLaunchKernelGGL((k_luma8<2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint8_t *)src, pitch, frame_stride, dst, W, H, n_frames);
     else return (int)hipErrorInvalidValue;
     return hipGetLastError();
 }

@@ -154,6 +154,15 @@ extern "C" int agx_detect_batch(agx_detector *det, const void *frames, const voi
         }
         rc = agx_saddles_batch_enqueue(det, d_chunk, nf, width, height, row_stride_bytes, frame_stride_bytes, format);
         if (rc) break;
+        // detector.rs:507: u8 luma for the decode.  L8 frames are their own; L16 / RGB8 chunks are converted on
+        // the device behind the chain (the frames are there) and come back with the saddles
+        const uint8_t *h_luma = nullptr;
+        if (format != AGX_L8) {
+            if (ci >= 2) pool->wait();  // tails of the chunk two back read this half of the luma staging
+            rc = agx_internal_chunk_luma8(det, d_chunk, nf, width, height, row_stride_bytes, frame_stride_bytes, format, par,
+                                          (size_t)chunk, &h_luma);
+            if (rc) break;
+        }
         // the tails of the chunk two back read saddles[par]: they must be done before it is refilled
         if (ci >= 2) pool->wait();
         saddles[par].resize((size_t)nf * cap_s);
@@ -185,18 +194,11 @@ extern "C" int agx_detect_batch(agx_detector *det, const void *frames, const voi
             const agx_saddle *sp = saddles[par].data() + (size_t)f * cap_s;
             const uint32_t n_s = ns[par][f];
             const uint8_t *img = h_chunk + (size_t)f * frame_stride_bytes;
+            const uint8_t *dev_grey = h_luma ? h_luma + (size_t)f * (size_t)width * (size_t)height : nullptr;
             pool->submit([=, &first_bad] {
               try {  // nothing unwinds out of a worker thread: host memory exhaustion becomes the frame's status
-                // detector.rs:507: u8 luma for the decode (a copy for L8 too: the tail reads rows at a tight pitch)
-                std::vector<uint8_t> grey;
-                const uint8_t *g = img;
-                size_t gstride = row_stride_bytes;
-                if (format != AGX_L8) {
-                    grey.resize((size_t)width * height);
-                    luma8(img, width, height, row_stride_bytes, format, grey.data());
-                    g = grey.data();
-                    gstride = (size_t)width;
-                }
+                const uint8_t *g = dev_grey ? dev_grey : img;  // L8: the frame itself, read at its own pitch
+                const size_t gstride = dev_grey ? (size_t)width : row_stride_bytes;
                 std::vector<agx_tag> tags;
                 detect_tail(*fam, max_boards, std::vector<agx_saddle>(sp, sp + n_s), g, width, height, gstride, tags);
                 int stf = AGX_OK;

@@ -98,7 +98,6 @@ struct agx_detector {
     void *pool = nullptr;  // agx_detect_batch: worker threads of the host tail
     int pool_threads = 0;
     std::vector<agx_saddle> scratch_saddles;  // host staging of agx_detect / agx_detect_planes (reused)
-    std::vector<uint8_t> scratch_grey;
 
     std::string last_error;
 };
@@ -436,6 +435,31 @@ __attribute__((visibility("hidden"))) void *agx_internal_pool(agx_detector *det,
         det->pool_threads = n_threads;
     }
     return det->pool;
+}
+// agx_detect_batch: u8 luma of a chunk of L16 / RGB8 frames (device pointers), computed on the device
+// behind whatever is on the detector's stream and copied into pinned host memory: [n_frames][H][W] at
+// *h_out (valid after the stream has been waited for -- the chunk's fetch does).  parity: two staging halves.
+__attribute__((visibility("hidden"))) int agx_internal_chunk_luma8(agx_detector *det, const void *d_frames, int n_frames,
+                                                                   int width, int height, size_t row_stride,
+                                                                   size_t frame_stride, int format, int parity,
+                                                                   size_t chunk_capacity_frames, const uint8_t **h_out)
+{
+    const size_t plane = (size_t)width * (size_t)height, half = plane * chunk_capacity_frames;
+    if (2 * half > det->luma_bytes) {
+        if (hipStreamSynchronize(det->stream) != hipSuccess) return AGX_ERR_HIP;
+        if (det->d_luma) (void)hipFree(det->d_luma);
+        if (det->h_luma) (void)hipHostFree(det->h_luma);
+        det->d_luma = det->h_luma = nullptr;
+        det->luma_bytes = 0;
+        if (hipMalloc((void **)&det->d_luma, 2 * half) != hipSuccess) return AGX_ERR_HIP;
+        if (hipHostMalloc((void **)&det->h_luma, 2 * half, hipHostMallocDefault) != hipSuccess) return AGX_ERR_HIP;
+        det->luma_bytes = 2 * half;
+    }
+    uint8_t *d = det->d_luma + (size_t)parity * half, *h = det->h_luma + (size_t)parity * half;
+    if (launch_luma8(d_frames, row_stride, frame_stride, n_frames, format, d, width, height, det->stream) != 0) return AGX_ERR_HIP;
+    if (hipMemcpyAsync(h, d, plane * (size_t)n_frames, hipMemcpyDeviceToHost, det->stream) != hipSuccess) return AGX_ERR_HIP;
+    *h_out = h;
+    return AGX_OK;
 }
 __attribute__((visibility("hidden"))) const void *agx_internal_family(const agx_detector *det) { return &det->fam; }
 __attribute__((visibility("hidden"))) int agx_internal_max_boards(const agx_detector *det) { return det->params.max_num_of_boards; }
@@ -815,7 +839,7 @@ int refined_saddle_points_impl(agx_detector *det, const void *pixels, int width,
             HIP_TRY(det, hipHostMalloc((void **)&det->h_luma, lb, hipHostMallocDefault));
             det->luma_bytes = lb;
         }
-        hipError_t e = (hipError_t)launch_luma8(det->d_stage, pitch, format, det->d_luma, width, height, det->stream);
+        hipError_t e = (hipError_t)launch_luma8(det->d_stage, pitch, need, 1, format, det->d_luma, width, height, det->stream);
         if (e != hipSuccess) return fail(det, AGX_ERR_HIP, std::string("k_luma8: ") + hipGetErrorString(e));
         HIP_TRY(det, hipMemcpyAsync(det->h_luma, det->d_luma, lb, hipMemcpyDeviceToHost, det->stream));
     }
