@@ -206,6 +206,9 @@ __device__ __forceinline__ int H_full_segs(const ChainArgs &a) { return a.H / a.
 
 // RESP: debug instantiation (agx_detector_set_option "store_response") that also stores the
 // determinant this kernel evaluates in registers, for the parity tests (AGX_DBG_RESP).
+#ifndef AGX_BLUR_STORE_AUX
+#define AGX_BLUR_STORE_AUX 0  // cache policy bits of the blur plane's buffer stores (A/B builds: -DAGX_BLUR_STORE_AUX=2 = nt)
+#endif
 template <int FMT, bool A4, bool RESP = false>
 __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
 {
@@ -517,7 +520,7 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
                     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                     const u32x4 v4 = __builtin_bit_cast(u32x4, bc);
                     const uint32_t row_off = (b >= ys && b < ye) ? (uint32_t)((a.dbg & 8) ? (b & 7) : b) * (uint32_t)W * 4u : blur_bytes;
-                    __builtin_amdgcn_raw_buffer_store_b128(v4, rs_blur, c0 * 4, (int)row_off, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(v4, rs_blur, c0 * 4, (int)row_off, AGX_BLUR_STORE_AUX);
                 } else {
                     float *dst = (b >= ys && b < ye) ? blur_f + (size_t)((a.dbg & 8) ? (b & 7) : b) * W + c0 : a.dummy + c0;
 #pragma unroll
