@@ -86,7 +86,8 @@ struct agx_detector {
 
     bool enqueued = false;
     int profiling = 0;  // 0 off, 1 = K1 only, 2 = every kernel
-    int prof_stride = 1;        // level 1: time the blur kernel of every prof_stride-th batch only
+    int prof_stride = 1;        // level 1: time the selected kernel of every prof_stride-th batch only
+    int prof_kernel = K_BLUR_HESSIAN;  // level 1: which kernel (option "profile_kernel", default the blur kernel)
     uint64_t prof_batches = 0;  // batches enqueued while profiling
     std::vector<EventPair> pending_events;
     std::vector<hipEvent_t> free_events;
@@ -362,7 +363,7 @@ int enqueue_chunk(agx_detector *d, int f0, int nf, hipStream_t st)
     for (int k = 0; k < K_COUNT; ++k) {
         EventPair ev{nullptr, nullptr, k};
         // (an event pair costs the stream two ~5 us gaps around the kernel: level 1 can sample)
-        const bool timed = d->profiling >= 2 || (d->profiling == 1 && k == K_BLUR_HESSIAN && d->prof_batches % (uint64_t)d->prof_stride == 0);
+        const bool timed = d->profiling >= 2 || (d->profiling == 1 && k == d->prof_kernel && d->prof_batches % (uint64_t)d->prof_stride == (uint64_t)d->prof_stride - 1);  // the last of each group: never the first batch after an idle stream
         if (timed) {
             ev.a = get_event(d);
             ev.b = get_event(d);
@@ -633,6 +634,7 @@ int agx_detector_set_option(agx_detector *det, const char *name, int value)
     else if (!std::strcmp(name, "debug_ablation")) det->dbg = value;  // timing only, results invalid
     else if (!std::strcmp(name, "store_response")) det->store_resp = value != 0;
     else if (!std::strcmp(name, "profile_stride")) det->prof_stride = value > 1 ? value : 1;
+    else if (!std::strcmp(name, "profile_kernel")) det->prof_kernel = value >= 0 && value < K_COUNT ? value : K_BLUR_HESSIAN;
     else if (!std::strcmp(name, "tail_threads")) {
         const int n = value < 1 ? 1 : (value > 64 ? 64 : value);
         if (n != det->tail_threads) {

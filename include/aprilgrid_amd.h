@@ -118,6 +118,10 @@ int agx_detector_set_limits(agx_detector *det, uint32_t max_candidates, uint32_t
  *                          registers (parity tests: agx_debug_fetch AGX_DBG_RESP); slower
  *   "profile_stride"       with agx_profile_enable(det, 1): time the blur kernel of every n-th batch
  *                          only (an event pair costs the stream two ~5 us gaps around the kernel)
+ *   "profile_kernel"       with agx_profile_enable(det, 1): which of the AGX_N_KERNELS launches is timed (0 = the blur
+ *                          kernel, the default).  One kernel at a time keeps its neighbours back to back on the
+ *                          stream, so the figure is the kernel's own duration; level 2 (all at once) opens a gap
+ *                          in front of every kernel
  *   "tail_threads"         n > 1: agx_detect / agx_detect_planes / agx_detect_from_saddles search the boards of
  *                          ONE frame on n host threads (the up-to-30 seed saddles of try_find_best_board,
  *                          detector.rs:611-625, in waves of n, merged in the reference's order: same result;
