@@ -493,7 +493,9 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
                     v = v + prod(j + 5, 5);
                     v = v + prod(j + 6, 6);
                 } else {
-                    v = x[j] * w0;
+                    // the reference folds from 0.0 (image_util.rs:146,160,178: `let mut sum = 0.0`): 0.0 + (-0.0) is
+                    // +0.0, which only an arbitrary f32 plane can produce (integer luma is >= 0, the taps > 0)
+                    v = FMT == 3 ? 0.0f + x[j] * w0 : x[j] * w0;
                     v = v + x[j + 1] * w1;
                     v = v + x[j + 2] * w2;
                     v = v + x[j + 3] * w3;
@@ -509,7 +511,7 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
                 acc[(k + 3) % 7][j] = acc[(k + 3) % 7][j] + p3;      // tap 3 of row r
                 acc[(k + 4) % 7][j] = acc[(k + 4) % 7][j] + p2;      // tap 2 of row r+1
                 acc[(k + 5) % 7][j] = acc[(k + 5) % 7][j] + p1;      // tap 1 of row r+2
-                acc[(k + 6) % 7][j] = p0;                            // tap 0 of row r+3 (free slot)
+                acc[(k + 6) % 7][j] = FMT == 3 ? 0.0f + p0 : p0;     // tap 0 of row r+3 (free slot; image_util.rs:190-201 starts from 0.0, see above)
             }
             const int b = r - 3;
             // the store is issued for every row (rows outside the segment go to a dummy row) so

@@ -117,6 +117,9 @@ extern "C" int agx_detect_batch(agx_detector *det, const void *frames, const voi
     if (width < 2 || height < 2) return AGX_ERR_ARG;
     const size_t bpp = format == AGX_L8 ? 1 : (format == AGX_L16 ? 2 : 3);
     if (row_stride_bytes < (size_t)width * bpp || (n_frames > 1 && frame_stride_bytes < row_stride_bytes * (size_t)height)) return AGX_ERR_ARG;
+    // one frame: the stride between frames means nothing to the caller (0 is a natural value), but the staging
+    // and the upload below are sized by it -- use the frame's own extent
+    if (n_frames == 1 && frame_stride_bytes < row_stride_bytes * (size_t)height) frame_stride_bytes = row_stride_bytes * (size_t)height;
     if (n_threads <= 0) n_threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 64u);
     WorkerPool *pool = static_cast<WorkerPool *>(agx_internal_pool(det, n_threads));
     if (!pool) return AGX_ERR_ARG;
@@ -140,6 +143,11 @@ extern "C" int agx_detect_batch(agx_detector *det, const void *frames, const voi
     uint32_t cap_s = 16384;  // saddles per frame the staging holds; grown when a chunk has a longer list
     std::atomic<int> first_bad{AGX_OK};
     int rc = AGX_OK;
+    bool pending_batch = false;  // a chunk is enqueued on the detector and not fetched yet
+    // Nothing unwinds through the C boundary: an allocation failure on this thread (staging vectors, a task's
+    // std::function) ends the loop like any other error, after the worker tasks -- which hold pointers into
+    // saddles[] and a reference to first_bad -- have finished.
+    try {
     for (int c0 = 0, ci = 0; c0 < n_frames; c0 += chunk, ++ci) {
         const int nf = std::min(chunk, n_frames - c0);
         const int par = ci & 1;
@@ -154,6 +162,7 @@ extern "C" int agx_detect_batch(agx_detector *det, const void *frames, const voi
         }
         rc = agx_saddles_batch_enqueue(det, d_chunk, nf, width, height, row_stride_bytes, frame_stride_bytes, format);
         if (rc) break;
+        pending_batch = true;
         // detector.rs:507: u8 luma for the decode.  L8 frames are their own; L16 / RGB8 chunks are converted on
         // the device behind the chain (the frames are there) and come back with the saddles
         const uint8_t *h_luma = nullptr;
@@ -169,6 +178,7 @@ extern "C" int agx_detect_batch(agx_detector *det, const void *frames, const voi
         ns[par].assign(nf, 0);
         fst[par].assign(nf, 0);
         rc = agx_saddles_batch_fetch(det, saddles[par].data(), cap_s, ns[par].data(), fst[par].data());  // waits for the device
+        pending_batch = false;
         if (rc == AGX_ERR_CAPACITY) {
             // a list longer than the staging (pure-noise frames of several megapixels; the reference's
             // Vec has no limit): the batch is still fetchable -- make room and fetch again
@@ -221,7 +231,11 @@ extern "C" int agx_detect_batch(agx_detector *det, const void *frames, const voi
             });
         }
     }
+    } catch (...) {
+        rc = AGX_ERR_CAPACITY;  // host memory exhausted
+    }
     pool->wait();
+    if (pending_batch) agx_internal_abandon_batch(det);  // an error between enqueue and fetch: no stale batch is left to be fetched later
     if (rc) return rc;
     return first_bad.load();
 }

@@ -388,7 +388,14 @@ int enqueue_chain(agx_detector *d)
     // kernel cleared, or -- first batch, larger batch, after an error -- one memset
     const int p = d->ctr_cur ^ 1;
     const size_t need = (size_t)a.n_frames + 1;
-    if (d->ctr_cleared[p] < need)
+    // While the stream is being captured into a HIP graph the memset is always recorded: a replayed
+    // graph must clear its own set every time (the clearing by the previous batch's last kernel is a fact
+    // about the capture, not about the replays -- an odd number of captured batches would otherwise
+    // accumulate counters from the second replay on), and nothing "known clear" survives the capture.
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(d->stream, &cap);
+    const bool capturing = cap == hipStreamCaptureStatusActive;
+    if (capturing || d->ctr_cleared[p] < need)
         HIP_TRY(d, hipMemsetAsync(d->d_ctr[p], 0, need * sizeof(FrameCounters), d->stream));
     d->ctr_cleared[p] = 0;
     a.ctr = d->d_ctr[p];
@@ -399,7 +406,7 @@ int enqueue_chain(agx_detector *d)
     // and lost every time: see DESIGN.md; batches in flight are separate detectors)
     const int rc = enqueue_chunk(d, 0, a.n_frames, d->stream);
     if (rc) return rc;
-    d->ctr_cleared[p ^ 1] = need;  // k_rare of this batch clears it, stream-ordered before the next batch
+    d->ctr_cleared[p ^ 1] = capturing ? 0 : need;  // k_rare of this batch clears it, stream-ordered before the next batch
     d->ctr_cur = p;
     d->enqueued = true;
     return AGX_OK;
@@ -461,6 +468,13 @@ __attribute__((visibility("hidden"))) int agx_internal_chunk_luma8(agx_detector 
     if (hipMemcpyAsync(h, d, plane * (size_t)n_frames, hipMemcpyDeviceToHost, det->stream) != hipSuccess) return AGX_ERR_HIP;
     *h_out = h;
     return AGX_OK;
+}
+__attribute__((visibility("hidden"))) void agx_internal_abandon_batch(agx_detector *det)
+{
+    if (!det) return;
+    (void)hipStreamSynchronize(det->stream);
+    harvest_events(det);
+    det->enqueued = false;
 }
 __attribute__((visibility("hidden"))) const void *agx_internal_family(const agx_detector *det) { return &det->fam; }
 __attribute__((visibility("hidden"))) int agx_internal_max_boards(const agx_detector *det) { return det->params.max_num_of_boards; }

@@ -322,7 +322,11 @@ int agx_group_saddles_fetch(agx_group *g, agx_saddle *out, uint32_t cap_per_fram
             if ((status & (AGX_FRAME_CANDIDATE_OVERFLOW | AGX_FRAME_CLUSTER_OVERFLOW | AGX_FRAME_SADDLE_OVERFLOW)) || cnt > cap_per_frame ||
                 (unsigned long long)off + cnt > g->slab_records)
                 st = AGX_ERR_CAPACITY;
-            counts[gf] = st == AGX_OK ? cnt : 0;
+            // as agx_saddles_batch_fetch: a list that is merely longer than the caller's room reports its
+            // length (so the caller can size a retry); a frame whose device-side lists overflowed reports 0
+            const bool device_overflow = (status & (AGX_FRAME_CANDIDATE_OVERFLOW | AGX_FRAME_CLUSTER_OVERFLOW | AGX_FRAME_SADDLE_OVERFLOW)) ||
+                                         (unsigned long long)off + cnt > g->slab_records;
+            counts[gf] = device_overflow ? 0 : cnt;
             if (frame_status) frame_status[gf] = st;
             if (st != AGX_OK) {
                 if (first_bad == AGX_OK) {

@@ -169,11 +169,14 @@ class TagDetector:
                                                 C.byref(n)))
         return {int(out[i].id): np.array(out[i].xy, np.float32).reshape(4, 2) for i in range(n.value)}
 
-    def detect_batch(self, frames, n_threads=0, cap=1024, device_frames=None):
+    def detect_batch(self, frames, n_threads=0, cap=1024, device_frames=None, raise_on_overflow=True):
         """detect() over a batch: frames = numpy [N,H,W] uint8 / uint16 or [N,H,W,3] uint8 in host
         memory (optionally also resident on the GPU as the torch tensor device_frames).  The chain
         runs on the device chunk by chunk while n_threads host threads (0 = all cores, <= 64) run the
-        board search + decode.  -> list of {tag_id: 4x2 corners}."""
+        board search + decode.  -> list of {tag_id: 4x2 corners}.  A frame with more than `cap` tags (or
+        over the detector's saddle capacity) raises by default; raise_on_overflow=False returns
+        (results, status) instead: status[i] != 0 marks such a frame (its entry is None), every other
+        frame keeps its result."""
         a = np.ascontiguousarray(frames)
         _, fmt, stride = _image_args(a[0])
         if fmt == _ffi.AGX_LF32:
@@ -182,10 +185,24 @@ class TagDetector:
         out = np.zeros((n, cap), np.dtype([("id", "u4"), ("xy", "f4", (8,))]))
         counts = np.zeros(n, np.uint32)
         status = np.zeros(n, np.int32)
-        dptr = device_frames.data_ptr() if device_frames is not None else None
-        self._check(self._lib.agx_detect_batch(self._h, a.ctypes.data, dptr, n, w, h, stride, stride * h, fmt,
-                                               out.ctypes.data, cap, counts.ctypes.data, status.ctypes.data, n_threads))
-        return [{int(t["id"]): t["xy"].reshape(4, 2).copy() for t in out[i, : counts[i]]} for i in range(n)]
+        dptr = None
+        if device_frames is not None:
+            # the chain reads device_frames, the decode reads `frames`: they must be the same pixels
+            t = device_frames
+            if not (getattr(t, "is_cuda", False) and t.is_contiguous()):
+                raise AgxError(_ffi.AGX_ERR_ARG, "device_frames must be a contiguous CUDA tensor")
+            if t.device.index != self.device:
+                raise AgxError(_ffi.AGX_ERR_ARG, "device_frames is on device %s, the detector on %d" % (t.device.index, self.device))
+            if tuple(t.shape) != tuple(a.shape) or t.element_size() != a.dtype.itemsize:
+                raise AgxError(_ffi.AGX_ERR_ARG, "device_frames %s / %d-byte elements differ from frames %s / %d-byte elements"
+                               % (tuple(t.shape), t.element_size(), tuple(a.shape), a.dtype.itemsize))
+            dptr = t.data_ptr()
+        rc = self._lib.agx_detect_batch(self._h, a.ctypes.data, dptr, n, w, h, stride, stride * h, fmt,
+                                        out.ctypes.data, cap, counts.ctypes.data, status.ctypes.data, n_threads)
+        if rc != _ffi.AGX_OK and (raise_on_overflow or rc != _ffi.AGX_ERR_CAPACITY):
+            self._check(rc)
+        res = [None if status[i] != 0 else {int(t["id"]): t["xy"].reshape(4, 2).copy() for t in out[i, : counts[i]]} for i in range(n)]
+        return res if raise_on_overflow else (res, status)
 
     def detect_kornia(self, img):
         """kornia::image::Image<u8, N>: an HxWxN uint8 array, N in {1, 3} (else the reference

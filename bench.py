@@ -30,7 +30,14 @@ N = 1 additionally reports, in the same line:
                  front-end layout), L16 x256 and the pure-noise sensitivity row, each with its own
                  K1 roofline and oracle check;
   host_boundary  the PCIe-inclusive rate: the same batch handed over in pinned HOST memory, saddle
-                 lists back in host memory, batch after batch -- never `value`.
+                 lists back in host memory, batch after batch -- never `value`;
+  extra_configs["configs[0]_single_frame"], reference_bench_detection
+                 BASELINE.json configs[0] (one frame through detect: the reference's
+                 data/1520525725372653511.png and one synthetic 1280x800 frame) and the reference's own
+                 bench shape (benches/bench_detection.rs:24-36) on its 7 images: latency of the GPU
+                 chain, of the GPU path's detect and of the oracle's detect, side by side.
+roofline additionally carries chain_frac (the bytes this design moves per step / ms_per_step / 8 TB/s)
+and a_min_frac (SURVEY.md 8(d)'s fused lower bound over the same time).
 """
 import argparse
 import json
@@ -512,8 +519,11 @@ def main():
         if traffic is None and world == 1:
             traffic, traffic_src = recorded_traffic("%dx%dx%d_%s%s" % (F, W, H, args.format, "_noise" if args.noise else ""))
         a_mat = in_b + 12  # SURVEY.md 8(d) A_mat: input + blur write + response write + response re-read
-        a_design = in_b + 4 + 0.125 + 0.125  # this design: input + blur write + mask write (K1) + mask read (K2);
-        # the sparse stages (verify / refine gathers at ~2.4 % of the pixels, lists) add < 0.5 B/px
+        # the bytes THIS design is built to move per pixel (the response plane is never materialised): input +
+        # blur write + mask write (K1) + mask re-read (K2) + 0.125 for the sparse stages' algorithmic gathers and
+        # lists (about 970 nine-row windows and 5 800 3x3 re-tests per megapixel frame): 5.375 B/px for L8
+        a_design = in_b + 4 + 0.125 + 0.125 + 0.125
+        a_min = 2 * in_b  # SURVEY.md 8(d) A_min: the input read twice, nothing dense written
         roof = k1_roofline(px_per_step_rank, in_b, k1_ms, k1_n, traffic, traffic_src)
         # the same kernel alone on the GPU (serial pass below the timed region): with
         # --pipeline > 1 the timed launches share the chip with another step's sparse kernels
@@ -522,6 +532,16 @@ def main():
             roof["copy_GBps_this_box"] = round(copy_gbps, 1)
             if traffic:
                 roof["traffic_frac_of_copy_this_box"] = round(traffic / (roof["avg_launch_ms"] * 1e-3) / 1e9 / copy_gbps, 4)
+        # the CHAIN against the roofline -- bytes the design moves (and A_min beside it) over the
+        # whole step as timed (first launch of K1 to the end of K5, ms_per_step), against 8 TB/s
+        step_s = ms_per_step * 1e-3  # every rank runs its own 256 frames in this time
+        roof["chain_design_bytes_per_px"] = a_design
+        roof["chain_GBps"] = round(px_per_step_rank * a_design / step_s / 1e9, 1)
+        roof["chain_frac"] = round(px_per_step_rank * a_design / step_s / 1e9 / HBM_PEAK_GBPS, 4)
+        roof["a_min_bytes_per_px"] = a_min
+        roof["a_min_frac"] = round(px_per_step_rank * a_min / step_s / 1e9 / HBM_PEAK_GBPS, 4)
+        roof["chain_note"] = ("chain_frac = design bytes per GPU / ms_per_step / 8 TB/s (what the whole step achieves); frac = the blur "
+                              "kernel alone; a_min_frac = the fused lower bound of SURVEY.md 8(d) over the same step time")
         if not serial:  # batches in flight: the timed launches shared the chip; the serial pass gives the kernel alone
             roof["alone_avg_launch_ms"] = round(k1_alone_ms, 5)
             roof["alone_frac"] = round(roof["bytes_per_launch"] / (k1_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
@@ -556,8 +576,11 @@ def main():
                 "a_mat_bytes_per_px": a_mat,
                 "kernel_ms_per_step": {k: round(v[0] / max(v[1], 1), 5) for k, v in prof.items()},
                 "sum_kernel_ms_per_step": round(chain_ms, 5),
-                "a_mat_GBps": round(px_per_step_rank * a_mat / (chain_ms * 1e-3) / 1e9, 1),
-                "a_mat_frac_of_peak": round(px_per_step_rank * a_mat / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                "a_mat_equivalent_GBps": round(px_per_step_rank * a_mat / (chain_ms * 1e-3) / 1e9, 1),
+                "a_mat_equivalent_frac_of_peak": round(px_per_step_rank * a_mat / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                "a_mat_equivalent_note": "NOT bytes moved: what a design that materialises the response plane (13 B/px) would "
+                                         "have to sustain to finish in the same time; the bytes this design moves are in "
+                                         "roofline.chain_frac",
                 "design_bytes_per_px": a_design,
                 "design_GBps": round(px_per_step_rank * a_design / (chain_ms * 1e-3) / 1e9, 1),
                 "design_frac_of_peak": round(px_per_step_rank * a_design / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
@@ -603,6 +626,17 @@ def main():
                                     16, True, st, args.warmup, 4 * vf),
         }
         result["host_boundary"] = host_boundary_leg(torch, A, dev, F, W, H, 10)
+        # BASELINE.json configs[0] and the reference's own bench shape (benches/bench_detection.rs:24-36): ONE frame
+        # through detect -- latency, GPU path beside the oracle on this box's host -- and the 7-image table
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_images
+        cpu = bench_images.Cpu()
+        det1 = A.TagDetector(A.TagFamily.T36H11, None, device=dev.index)
+        try:
+            result["extra_configs"]["configs[0]_single_frame"] = bench_images.config0(det1, cpu, 9)
+            result["reference_bench_detection"] = bench_images.detection_table(det1, cpu, 5)
+        finally:
+            det1.close()
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

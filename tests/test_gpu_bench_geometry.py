@@ -9,6 +9,8 @@ heights that are / are not multiples of the segment and of the 32-row mask words
 and RGB8 / L16 at 1280x800.  Every test also reads the response the blur kernel evaluated in its
 registers (option store_response) on a second detector.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -135,3 +137,26 @@ def test_other_formats_full_size(det, det_resp, oracle, fmt):
     for i in (0, 7):
         check_frame(det_resp, oracle, host[i], i, "%s frame %d rows 128" % (fmt, i))
     det_resp.set_option("k1_rows_per_segment", 0)
+
+
+def test_reference_bench_shape_runs_and_pins_hold():
+    """f4: tools/bench_images.py -- the reference's benches/bench_detection.rs and
+    benches/bench_blur.rs shape on its own images, plus BASELINE.json configs[0] -- runs, reproduces the
+    reference's 7 tag-count pins (tests/test_detector.rs:26-32) through the GPU path, and the blur kernel's
+    plane equals the oracle's gaussian_blur_f32 bit for bit."""
+    import json
+    import subprocess
+    import sys
+    from tests.util import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_images.py"), "--runs", "2", "--no-batch"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = json.loads(r.stdout[r.stdout.index("{"):])
+    want = {"iphone.png": 66, "EuRoC.png": 36, "TUM_VI.png": 36, "right.png": 36, "r45.png": 36, "top.png": 36, "two_boards.png": 72}
+    assert {k: v["tags"] for k, v in out["detection"].items()} == want
+    assert all(v["blur_plane_bit_exact"] for v in out["blur"].values()) and len(out["blur"]) == 3
+    c0 = out["configs[0]"]
+    assert c0["data/1520525725372653511.png"]["tags"] == 36 and c0["data/1520525725372653511.png"]["size"] == "1024x1024"
+    assert c0["synthetic_1280x800_L8_frame0"]["tags"] >= 30
+    for row in list(c0.values()) + list(out["detection"].values()):
+        assert row["gpu_detect_ms"] > 0 and row["cpu_detect_ms"] > 0 and row["gpu_saddle_chain_ms_incl_pcie"] > 0

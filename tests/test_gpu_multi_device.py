@@ -165,8 +165,8 @@ def test_batches_in_flight_are_bitwise_reproducible():
 
 def test_chain_can_be_captured_into_a_hip_graph():
     """tools/graph_capture_probe.py: two consecutive batches captured with torch.cuda.CUDAGraph on a side
-    stream and replayed give the eager results (in its own process: a failed capture would leave the
-    stream in an error state)."""
+    stream and replayed give the eager results, and so does a single captured batch replayed three times
+    (in its own process: a failed capture would leave the stream in an error state)."""
     import subprocess
     import sys
     from tests.util import ROOT
@@ -174,3 +174,6 @@ def test_chain_can_be_captured_into_a_hip_graph():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "graph_capture_probe.py")], capture_output=True, text=True,
                        timeout=600, env=env)
     assert r.returncode == 0 and r.stdout.count("graph replay equals eager: True") == 2, r.stdout[-2000:] + r.stderr[-2000:]
+    # ONE captured batch replayed three times (every captured batch clears its own counter set), and an
+    # eager batch behind the graphs
+    assert r.stdout.count("equals eager: True") == 6, r.stdout[-2000:]

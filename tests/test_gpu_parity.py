@@ -566,8 +566,14 @@ def test_lf32_arbitrary_float_planes(det_resp, oracle):
     a[10:20, 10:60] *= np.float32(1e-20)
     a[30:40, 40:90] = np.float32(1e-41) * rng.integers(0, 50, (10, 50)).astype(np.float32)  # subnormals
     a[50:60, :] = rng.random((10, 132), dtype=np.float32) * np.float32(3e-19)
+    # negative zeros: the reference's sums start from +0.0 (image_util.rs:146,190), so a region of -0.0 blurs
+    # to +0.0 -- check_frame compares the blur plane bit for bit, signs of zero included
+    a[70:84, 20:40] = np.float32(-0.0)
+    a[86:90, :] = np.float32(-0.0)
     got = det_resp.refined_saddle_points(a, as_array=True)
     check_saddles(got, check_frame(det_resp, oracle, a, 0, "arbitrary f32 plane"), "arbitrary f32")
+    blur = det_resp.debug_fetch(0, "blur", a.shape)
+    assert not np.signbit(blur[74:80, 25:35]).any(), "a -0.0 region must blur to +0.0"
 
 
 @pytest.mark.parametrize("fmt", ["L8", "L16", "RGB8"])
@@ -592,6 +598,47 @@ def test_detect_batch_equals_per_frame_detect(det, oracle, fmt):
             assert bits_equal(got[i][t], one[t]) and bits_equal(got_dev[i][t], one[t])
         n_tags += len(one)
     assert n_tags > 20 * n
+
+
+def test_detect_batch_single_frame_ignores_frame_stride(det, oracle):
+    """with ONE frame the stride between frames carries no information (0 is a natural value); the
+    upload must still cover the whole frame."""
+    import ctypes as C
+    synth = synth_module()
+    fr, _ = synth.render_batch(77, 1, 320, 240, device="cuda")
+    host = np.ascontiguousarray(fr.cpu().numpy()[0])
+    ref = oracle.detect(host)
+    assert len(ref) > 10
+    out = np.zeros(256, np.dtype([("id", "u4"), ("xy", "f4", (8,))]))
+    cnt = np.zeros(1, np.uint32)
+    st = np.zeros(1, np.int32)
+    for stride in (0, 100, 320 * 240):
+        cnt[:] = 0
+        rc = det._lib.agx_detect_batch(det._h, host.ctypes.data, None, 1, 320, 240, 320, stride, 0, out.ctypes.data, 256,
+                                       cnt.ctypes.data, st.ctypes.data, 2)
+        assert rc == 0 and st[0] == 0, (stride, rc)
+        got = {int(t["id"]): t["xy"].reshape(4, 2) for t in out[: cnt[0]]}
+        assert sorted(got) == sorted(ref), stride
+        for t in ref:
+            assert bits_equal(got[t], ref[t])
+
+
+def test_detect_batch_reports_overflow_per_frame_without_raising(det):
+    """one frame over `cap` tags must not throw the other frames' results away."""
+    synth = synth_module()
+    fr, _ = synth.render_batch(300, 6, 320, 240, device="cuda")
+    host = fr.cpu().numpy()
+    full = det.detect_batch(host, n_threads=2)
+    res, status = det.detect_batch(host, n_threads=2, cap=max(len(t) for t in full) - 1, raise_on_overflow=False)
+    over = [i for i in range(6) if status[i] != 0]
+    assert over and all(res[i] is None for i in over)
+    for i in range(6):
+        if status[i] == 0:
+            assert sorted(res[i]) == sorted(full[i])
+    with pytest.raises(Exception):
+        det.detect_batch(host, n_threads=2, cap=max(len(t) for t in full) - 1)
+    with pytest.raises(Exception):  # a device tensor that is not the frames
+        det.detect_batch(host, n_threads=2, device_frames=fr[:3])
 
 
 def test_more_than_16384_saddles_per_frame(det, oracle):

@@ -1,7 +1,8 @@
-"""Can the chain be captured into a HIP graph?  Two consecutive batches (the two counter sets alternate, so
-an even number of enqueues returns the handle to the state the capture started from) are captured with
-torch.cuda.CUDAGraph on a side stream and replayed; results must equal the eager ones, and the replay
-time per batch is printed next to the eager time."""
+"""Can the chain be captured into a HIP graph?  Two consecutive batches are captured with
+torch.cuda.CUDAGraph on a side stream and replayed; then ONE batch is captured on its own and replayed
+three times (every captured batch clears its own counter set, so any number of batches per graph
+replays correctly); results must equal the eager ones, and the replay time per batch is printed next to
+the eager time."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -39,6 +40,29 @@ for i, b in enumerate(bufs):
             if a.tobytes() != e.tobytes(): same = False; break
     print("batch", i, "graph replay equals eager:", same, "saddles", int(t[:, 0].sum()), flush=True)
     ok = ok and same
+# one batch per graph, replayed three times, then an eager batch behind it
+g1 = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g1, stream=s):
+    det.saddles_batch_enqueue_to(frames, *bufs[0])
+for rep in range(3):
+    bufs[0][0].zero_(); bufs[0][1].zero_()
+    torch.cuda.synchronize()
+    g1.replay(); torch.cuda.synchronize()
+    t = bufs[0][1].cpu().numpy(); sd = bufs[0][0].cpu().numpy()
+    same = np.array_equal(t[:, [0, 2, 3]], eager[0][1][:, [0, 2, 3]])
+    if same:
+        for f in range(F):
+            a = sd[t[f, 1]: t[f, 1] + t[f, 0]]; e = eager[0][0][eager[0][1][f, 1]: eager[0][1][f, 1] + eager[0][1][f, 0]]
+            if a.tobytes() != e.tobytes(): same = False; break
+    print("single-batch graph, replay", rep, "equals eager:", same, flush=True)
+    ok = ok and same
+with torch.cuda.stream(s):
+    det.saddles_batch_enqueue_to(frames, *bufs[1])
+s.synchronize()
+t = bufs[1][1].cpu().numpy()
+same = np.array_equal(t[:, [0, 2, 3]], eager[1][1][:, [0, 2, 3]])
+print("eager batch after the graphs equals eager:", same, flush=True)
+ok = ok and same
 for name, fn in (("eager", lambda: (det.saddles_batch_enqueue_to(frames, *bufs[0]), det.saddles_batch_enqueue_to(frames, *bufs[1]))),
                  ("graph", g.replay)):
     with torch.cuda.stream(s):
