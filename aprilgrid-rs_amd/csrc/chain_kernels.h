@@ -11,12 +11,12 @@ enum Kernel : int {
     K_THRESHOLD = 1,     // K2: verify K1's candidate superset mask against the final threshold
                          //     (exact response recomputed from the blur plane at set bits only),
                          //     then mask scan -> flood seeds
-    K_FLOOD = 2,         // K3: bit-parallel flood fill per seed (32x32 per lane, 128x64 per wave) -> cluster records
-    K_REFINE = 3,        // K4: rochade_refine per cluster + k/phi filter and reference-order emission
-                         //     (by the frame's last workgroup)
-    K_RARE = 4,          // K5: one guarded launch: generic clustering fallback for frames with oversized
-                         //     clusters (then refine + emission), large-list emission (> 512 saddles)
-    K_COUNT = 5
+    K_FLOOD_REFINE = 2,  // K3: bit-parallel flood fill per seed (32x32 window per lane) -> cluster record ->
+                         //     rochade_refine of the cluster, by the same lane
+    K_RARE = 3,          // K4: per frame: second flood tier (128x64 per wave), generic clustering fallback for frames
+                         //     with larger components, k/phi filter and reference-order emission; clears the
+                         //     next batch's counters
+    K_COUNT = 4
 };
 
 // One record of K4's output list.
@@ -31,7 +31,7 @@ struct FrameCounters {
     uint32_t min_key_inv;  // ~order_preserving(min response); atomicMax
     uint32_t pad0[31];
     uint32_t n_seeds;      // flood seeds
-    uint32_t n_clusters;   // cluster records of the first flood tier (k_flood) or of the generic path
+    uint32_t n_clusters;   // cluster records of the first flood tier (k_flood_refine) or of the generic path
     uint32_t n_refined;    // rochade_refine survivors
     uint32_t max_k_bits;   // max k (k >= 0 so the raw bits order correctly)
     uint32_t flags;        // FLAG_* below
@@ -40,9 +40,8 @@ struct FrameCounters {
     uint32_t n_cand;       // generic path: candidate pixels
     uint32_t n_roots;      // generic path: union-find roots
     uint32_t n_big;        // seeds handed to the wave-wide second flood tier
-    uint32_t refine_done;  // workgroups of k_refine that have finished this frame
-    uint32_t n_clusters2;  // cluster records the second flood tier appends behind them (k_refine); its own counter:
-                           // k_refine's workgroups take n_clusters as the bound of their first-tier loop while others append
+    uint32_t refine_done;  // (unused since the emission moved into k_rare)
+    uint32_t n_clusters2;  // cluster records the second flood tier (k_rare) appends behind them
     uint32_t stats[20];    // debug_ablation & 128: verify statistics by word row within a 128-row segment
 };
 static_assert(sizeof(FrameCounters) == 256, "FrameCounters is cleared as 64 dwords");
@@ -53,7 +52,7 @@ enum : uint32_t {
     FLAG_CENTROID_INEXACT = 8u,  // a cluster's coordinate sum reached 2^24 (f32 sums of the
                                  // reference would round there)
     FLAG_BIG_CLUSTER = 16u,      // a component left the flood windows: frame redone generically
-    FLAG_LARGE_RESULT = 64u      // more saddles than k_refine's emission tail sorts: emitted by k_rare
+    FLAG_LARGE_RESULT = 64u      // more than 1024 refined records: emitted by k_rare's large-list sort
 };
 
 struct RefineConsts {
@@ -96,6 +95,10 @@ struct ChainArgs {
     int mask_yb;             // word rows: H/32 + 4
     long long mask_plane;    // words per frame = mask_wpr * mask_yb
     int force_generic;       // test hook: treat every frame as FLAG_BIG_CLUSTER
+    // debug_ablation & 4096: every wave of the sparse kernels records when it started and ended (100 MHz
+    // constant clock, s_memrealtime) -- record (kernel - 1) * WAVE_TIMES_STRIDE + blockIdx.x of this array
+    // (two 64-bit words each; the generic path's slot plane serves as storage).  Else null.
+    unsigned long long *wave_times;
     int dbg;                 // timing ablations only (results invalid): 1 = K1 skips blur stores,
                              // 4 = K1 skips the Hessian/min, 8 = K1 stores into an L2-resident
                              // region, 16 = no shared-min refresh
@@ -131,6 +134,8 @@ int launch_kernel(int which, const ChainArgs &a, const RefineConsts &rc, void *s
 
 size_t k5_lds_bytes(const ChainArgs &a);
 
+constexpr size_t WAVE_TIMES_STRIDE = (size_t)1 << 20;  // records per kernel (debug_ablation & 4096)
+
 constexpr int MASK_PAD_X = 64;  // zero columns on each side of the transposed mask (flood windows)  // flood window rows below the last image row
 
 // Debug: recompute the Hessian response plane of `frame` from its blur plane into dst.
@@ -138,6 +143,8 @@ constexpr int MASK_PAD_X = 64;  // zero columns on each side of the transposed m
 int init_device_kernels();
 
 int launch_debug_resp(const ChainArgs &a, int frame, float *dst, void *stream);
+// Zero n_records counter records on `stream` (used instead of a memset while the stream is being captured).
+int launch_clear_counters(FrameCounters *ctr, size_t n_records, void *stream);
 // u8 luma (to_luma8) of n_frames L16 (format 1) / RGB8 (format 2) frames in device memory: rows `pitch`
 // bytes apart, frames `frame_stride` bytes apart -> tight [n_frames][H][W]
 int launch_luma8(const void *src, size_t pitch, size_t frame_stride, int n_frames, int format, uint8_t *dst, int W, int H,

@@ -104,6 +104,53 @@ __device__ __forceinline__ uint32_t from_right_u(uint32_t v)
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true);
 }
 
+// The lane id recomputed where it is used (2 VALU): values that are needed once every few rows are derived
+// from it on the spot instead of living in registers across K1's row loop (the kernel sits exactly at
+// the 5-waves-per-SIMD register limit, and the compiler hoists anything loop-invariant).
+__device__ __forceinline__ int lane_id_here()
+{
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
+// Build option (-DAGX_K1_DEFER_ROWS=10; OFF by default): K1 defers the threshold decision of the first rows of
+// every segment.  A wave that starts with nothing published admits every negative response of its first rows
+// (its running threshold is 0.05 x the minimum of one or two rows), and K2 re-tests all of those from the blur
+// plane.  With the option the responses of those rows are kept in LDS as bf16 (truncated: for a negative value an
+// upper bound; with the low half set, a lower bound) and the rows' mask bits are decided again when the segment's
+// first TWO word rows are complete, still as a superset: a bit stays if the lower bound is below the running
+// threshold, and the block's weakest admitted candidate (cand_max) takes the upper bounds of the bits that stay.
+// Measured (round 3, 256 x 1280x800, 8 alternating runs per build on one box): K2's re-tests 5 760 -> 2 870 per
+// frame, K2 64 -> 61 us -- but K1 300 -> 307 us (29 KB of LDS per workgroup and the extra branches in the row
+// loop), a net loss; the parity suite passes with it on.
+#ifndef AGX_K1_WPE
+#define AGX_K1_WPE 1  // A/B builds: -DAGX_K1_WPE=0 leaves the register budget of K1 to the compiler
+#endif
+#ifndef AGX_K1_DEFER_ROWS
+#define AGX_K1_DEFER_ROWS 0  // off by default (measured: see the note at K1_DEFER_ROWS); A/B builds: -DAGX_K1_DEFER_ROWS=10
+#endif
+constexpr int K1_DEFER_ROWS = AGX_K1_DEFER_ROWS > 0 ? AGX_K1_DEFER_ROWS : 1;
+
+// debug_ablation & 4096: start / end time of a wave (see ChainArgs::wave_times); the destructor runs on
+// every exit path of the kernel.
+struct WaveTimer {
+    unsigned long long *rec;
+    unsigned long long t0;
+    __device__ __forceinline__ WaveTimer(const ChainArgs &a, int kernel)
+        : rec(a.wave_times ? a.wave_times + 2 * ((size_t)(kernel - 1) * WAVE_TIMES_STRIDE + (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) : nullptr), t0(0)
+    {
+        if (rec) t0 = wall_clock64();
+    }
+    __device__ __forceinline__ ~WaveTimer()
+    {
+        if (rec && (threadIdx.x & 63) == 0 && (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6) < WAVE_TIMES_STRIDE) {
+            rec[0] = t0;
+            rec[1] = wall_clock64();
+        }
+    }
+};
+
 // Raw pixel words of 4 consecutive pixels: L8 1 dword, L16 2 dwords, RGB8 3 dwords, LF32 4 dwords.
 template <int FMT>
 struct RawPx {
@@ -210,7 +257,7 @@ __device__ __forceinline__ int H_full_segs(const ChainArgs &a) { return a.H / a.
 #define AGX_BLUR_STORE_AUX 0  // cache policy bits of the blur plane's buffer stores (A/B builds: -DAGX_BLUR_STORE_AUX=2 = nt)
 #endif
 template <int FMT, bool A4, bool RESP = false>
-__global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((A4 && !RESP && AGX_K1_WPE) ? ((FMT == 0 || FMT == 1) ? 5 : 4) : 1, 8))) k_blur_hessian(ChainArgs a)
 {
     const int lane = threadIdx.x & 63;
     // u8 -> the pixel's four distinct tap products of the horizontal pass: entry v holds
@@ -218,6 +265,12 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
     // per entry; w4..w6 equal w2..w0 bit for bit).  One 16-byte LDS read per pixel replaces the
     // conversion AND the pass's 7 multiplications per output pixel; the LDS pipe is otherwise idle.
     __shared__ float4 s_lut4[256];
+    // deferred rows (see K1_DEFER_ROWS): per wave, the rows' responses as 4 x bf16 per lane, and the first word
+    // row of the segment (4 mask words + the block's cand_max) until it is decided.  Arbitrary f32 planes
+    // (FMT 3) may hold infinities, whose truncated bounds are not ordered: they keep the direct decision.
+    constexpr bool DEFER = FMT != 3 && AGX_K1_DEFER_ROWS > 0;
+    __shared__ uint2 s_def[DEFER ? 4 : 1][K1_DEFER_ROWS][64];
+    __shared__ uint32_t s_blk0[DEFER ? 4 : 1][5][64];
     if (FMT == 0 || FMT == 2) {
         for (int i = threadIdx.x; i < 256; i += blockDim.x) {
             const float f = (float)i / 255.0f;
@@ -270,6 +323,7 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
 
     const uint8_t *fbase = a.frames + (size_t)frame * (size_t)a.frame_stride;
     float *blur_f = a.blur + (size_t)frame * (size_t)a.plane;
+    const int wv = DEFER ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;  // this wave's part of s_def / s_blk0
     const float w0 = a.w[0], w1 = a.w[1], w2 = a.w[2], w3 = a.w[3], w4 = a.w[4], w5 = a.w[5],
                 w6 = a.w[6];
 
@@ -611,7 +665,10 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
                         // not have to drain its blur stores (vmcnt) to read one word
                         asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(polled) : "s"(&ctr.min_key_inv) : "memory");
                         rows_to_sync = sync_gap;
-                        sync_gap = min(sync_gap * 2, 128);
+#ifndef AGX_K1_SYNC_GAP_MAX
+#define AGX_K1_SYNC_GAP_MAX 16  // rows between two refreshes of the running threshold at most (128: K2 +5 us, frames whose strips see no corner for long: 1.5x the re-tests)
+#endif
+                        sync_gap = min(sync_gap * 2, AGX_K1_SYNC_GAP_MAX);
                     }
                     --rows_to_sync;
                     // Candidate bit of this row: compare -> lane mask (SGPR pair), restricted to the
@@ -619,7 +676,7 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
                     // rows enter at bit 0, the word is bit-reversed when it is stored).  One block with
                     // the four columns interleaved: a VALU-written SGPR needs two wait states before
                     // a VALU reads it on gfx950, which the assembler does not insert inside asm.
-                    uint64_t cj[4];
+                    uint64_t cj[4], cj_any;  // cj_any: some lane has a candidate in this row
                     asm("v_cmp_lt_f32_e64 %[c0], %[d0], %[thr]\n\t"
                         "v_cmp_lt_f32_e64 %[c1], %[d1], %[thr]\n\t"
                         "v_cmp_lt_f32_e64 %[c2], %[d2], %[thr]\n\t"
@@ -631,13 +688,23 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
                         "v_addc_co_u32_e64 %[m0], vcc, %[m0], %[m0], %[c0]\n\t"
                         "v_addc_co_u32_e64 %[m1], vcc, %[m1], %[m1], %[c1]\n\t"
                         "v_addc_co_u32_e64 %[m2], vcc, %[m2], %[m2], %[c2]\n\t"
-                        "v_addc_co_u32_e64 %[m3], vcc, %[m3], %[m3], %[c3]"
+                        "v_addc_co_u32_e64 %[m3], vcc, %[m3], %[m3], %[c3]\n\t"
+                        "s_or_b64 %[any], %[c0], %[c1]\n\t"
+                        "s_or_b64 %[any], %[any], %[c2]\n\t"
+                        "s_or_b64 %[any], %[any], %[c3]"
                         : [m0] "+v"(mw[0]), [m1] "+v"(mw[1]), [m2] "+v"(mw[2]), [m3] "+v"(mw[3]),
-                          [c0] "=&s"(cj[0]), [c1] "=&s"(cj[1]), [c2] "=&s"(cj[2]), [c3] "=&s"(cj[3])
+                          [c0] "=&s"(cj[0]), [c1] "=&s"(cj[1]), [c2] "=&s"(cj[2]), [c3] "=&s"(cj[3]), [any] "=&s"(cj_any)
                         : [d0] "v"(dv[0]), [d1] "v"(dv[1]), [d2] "v"(dv[2]), [d3] "v"(dv[3]), [thr] "s"(thr_run_bits),
                           [k0] "s"(ok_mask[0]), [k1] "s"(ok_mask[1]), [k2] "s"(ok_mask[2]), [k3] "s"(ok_mask[3])
                         : "vcc", "scc");  // s_and_b64 writes SCC
-                    if ((cj[0] | cj[1] | cj[2] | cj[3]) != 0ull) {  // wave-uniform; most rows have no candidate
+                    const bool defer_row = DEFER && __builtin_expect((y - ys) < K1_DEFER_ROWS, 0);  // wave-uniform, 10 rows of a segment
+                    if (defer_row) {  // the row's bits are decided again later: keep its responses (bf16, truncated)
+                        uint2 pk;
+                        pk.x = __builtin_amdgcn_perm(__float_as_uint(dv[1]), __float_as_uint(dv[0]), 0x07060302u);
+                        pk.y = __builtin_amdgcn_perm(__float_as_uint(dv[3]), __float_as_uint(dv[2]), 0x07060302u);
+                        s_def[wv][y - ys][lane_id_here()] = pk;
+                    }
+                    if (cj_any != 0ull && !defer_row) {  // wave-uniform; most rows have no candidate
                         float sel[4];  // the candidate's response, or the current maximum itself
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
@@ -647,22 +714,66 @@ __global__ void __launch_bounds__(256) k_blur_hessian(ChainArgs a)
                     }
                     y_pushed = y;
                 }
-                if ((y & 31) == 31 || y == ye - 1) {  // word row complete (segments are 32-row aligned)
-                    if (lane_valid) {
-                        a.cand_max[((size_t)frame * a.mask_yb + (y >> 5)) * (a.mask_wpr >> 2) + ((MASK_PAD_X + c0) >> 2)] = cmax;
-                        uint32_t *dst = mask_f + (size_t)(y >> 5) * a.mask_wpr + MASK_PAD_X + c0;
-                        // the last row pushed sits at bit 0: reverse, then move it to bit (row & 31)
-                        const int fix = 31 - (y_pushed & 31);
-                        uint32_t o[4];
+                if (__builtin_expect((y & 31) == 31 || y == ye - 1, 0)) {  // word row complete (segments are 32-row aligned)
+                    const int ln = lane_id_here();
+                    const int c0h = xs - 4 + 4 * ln;  // == c0, derived here (see lane_id_here)
+                    auto store_block = [&](int yb, const uint32_t (&w)[4], float m) {
+                        if (c0h >= xs && c0h < xe) {  // == lane_valid
+                            a.cand_max[((size_t)frame * a.mask_yb + yb) * (a.mask_wpr >> 2) + ((MASK_PAD_X + c0h) >> 2)] = m;
+                            uint32_t *dst = mask_f + (size_t)yb * a.mask_wpr + MASK_PAD_X + c0h;
+                            if (A4) {
+                                *reinterpret_cast<uint4 *>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
+                            } else {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) o[j] = __brev(mw[j]) >> fix;
-                        if (A4) {
-                            *reinterpret_cast<uint4 *>(dst) = make_uint4(o[0], o[1], o[2], o[3]);
-                        } else {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                if (c0 + j < W) dst[j] = o[j];
+                                for (int j = 0; j < 4; ++j)
+                                    if (c0h + j < W) dst[j] = w[j];
+                            }
                         }
+                    };
+                    // the deferred rows of the segment's first word row, decided against the running threshold as
+                    // it stands now (row ys + q is bit q of the word: segments start on a word row)
+                    auto refilter = [&](uint32_t (&w)[4], float &m) {
+                        const float thr_now = __builtin_bit_cast(float, thr_run_bits);
+                        // rows with a response: 1 <= ys + q <= min(ye, H - 1) - 1 (wave-uniform bounds; a rolled loop:
+                        // the body sits in each of the seven unrolled row bodies)
+                        const int q_lo = ys < 1 ? 1 - ys : 0;
+                        const int q_hi = min(K1_DEFER_ROWS, min(ye, H - 1) - ys);
+#pragma unroll 1
+                        for (int q = q_lo; q < q_hi; ++q) {
+                            const uint2 pk = s_def[wv][q][ln];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const uint32_t half = j < 2 ? pk.x : pk.y;
+                                const uint32_t raw = (j & 1) ? (half & 0xffff0000u) : (half << 16);
+                                const float hi = __uint_as_float(raw), lo = __uint_as_float(raw | 0xffffu);  // hi >= response >= lo (negative)
+                                const bool bit = ((w[j] >> q) & 1u) != 0u;
+                                const bool keep = bit && lo < thr_now;
+                                if (bit && !keep) w[j] &= ~(1u << q);
+                                if (keep) m = fmaxf(m, hi);
+                            }
+                        }
+                    };
+                    const int blk = (y >> 5) - (ys >> 5);  // word row within the segment (wave-uniform)
+                    if (DEFER && blk == 1) {  // the segment's first word row is decided now and goes out first
+                        uint32_t o0[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o0[j] = s_blk0[wv][j][ln];
+                        float cm0 = __uint_as_float(s_blk0[wv][4][ln]);
+                        refilter(o0, cm0);
+                        store_block((y >> 5) - 1, o0, cm0);
+                    }
+                    // the last row pushed sits at bit 0: reverse, then move it to bit (row & 31)
+                    const int fix = 31 - (y_pushed & 31);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) mw[j] = __brev(mw[j]) >> fix;
+                    if (DEFER && blk == 0 && y != ye - 1) {
+                        // first word row, more rows follow: decided when the second one is complete
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) s_blk0[wv][j][ln] = mw[j];
+                        s_blk0[wv][4][ln] = __float_as_uint(cmax);
+                    } else {
+                        if (DEFER && blk == 0) refilter(mw, cmax);  // a segment of one word row
+                        store_block(y >> 5, mw, cmax);
                     }
                     mw[0] = mw[1] = mw[2] = mw[3] = 0u;
                     cmax = -__builtin_inff();
@@ -752,13 +863,34 @@ constexpr int VS_ROWS = 4;         // word rows per tile
 constexpr uint32_t VS_LIST = 512;  // re-test work list entries per pass
 constexpr uint32_t VS_SEEDS = 256; // seeds buffered per tile
 
-__global__ void __launch_bounds__(64) k_verify_seeds(ChainArgs a)
+// Workgroups of VS_WAVES independent waves (each with its own part of the LDS arrays, no workgroup barrier): the
+// launch used to be 41 000 single-wave workgroups for 256 frames and was bound by the rate at which workgroups
+// are dispatched (~580 per us sustained, half of the wave slots empty); a wave = a slot of its frame as before.
+#ifndef AGX_VS_WAVES
+#define AGX_VS_WAVES 1
+#endif
+constexpr int VS_WAVES = AGX_VS_WAVES;
+// orders the LDS traffic of ONE wave (its lanes exchange data through LDS; the LDS queue of a wave is in order)
+__device__ __forceinline__ void wave_lds_sync()
 {
-    __shared__ uint32_t s_keep[(VS_ROWS + 1) * 64];  // row VS_ROWS: bit 0 = the pixel above the tile's first row
-    __shared__ uint32_t s_list[VS_LIST];  // re-test work list, then the tile's seeds (VS_SEEDS <= VS_LIST)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ void __launch_bounds__(64 * VS_WAVES) k_verify_seeds(ChainArgs a)
+{
+    __shared__ uint32_t s_keep_all[VS_WAVES][(VS_ROWS + 1) * 64];  // row VS_ROWS: bit 0 = the pixel above the tile's first row
+    __shared__ uint32_t s_list_all[VS_WAVES][VS_LIST];  // re-test work list, then the tile's seeds (VS_SEEDS <= VS_LIST)
+    __shared__ uint32_t s_nseeds_all[VS_WAVES], s_base_all[VS_WAVES];
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint32_t *s_keep = s_keep_all[wv], *s_list = s_list_all[wv];
     uint32_t *s_seeds = s_list;
-    __shared__ uint32_t s_nseeds, s_base;
-    const FrameSlot fs = frame_slot(a.n_frames, true);  // latest-written blur planes first (cache)
+    uint32_t &s_nseeds = s_nseeds_all[wv], &s_base = s_base_all[wv];
+    const WaveTimer wt(a, K_THRESHOLD);
+    FrameSlot fs = frame_slot(a.n_frames, true);  // latest-written blur planes first (cache)
+    fs.slot = fs.slot * VS_WAVES + (uint32_t)wv;  // this wave's slot of the frame
+    fs.n_slots *= VS_WAVES;
     const int frame = fs.frame;
     FrameCounters &ctr = a.ctr[frame];
     const float thr = f32_from_order_key(~ctr.min_key_inv) * 0.05f;
@@ -766,12 +898,12 @@ __global__ void __launch_bounds__(64) k_verify_seeds(ChainArgs a)
     const float *blur = a.blur + (size_t)frame * (size_t)a.plane;
     const float *cmax_f = a.cand_max + (size_t)frame * (size_t)a.mask_yb * (size_t)(a.mask_wpr >> 2);
     const int W = a.W, wpr = a.mask_wpr;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int n_yb = (a.H + 31) >> 5;
     const int groups = (W + VS_OWN - 1) / VS_OWN;
     const int tiles = ((n_yb + VS_ROWS - 1) / VS_ROWS) * groups;
     if (lane == 0) s_nseeds = 0u;
-    __syncthreads();
+    wave_lds_sync();
     for (int t = (int)fs.slot; t < tiles; t += (int)fs.n_slots) {  // wave-uniform
         const int ch = t / groups, g = t - ch * groups;
         const int yb0 = ch * VS_ROWS;
@@ -849,7 +981,7 @@ __global__ void __launch_bounds__(64) k_verify_seeds(ChainArgs a)
             rows_any = __builtin_amdgcn_readfirstlane(rows_any);
             uint32_t n_list = 0;  // wave-uniform fill of s_list
             auto run_list = [&]() {
-                __syncthreads();
+                wave_lds_sync();
                 for (uint32_t e0 = 0; e0 < n_list; e0 += 128) {  // two bits per lane and round: 18 loads in flight
                     float d[2];
                     uint32_t ent[2];
@@ -867,7 +999,7 @@ __global__ void __launch_bounds__(64) k_verify_seeds(ChainArgs a)
                     for (int q = 0; q < 2; ++q)
                         if (on[q] && !(d[q] < thr)) atomicAnd(&s_keep[ent[q] >> 5], ~(1u << (ent[q] & 31u)));
                 }
-                __syncthreads();
+                wave_lds_sync();
                 n_list = 0;
             };
             auto push = [&](bool mine, uint32_t entry) {  // one ballot: the lanes that have this (row, bit)
@@ -944,19 +1076,19 @@ __global__ void __launch_bounds__(64) k_verify_seeds(ChainArgs a)
             }
         }
         // append the tile's seeds to the frame's list: one atomic, coalesced stores
-        __syncthreads();
+        wave_lds_sync();
         const uint32_t ns = min(s_nseeds, VS_SEEDS);
         if (ns) {  // wave-uniform
             if (lane == 0) s_base = atomicAdd(&ctr.n_seeds, ns);
-            __syncthreads();
+            wave_lds_sync();
             for (uint32_t i = (uint32_t)lane; i < ns; i += 64u) {
                 const uint32_t o = s_base + i;
                 if (o < a.cap_roots) a.seeds[(size_t)frame * a.cap_roots + o] = s_seeds[i];
                 else atomicOr(&ctr.flags, FLAG_CAND_OVERFLOW);
             }
-            __syncthreads();
+            wave_lds_sync();
             if (lane == 0) s_nseeds = 0u;
-            __syncthreads();
+            wave_lds_sync();
         }
     }
 }
@@ -988,7 +1120,17 @@ __device__ __forceinline__ uint32_t bitpos_sum(uint32_t c)
            16u * (uint32_t)__popc(c & 0xFFFF0000u);
 }
 
-constexpr int FLOOD_COLS = 32;
+#ifndef AGX_FLOOD_COLS
+#define AGX_FLOOD_COLS 32
+#endif
+#ifndef AGX_FLOOD_WPE
+#define AGX_FLOOD_WPE 4  // waves per SIMD the fused flood + refine kernel is compiled for
+#endif
+// First-tier flood window: FLOOD_COLS columns [sx - FLOOD_SEED_COL, ...] x 32 rows [sy - 1, sy + 30].  Both column arrays
+// of the window live in registers (32 columns: 4 waves per SIMD; narrower windows were measured -- 24 columns run at 5
+// waves per SIMD but send three times as many seeds to the second tier, and the launch got slower).
+constexpr int FLOOD_COLS = AGX_FLOOD_COLS;
+constexpr int FLOOD_SEED_COL = FLOOD_COLS / 2;
 
 // Second tier, wave-wide: lane t holds columns sx-64+2t and sx-63+2t of a 128-column x 64-row
 // window [sy-1, sy+62] as two 64-bit words (bit = row); each round ORs the neighbouring columns
@@ -1021,8 +1163,13 @@ __device__ __forceinline__ unsigned long long from_right_u64(unsigned long long 
     return (unsigned long long)from_right_u((uint32_t)v) | ((unsigned long long)from_right_u((uint32_t)(v >> 32)) << 32);
 }
 
-__device__ __forceinline__ uint32_t wave_flood_128x64(const ChainArgs &a, int frame, uint32_t *flags, uint32_t n_first,
-                                                      uint32_t *n_clusters2, const uint32_t *mask, uint32_t p, int lane)
+enum : int { FLOOD_NONE = 0, FLOOD_CLUSTER = 1, FLOOD_BIG = 2 };
+
+// Second tier: the whole wave floods the 128 x 64 window around seed p.  Returns (in every lane) FLOOD_CLUSTER with
+// the component's exact integer sums, FLOOD_NONE if the seed is not the component's first pixel, or FLOOD_BIG
+// if the component leaves this window too (the frame then goes to the generic path: FLAG_BIG_CLUSTER is set).
+__device__ __forceinline__ int wave_flood_128x64(const ChainArgs &a, uint32_t *flags, const uint32_t *mask, uint32_t p, int lane,
+                                                 uint32_t &cnt_out, uint32_t &sumx_out, uint32_t &sumy_out)
 {
     const uint32_t W = (uint32_t)a.W;
     const uint32_t sx = p % W, sy = p / W;
@@ -1051,10 +1198,10 @@ __device__ __forceinline__ uint32_t wave_flood_128x64(const ChainArgs &a, int fr
     // not the canonical seed: a pixel of the component precedes it in raster order
     const bool earlier = (both & 1ull) != 0ull || (lane < 32 && (both & 2ull) != 0ull);
     const bool edge = (lane == 0 && comp[0] != 0ull) || (lane == 63 && comp[1] != 0ull) || (both >> 63) != 0ull;
-    if (__any(earlier)) return 0xffffffffu;
+    if (__any(earlier)) return FLOOD_NONE;
     if (__any(edge)) {
         if (lane == 0) atomicOr(flags, FLAG_BIG_CLUSTER);
-        return 0xffffffffu;
+        return FLOOD_BIG;
     }
     const uint32_t n0 = (uint32_t)__popcll(comp[0]), n1 = (uint32_t)__popcll(comp[1]);
     const uint32_t x0 = sx - 64u + 2u * (uint32_t)lane;
@@ -1065,35 +1212,21 @@ __device__ __forceinline__ uint32_t wave_flood_128x64(const ChainArgs &a, int fr
         s_x += __shfl_xor(s_x, off, 64);
         s_y += __shfl_xor(s_y, off, 64);
     }
-    uint32_t o = 0xffffffffu;
-    if (lane == 0) {
-        // behind the first tier's records, counted separately: the first tier's count is the loop bound of
-        // every workgroup of this launch and must not move while they start (a workgroup that started
-        // late used to see this cluster in "the first tier's" range and refine it a second time)
-        o = n_first + atomicAdd(n_clusters2, 1u);
-        if (o < a.cap_roots) {
-            const size_t q = (size_t)frame * a.cap_roots + o;
-            a.clu_key[q] = p;
-            a.clu_cnt[q] = s_n;
-            a.clu_sx[q] = s_x;
-            a.clu_sy[q] = s_y;
-        } else {
-            atomicOr(flags, FLAG_ROOT_OVERFLOW);
-            o = 0xffffffffu;
-        }
-    }
-    return __shfl(o, 0, 64);  // index of the cluster record, or ~0: not a cluster of its own / no room
+    cnt_out = s_n;
+    sumx_out = s_x;
+    sumy_out = s_y;
+    return FLOOD_CLUSTER;
 }
 
-// First flood tier for one seed (one lane): 32 x 32 window.  Emits the cluster if the seed is the
-// canonical one and the component stays inside the window; returns true if the component may
-// continue outside (second tier).
-__device__ __forceinline__ bool flood_lane(const ChainArgs &a, int frame, const uint32_t *mask, uint32_t W, uint32_t p,
-                                           uint32_t *flags, uint32_t *n_clusters)
+// First flood tier for one seed (one lane): 32 x 32 window.  Returns FLOOD_CLUSTER with the component's exact
+// integer sums if the seed is the canonical one and the component stays inside the window, FLOOD_BIG if the
+// component may continue outside (second tier), FLOOD_NONE if the seed is not the component's first pixel.
+__device__ __forceinline__ int flood_lane(const ChainArgs &a, const uint32_t *mask, uint32_t W, uint32_t p, uint32_t &cnt_out,
+                                          uint32_t &sumx_out, uint32_t &sumy_out)
 {
     const uint32_t sx = p % W, sy = p / W;
     const int sh = (int)((sy - 1u) & 31u);
-    const uint32_t *wp = mask + (size_t)((sy - 1u) >> 5) * a.mask_wpr + MASK_PAD_X + ((int)sx - 16);
+    const uint32_t *wp = mask + (size_t)((sy - 1u) >> 5) * a.mask_wpr + MASK_PAD_X + ((int)sx - FLOOD_SEED_COL);
     uint32_t cand[FLOOD_COLS], comp[FLOOD_COLS];
 #pragma unroll
     for (int c = 0; c < FLOOD_COLS; ++c) {
@@ -1101,7 +1234,7 @@ __device__ __forceinline__ bool flood_lane(const ChainArgs &a, int frame, const 
         cand[c] = (uint32_t)(two >> sh);  // bit r = row sy-1+r of column sx-16+c
         comp[c] = 0u;
     }
-    comp[16] = 2u;  // the seed: column sx, row sy
+    comp[FLOOD_SEED_COL] = 2u;  // the seed: column sx, row sy
     // One left-to-right and one right-to-left sweep, then the fixed-point test.  After a sweep every
     // comp[c] is a union of whole vertical runs of cand[c], so the update rule would change column c
     // exactly if a neighbouring column holds a component pixel next to a candidate of c that is not
@@ -1136,13 +1269,13 @@ __device__ __forceinline__ bool flood_lane(const ChainArgs &a, int frame, const 
 #pragma unroll
     for (int c = 0; c < FLOOD_COLS; ++c) {
         all |= comp[c];
-        if (c < 16) left_of_seed |= comp[c];
+        if (c < FLOOD_SEED_COL) left_of_seed |= comp[c];
     }
     // a pixel of the component precedes the seed in raster order -> not the canonical seed
     const bool canonical = !((all & 1u) || (left_of_seed & 2u));
     if (canonical) {
         if ((all >> 31) || comp[0] || comp[FLOOD_COLS - 1]) {
-            return true;  // may continue outside the window: second tier below
+            return FLOOD_BIG;  // may continue outside the window: second tier
         } else {
             uint32_t cnt = 0, sumx = 0, sumy = 0;
 #pragma unroll
@@ -1153,51 +1286,15 @@ __device__ __forceinline__ bool flood_lane(const ChainArgs &a, int frame, const 
                 sumy += bitpos_sum(w);
                 sumx += nc * (uint32_t)c;
             }
-            sumx += cnt * (sx - 16u);  // window column 0 is image column sx-16 (mod 2^32 arithmetic)
+            sumx += cnt * (sx - (uint32_t)FLOOD_SEED_COL);  // window column 0 is image column sx - FLOOD_SEED_COL (mod 2^32 arithmetic)
             sumy += cnt * (sy - 1u);   // window row 0 is image row sy-1
-            const uint32_t o = atomicAdd(n_clusters, 1u);
-            if (o < a.cap_roots) {
-                const size_t q = (size_t)frame * a.cap_roots + o;
-                a.clu_key[q] = p;
-                a.clu_cnt[q] = cnt;
-                a.clu_sx[q] = sumx;
-                a.clu_sy[q] = sumy;
-            } else {
-                atomicOr(flags, FLAG_ROOT_OVERFLOW);
-            }
+            cnt_out = cnt;
+            sumx_out = sumx;
+            sumy_out = sumy;
+            return FLOOD_CLUSTER;
         }
     }
-    return false;
-}
-
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) k_flood(ChainArgs a)
-{
-    const FrameSlot fs = frame_slot(a.n_frames, false);
-    const int frame = fs.frame;
-    FrameCounters &ctr = a.ctr[frame];
-    if (ctr.flags & FLAG_CAND_OVERFLOW) return;
-    const uint32_t n = min(ctr.n_seeds, a.cap_roots);
-    const uint32_t *mask = a.mask + (size_t)frame * (size_t)a.mask_plane;
-    const uint32_t W = (uint32_t)a.W;
-    const int lane = threadIdx.x;
-    for (uint32_t base = fs.slot * 64u; base < n; base += fs.n_slots * 64u) {  // wave-uniform trip count
-        const uint32_t i = base + (uint32_t)lane;
-        uint32_t p = 0u;
-        bool big = false;
-        if (i < n) {
-            p = a.seeds[(size_t)frame * a.cap_roots + i];
-            big = flood_lane(a, frame, mask, W, p, &ctr.flags, &ctr.n_clusters);
-        }
-        // Oversized components (about 0.5 % of the seeds on real frames) need the wave-wide 128 x 64
-        // window.  Doing them here, one after the other, made the few waves that found several the
-        // critical path of the launch (23 of 48 us); they go into the frame's list instead and are
-        // flooded by the first workgroups of k_refine, one wave each, all in parallel.
-        if (big) {
-            const uint32_t bi = atomicAdd(&ctr.n_big, 1u);
-            if (bi < a.cap_roots) a.roots[(size_t)frame * a.cap_roots + bi] = p;  // (the generic path's list, free until k_rare)
-            else atomicOr(&ctr.flags, FLAG_ROOT_OVERFLOW);
-        }
-    }
+    return FLOOD_NONE;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1364,12 +1461,12 @@ __global__ void k_debug_resp(const float *__restrict__ blur, float *__restrict__
 // ------------------------------------------------------------------------------------------
 // rochade_refine of cluster s of `frame` (detector.rs:265-359).  Appends a RefinedRec through the
 // counters given (the global per-frame counters, or a workgroup's LDS copies).
+// Core: cluster record s of the frame with first pixel `key`, cn pixels and the integer coordinate sums sx, sy.
 template <bool VEC>
-__device__ __forceinline__ void refine_cluster(const ChainArgs &a, const RefineConsts &rc, int frame, size_t cbase,
-                                               const float *img, int W, int H, uint32_t s, uint32_t *n_refined,
-                                               uint32_t *max_k_bits)
+__device__ __forceinline__ void refine_values(const ChainArgs &a, const RefineConsts &rc, int frame, size_t cbase,
+                                              const float *img, int W, int H, uint32_t s, uint32_t key, uint32_t cn, uint32_t sx,
+                                              uint32_t sy, uint32_t *n_refined, uint32_t *max_k_bits)
 {
-    const uint32_t sx = a.clu_sx[cbase + s], sy = a.clu_sy[cbase + s], cn = a.clu_cnt[cbase + s];
     if (sx >= (1u << 24) || sy >= (1u << 24)) atomicOr(&a.ctr[frame].flags, FLAG_CENTROID_INEXACT);
     const float fn = (float)cn;
     const float initial_x = (float)sx / fn;  // detector.rs:427
@@ -1461,11 +1558,83 @@ __device__ __forceinline__ void refine_cluster(const ChainArgs &a, const RefineC
     // The record is handed to another workgroup (the frame's emission tail, possibly on another
     // CU): write-through stores (sc1) here, bypassing loads there -- no cache-wide release fence.
     uint32_t *rec = reinterpret_cast<uint32_t *>(a.refined + (size_t)frame * a.cap_roots + o);
-    const uint32_t f[6] = {a.clu_key[cbase + s], __float_as_uint(rxf + x0), __float_as_uint(ryf + y0),
+    const uint32_t f[6] = {key, __float_as_uint(rxf + x0), __float_as_uint(ryf + y0),
                            __float_as_uint(k),  __float_as_uint(theta),     __float_as_uint(phi)};
 #pragma unroll
     for (int q = 0; q < 6; ++q) __hip_atomic_store(rec + q, f[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     atomicMax(max_k_bits, __float_as_uint(k));
+}
+
+// rochade_refine of cluster record s of `frame` as it stands in the cluster table.
+template <bool VEC>
+__device__ __forceinline__ void refine_cluster(const ChainArgs &a, const RefineConsts &rc, int frame, size_t cbase,
+                                               const float *img, int W, int H, uint32_t s, uint32_t *n_refined,
+                                               uint32_t *max_k_bits)
+{
+    refine_values<VEC>(a, rc, frame, cbase, img, W, H, s, a.clu_key[cbase + s], a.clu_cnt[cbase + s], a.clu_sx[cbase + s],
+                       a.clu_sy[cbase + s], n_refined, max_k_bits);
+}
+
+// ------------------------------------------------------------------------------------------
+// K3: flood + refine in one launch.  One seed per lane: the bit-parallel flood of its 32 x 32 window, and --
+// where the seed turns out to be the first pixel of a component that stays inside the window -- the
+// component's cluster record and its rochade_refine right behind it, from the sums still in registers.
+// (Two launches until round 3: the flood, bound by its slowest waves with a quarter of the wave slots in use,
+// and the refinement, bound by the random sector reads of the 9 x 9 windows; fused, the floods of some waves
+// run under the window reads of the others.)  Seeds whose component may leave the window go to the frame's
+// second-tier list, which k_rare's workgroup floods wave-wide.
+// ------------------------------------------------------------------------------------------
+template <bool VEC>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AGX_FLOOD_WPE, 8))) k_flood_refine(ChainArgs a, RefineConsts rc)
+{
+    const WaveTimer wt(a, K_FLOOD_REFINE);
+    const FrameSlot fs = frame_slot(a.n_frames, true);  // latest-written blur planes first (cache)
+    const int frame = fs.frame;
+    FrameCounters &ctr = a.ctr[frame];
+    if (a.force_generic || (ctr.flags & FLAG_CAND_OVERFLOW)) return;  // whole frame: k_rare / reported
+    const uint32_t n = min(ctr.n_seeds, a.cap_roots);
+    const uint32_t *mask = a.mask + (size_t)frame * (size_t)a.mask_plane;
+    const float *img = a.blur + (size_t)frame * (size_t)a.plane;
+    const size_t cbase = (size_t)frame * a.cap_roots;
+    const uint32_t W = (uint32_t)a.W;
+    const int lane = threadIdx.x;
+    for (uint32_t base = fs.slot * 64u; base < n; base += fs.n_slots * 64u) {  // wave-uniform trip count
+        const uint32_t i = base + (uint32_t)lane;
+        uint32_t p = 0u, cnt = 0, sumx = 0, sumy = 0;
+        int what = FLOOD_NONE;
+        if (i < n) {
+            p = a.seeds[cbase + i];
+            what = flood_lane(a, mask, W, p, cnt, sumx, sumy);
+        }
+        // Second tier: components that may leave the lane's window (about 1 % of the seeds on real frames) are
+        // flooded again by the whole wave in a 128 x 64 window, one after the other; the lane that owns the seed
+        // takes the result and refines the cluster together with everyone else below.  (A component that leaves
+        // that window too flags the frame: k_rare clusters it again by the generic path.)
+        unsigned long long big = __ballot(what == FLOOD_BIG);
+        if (big && lane == 0) atomicAdd(&ctr.n_big, (uint32_t)__popcll(big));  // (informational: agx_debug_fetch)
+        while (big) {  // wave-uniform
+            const int src = __ffsll((long long)big) - 1;
+            big &= big - 1ull;
+            uint32_t c2 = 0, x2 = 0, y2 = 0;
+            const int w2 = wave_flood_128x64(a, &ctr.flags, mask, (uint32_t)__builtin_amdgcn_readlane((int)p, src), lane, c2, x2, y2);
+            if (lane == src) {
+                what = w2 == FLOOD_CLUSTER ? FLOOD_CLUSTER : FLOOD_NONE;
+                cnt = c2;
+                sumx = x2;
+                sumy = y2;
+            }
+        }
+        if (what == FLOOD_CLUSTER) {
+            const uint32_t o = atomicAdd(&ctr.n_clusters, 1u);
+            if (o < a.cap_roots) {
+                a.clu_key[cbase + o] = p;
+                a.clu_cnt[cbase + o] = cnt;
+                refine_values<VEC>(a, rc, frame, cbase, img, a.W, a.H, o, p, cnt, sumx, sumy, &ctr.n_refined, &ctr.max_k_bits);
+            } else {
+                atomicOr(&ctr.flags, FLAG_ROOT_OVERFLOW);
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1562,54 +1731,31 @@ __device__ __forceinline__ void filter_sort_emit(const ChainArgs &a, int frame, 
     }
 }
 
-// The emission tail of k_refine: filter and ordered emission of one frame by ONE wave, for up to
-// TAIL_CAP refined records.  Every lane fetches its records' (key, k, phi) with the loads in flight
-// together, rejected records get the key 0xffffffff, and a surviving record's output position is
-// its rank = the number of smaller keys (keys are distinct: the first pixel of distinct clusters) --
-// no sort passes, two memory round trips.  Returns false (nothing emitted) if the list is longer.
+// Filter (detector.rs:436-445) and ordered emission of one frame with up to TAIL_CAP refined records by the
+// frame's 1024-thread workgroup of k_rare: thread t holds record t, rejected records get the key 0xffffffff, and a
+// surviving record's output position is its rank = the number of smaller keys (keys are distinct: the first pixel
+// of distinct clusters) -- no sort passes, one memory round trip for the records and one for the output.
 constexpr uint32_t TAIL_CAP = 1024;
 
-__device__ __forceinline__ bool emit_small(const ChainArgs &a, int frame, uint32_t n, uint32_t max_k_bits, uint32_t *keys,
-                                           uint32_t *s_misc)
+__device__ __forceinline__ void emit_wide(const ChainArgs &a, int frame, uint32_t n, uint32_t max_k_bits, uint32_t *keys,
+                                          uint32_t *s_misc)
 {
-    const uint32_t t = threadIdx.x;  // 64 threads
+    const uint32_t t = threadIdx.x;  // 1024 threads, n <= TAIL_CAP
     FrameCounters &ctr = a.ctr[frame];
-    if (n > TAIL_CAP) {
-        if (t == 0) atomicOr(&ctr.flags, FLAG_LARGE_RESULT);
-        return false;
-    }
-    uint32_t *rec = reinterpret_cast<uint32_t *>(a.refined + (size_t)frame * a.cap_roots);
-    auto rec_u = [&](uint32_t i, int field) { return __hip_atomic_load(rec + (size_t)i * 6 + field, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    const uint32_t *rec = reinterpret_cast<const uint32_t *>(a.refined + (size_t)frame * a.cap_roots) + (size_t)t * 6;
     const float s_max_k = __uint_as_float(max_k_bits) / 10.0f;  // detector.rs:436
-    uint32_t mine = 0;
-    for (uint32_t i0 = 0; i0 < n; i0 += 256) {  // 4 records per lane and round, 12 loads in flight
-        uint32_t key[4], kb[4], pb[4];
+    uint32_t f[6] = {0xffffffffu, 0u, 0u, 0u, 0u, 0u};
+    bool pass = false;
+    if (t < n) {
+        // (written by k_flood_refine, the previous launch -- or by this workgroup's generic path behind an agent-scope fence)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint32_t i = i0 + q * 64 + t;
-            key[q] = kb[q] = pb[q] = 0u;
-            if (i < n) {
-                key[q] = rec_u(i, 0);
-                kb[q] = rec_u(i, 3);
-                pb[q] = rec_u(i, 5);
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint32_t i = i0 + q * 64 + t;
-            if (i < n) {
-                const float k = __uint_as_float(kb[q]), phi = __uint_as_float(pb[q]);
-                const bool pass = k >= s_max_k && phi >= a.min_angle && phi <= a.max_angle;
-                keys[i] = pass ? key[q] : 0xffffffffu;
-                mine += pass ? 1u : 0u;
-            }
-        }
+        for (int q = 0; q < 6; ++q) f[q] = __hip_atomic_load(rec + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float k = __uint_as_float(f[3]), phi = __uint_as_float(f[5]);
+        pass = k >= s_max_k && phi >= a.min_angle && phi <= a.max_angle;
     }
-    // pad to a multiple of 4 for the 16-byte reads of the rank loop
-    if (t < 4 && n + t < ((n + 3u) & ~3u)) keys[n + t] = 0xffffffffu;
-    uint32_t nf = mine;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) nf += __shfl_xor(nf, off, 64);
+    keys[t] = pass ? f[0] : 0xffffffffu;
+    if (t < 4) keys[TAIL_CAP + t] = 0xffffffffu;  // (padding for the 16-byte reads of the rank loop)
+    const uint32_t nf = (uint32_t)__syncthreads_count(pass ? 1 : 0);
     if (t == 0) {
         uint32_t off = 0, fits = 1;
         const bool ok = nf <= a.cap_out;
@@ -1634,82 +1780,30 @@ __device__ __forceinline__ bool emit_small(const ChainArgs &a, int frame, uint32
         }
     }
     __syncthreads();
-    if (!nf || !s_misc[1]) return true;
+    if (!pass || !s_misc[1]) return;
     float *out = a.out + (size_t)s_misc[0] * 5;
     const uint32_t n4 = (n + 3u) >> 2;
-    for (uint32_t i = t; i < n; i += 64) {
-        const uint32_t key = keys[i];
-        if (key == 0xffffffffu) continue;
-        uint32_t rank = 0;
-        for (uint32_t j = 0; j < n4; ++j) {  // every lane reads the same 16 bytes: LDS broadcast
-            const uint4 q = reinterpret_cast<const uint4 *>(keys)[j];
-            rank += (q.x < key ? 1u : 0u) + (q.y < key ? 1u : 0u) + (q.z < key ? 1u : 0u) + (q.w < key ? 1u : 0u);
-        }
-        uint32_t f[5];
-#pragma unroll
-        for (int q = 0; q < 5; ++q) f[q] = rec_u(i, q + 1);
-#pragma unroll
-        for (int q = 0; q < 5; ++q) out[(size_t)rank * 5 + q] = __uint_as_float(f[q]);
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < n4; ++j) {  // every lane reads the same 16 bytes: LDS broadcast
+        const uint4 q = reinterpret_cast<const uint4 *>(keys)[j];
+        rank += (q.x < f[0] ? 1u : 0u) + (q.y < f[0] ? 1u : 0u) + (q.z < f[0] ? 1u : 0u) + (q.w < f[0] ? 1u : 0u);
     }
-    return true;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) out[(size_t)rank * 5 + q] = __uint_as_float(f[q + 1]);
 }
 
-// K4 launch: rochade_refine of every cluster, then -- by the workgroup of a frame that finishes
-// last -- the k / phi filter and the ordered emission of that frame (up to TAIL_CAP refined
-// records; longer lists are left to k_rare).  Frames on the generic clustering path are skipped
-// here altogether and done by k_rare.
-template <bool VEC>
-__global__ void __launch_bounds__(64, 4) k_refine(ChainArgs a, RefineConsts rc)
-{
-    __shared__ __attribute__((aligned(16))) uint32_t s_keys[TAIL_CAP + 4];
-    __shared__ uint32_t s_misc[2], s_last;
-    const FrameSlot fs = frame_slot(a.n_frames, true);  // latest-written blur planes first (cache)
-    const int frame = fs.frame;
-    FrameCounters &ctr = a.ctr[frame];
-    if (frame_is_generic(a, ctr)) return;  // whole frame: k_rare
-    if (!(ctr.flags & (FLAG_CAND_OVERFLOW | FLAG_ROOT_OVERFLOW))) {
-        const uint32_t n = min(ctr.n_clusters, a.cap_roots);  // the first flood tier's clusters
-        const size_t cbase = (size_t)frame * a.cap_roots;
-        const float *img = a.blur + (size_t)frame * (size_t)a.plane;
-        // second flood tier: the frame's oversized seeds, one per workgroup (= wave); the cluster it
-        // yields is refined right here by lane 0.  A component that leaves the 128 x 64 window too
-        // flags the frame for the generic path: whatever this launch does with the frame is then
-        // discarded and k_rare redoes it.
-        const uint32_t n_big = min(ctr.n_big, a.cap_roots);
-        const uint32_t *mask = a.mask + (size_t)frame * (size_t)a.mask_plane;
-        for (uint32_t b = fs.slot; b < n_big; b += fs.n_slots) {
-            const uint32_t o = wave_flood_128x64(a, frame, &ctr.flags, n, &ctr.n_clusters2, mask, a.roots[cbase + b], (int)threadIdx.x);
-            if (o != 0xffffffffu && threadIdx.x == 0)
-                refine_cluster<VEC>(a, rc, frame, cbase, img, a.W, a.H, o, &ctr.n_refined, &ctr.max_k_bits);
-        }
-        for (uint32_t i = fs.slot * blockDim.x + threadIdx.x; i < n; i += fs.n_slots * blockDim.x)
-            refine_cluster<VEC>(a, rc, frame, cbase, img, a.W, a.H, i, &ctr.n_refined, &ctr.max_k_bits);
-    }
-    // The workgroup of this frame that arrives last emits the frame.  Everything it reads from the
-    // others (records, counters, flags) was written by write-through stores / atomics and is read by
-    // bypassing loads, so the hand-off needs only "my stores have left" -- an agent-scope release
-    // fence would write back the XCD's whole L2 once per workgroup (6144 times per launch).
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(&ctr.refine_done, 1u) == fs.n_slots - 1u;
-    __syncthreads();
-    if (!s_last) return;
-    if (__hip_atomic_load(&ctr.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & FLAG_BIG_CLUSTER) return;  // flagged by a second-tier flood of this launch: k_rare
-    const uint32_t n_ref = __hip_atomic_load(&ctr.n_refined, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t maxk = __hip_atomic_load(&ctr.max_k_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    emit_small(a, frame, n_ref, maxk, s_keys, s_misc);
-}
-
-// Rare paths, one guarded launch at the end of the chain (a 1024-thread workgroup per frame that
-// returns at once unless the frame is flagged):
-//   FLAG_BIG_CLUSTER   a component left the flood windows: the frame is clustered again by the
-//                      generic union-find path, refined and emitted here;
-//   FLAG_LARGE_RESULT  more than TAIL_CAP refined records: filter and ordered emission with the large
-//                      LDS sort.
+// K5, the last launch of the chain: a 1024-thread workgroup per frame
+//   - filters (detector.rs:436-445) and emits the frame's saddles in the reference's order (emit_wide; lists of
+//     more than TAIL_CAP refined records -- FLAG_LARGE_RESULT -- by the large LDS / global-memory sort);
+//   - before that, for a frame where a component left the flood windows (FLAG_BIG_CLUSTER): clusters it again by
+//     the generic union-find path and refines it;
+//   - clears the other counter set for the next batch.
 __global__ void __launch_bounds__(1024) k_rare(ChainArgs a, RefineConsts rc, uint32_t lds_entries)
 {
     extern __shared__ uint32_t lds_u[];
-    __shared__ uint32_t s_count, s_offset, s_fits;
+    __shared__ uint32_t s_misc3[3];
+    uint32_t &s_count = s_misc3[0], &s_offset = s_misc3[1], &s_fits = s_misc3[2];
+    const WaveTimer wt(a, K_RARE);
     const int frame = blockIdx.x;
     // The last launch of the batch also clears the OTHER counter set for the next batch (the two sets
     // alternate): a memset between the batches costs a fill kernel and two ~5 us gaps on the stream.
@@ -1719,10 +1813,11 @@ __global__ void __launch_bounds__(1024) k_rare(ChainArgs a, RefineConsts rc, uin
     }
     FrameCounters &ctr = a.ctr[frame];
     const bool generic = frame_is_generic(a, ctr);
-    if (!generic && !(ctr.flags & FLAG_LARGE_RESULT)) return;  // whole workgroup
+    const size_t cbase = (size_t)frame * a.cap_roots;
+    const float *img = a.blur + (size_t)frame * (size_t)a.plane;
     if (generic) {
         generic_frame(a, frame);
-        if (threadIdx.x == 0) {  // k_refine may have refined part of the frame before a second-tier flood flagged it
+        if (threadIdx.x == 0) {  // part of the frame was refined before a second-tier flood flagged it
             __hip_atomic_store(&ctr.n_refined, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&ctr.max_k_bits, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -1730,15 +1825,21 @@ __global__ void __launch_bounds__(1024) k_rare(ChainArgs a, RefineConsts rc, uin
         const uint32_t flags = __hip_atomic_load(&ctr.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (!(flags & (FLAG_CAND_OVERFLOW | FLAG_ROOT_OVERFLOW))) {
             const uint32_t n = min(__hip_atomic_load(&ctr.n_clusters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), a.cap_roots);
-            const size_t cbase = (size_t)frame * a.cap_roots;
-            const float *img = a.blur + (size_t)frame * (size_t)a.plane;
             for (uint32_t i = threadIdx.x; i < n; i += blockDim.x)
                 refine_cluster<false>(a, rc, frame, cbase, img, a.W, a.H, i, &ctr.n_refined, &ctr.max_k_bits);
         }
         phase_barrier();
     }
-    const uint32_t n_ref = __hip_atomic_load(&ctr.n_refined, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // a frame whose seed / cluster lists overflowed is reported, not emitted (whatever was refined before the overflow is void)
+    const bool void_frame = (__hip_atomic_load(&ctr.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (FLAG_CAND_OVERFLOW | FLAG_ROOT_OVERFLOW)) != 0;
+    const uint32_t n_ref = void_frame ? 0u : __hip_atomic_load(&ctr.n_refined, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const uint32_t maxk = __hip_atomic_load(&ctr.max_k_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (n_ref <= TAIL_CAP && lds_entries * 2 >= TAIL_CAP + 8) {  // the usual case (lds_entries >= 1024 always: k5_lds_bytes)
+        emit_wide(a, frame, n_ref, maxk, lds_u, &s_count);  // (s_count, s_offset: two adjacent words)
+        return;
+    }
+    if (threadIdx.x == 0) atomicOr(&ctr.flags, FLAG_LARGE_RESULT);
+    __syncthreads();
     if (n_ref <= lds_entries) {
         filter_sort_emit(a, frame, n_ref, maxk, lds_u, lds_u + lds_entries, lds_entries, &s_count, &s_offset, &s_fits);
     } else {
@@ -1793,7 +1894,7 @@ bool plan_k1(ChainArgs &a, int override_rows_per_seg)
 
 size_t k5_lds_bytes(const ChainArgs &a)
 {
-    uint32_t e = 1;
+    uint32_t e = 1024;  // at least the TAIL_CAP + 8 words of emit_wide
     while (e < a.cap_out && e < 16384u) e <<= 1;  // 16384 entries = 128 KB of the CU's 160 KB; longer lists sort in global memory
     return (size_t)e * 8;
 }
@@ -1841,20 +1942,15 @@ int launch_kernel(int which, const ChainArgs &a, const RefineConsts &rc, void *s
         const int n_yb = (a.H + 31) >> 5;
         int tiles = ((n_yb + VS_ROWS - 1) / VS_ROWS) * ((a.W + VS_OWN - 1) / VS_OWN);
         if (tiles > 512) tiles = 512;
-        const int per_frame = env_int("AGX_G_VERIFY", tiles);
-        dim3 grid((unsigned)per_frame * (unsigned)a.n_frames), block(64);  // slot-major, see frame_slot
+        const int per_frame = (env_int("AGX_G_VERIFY", tiles) + VS_WAVES - 1) / VS_WAVES;  // workgroups of VS_WAVES waves
+        dim3 grid((unsigned)per_frame * (unsigned)a.n_frames), block(64 * VS_WAVES);  // slot-major, see frame_slot
         hipLaunchKernelGGL(k_verify_seeds, grid, block, 0, st, a);
         return hipGetLastError();
     }
-    case K_FLOOD: {
+    case K_FLOOD_REFINE: {
         dim3 grid((unsigned)sparse_grid_x(a, 48, "AGX_G_FLOOD") * (unsigned)a.n_frames), block(64);  // slot-major, see frame_slot
-        hipLaunchKernelGGL(k_flood, grid, block, 0, st, a);
-        return hipGetLastError();
-    }
-    case K_REFINE: {
-        dim3 grid((unsigned)sparse_grid_x(a, 24, "AGX_G_REFINE") * (unsigned)a.n_frames), block(64);  // slot-major
-        if ((a.W & 3) == 0) hipLaunchKernelGGL(k_refine<true>, grid, block, 0, st, a, rc);
-        else hipLaunchKernelGGL(k_refine<false>, grid, block, 0, st, a, rc);
+        if ((a.W & 3) == 0) hipLaunchKernelGGL(k_flood_refine<true>, grid, block, 0, st, a, rc);
+        else hipLaunchKernelGGL(k_flood_refine<false>, grid, block, 0, st, a, rc);
         return hipGetLastError();
     }
     case K_RARE: {
@@ -1872,7 +1968,7 @@ int launch_kernel(int which, const ChainArgs &a, const RefineConsts &rc, void *s
 // agx_detector_create after hipSetDevice, once per handle (any number of devices per process).
 int init_device_kernels()
 {
-    return hipFuncSetAttribute((const void *)k_rare, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+    return hipFuncSetAttribute((const void *)k_rare, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
 }
 
 // to_luma8 of one staged frame (detector.rs:507; image 0.25.9: Luma16 -> (v + 128) / 257, Rgb8 ->
@@ -1907,6 +2003,21 @@ int launch_luma8(const void *src, size_t pitch, size_t frame_stride, int n_frame
     else if (format == 2)
         hipLaunchKernelGGL((k_luma8<2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint8_t *)src, pitch, frame_stride, dst, W, H, n_frames);
     else return (int)hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// Zero n counter records (the library's own kernel: a memset node inside a captured HIP graph faulted on the
+// graph's second replay on ROCm 7.2, a kernel node does not).
+__global__ void __launch_bounds__(256) k_clear_counters(uint32_t *p, size_t n_words)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+
+int launch_clear_counters(FrameCounters *ctr, size_t n_records, void *stream)
+{
+    const size_t n_words = n_records * (sizeof(FrameCounters) / 4);
+    const unsigned grid = (unsigned)std::min<size_t>((n_words + 255) / 256, 1024);
+    hipLaunchKernelGGL(k_clear_counters, dim3(grid), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<uint32_t *>(ctr), n_words);
     return hipGetLastError();
 }
 

@@ -21,7 +21,7 @@ using namespace agx;
 
 namespace {
 
-const char *kKernelNames[K_COUNT] = {"k_blur_hessian", "k_verify_seeds", "k_flood", "k_refine_emit", "k_rare"};
+const char *kKernelNames[K_COUNT] = {"k_blur_hessian", "k_verify_seeds", "k_flood_refine", "k_rare_emit"};
 
 struct EventPair {
     hipEvent_t a, b;
@@ -395,8 +395,11 @@ int enqueue_chain(agx_detector *d)
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(d->stream, &cap);
     const bool capturing = cap == hipStreamCaptureStatusActive;
-    if (capturing || d->ctr_cleared[p] < need)
+    if (capturing) {  // (a kernel node: see launch_clear_counters)
+        HIP_TRY(d, (hipError_t)launch_clear_counters(d->d_ctr[p], need, d->stream));
+    } else if (d->ctr_cleared[p] < need) {
         HIP_TRY(d, hipMemsetAsync(d->d_ctr[p], 0, need * sizeof(FrameCounters), d->stream));
+    }
     d->ctr_cleared[p] = 0;
     a.ctr = d->d_ctr[p];
     a.ctr_next = d->d_ctr[p ^ 1];
@@ -734,6 +737,9 @@ static int batch_enqueue_impl(agx_detector *det, const void *d_frames, int n_fra
     }
     a.force_generic = det->force_generic;
     a.dbg = det->dbg;
+    // debug_ablation & 4096: wave start / end times of the sparse kernels into the slot plane (generic path's, sparsely used)
+    a.wave_times = ((det->dbg & 4096) && (size_t)n_frames * (size_t)a.plane * 4 >= 3 * WAVE_TIMES_STRIDE * 16)
+                       ? reinterpret_cast<unsigned long long *>(a.slot_plane) : nullptr;
     a.resp_dbg = nullptr;
     det->resp_stored = false;
     if (det->store_resp) {  // parity tests: K1 also stores the response it evaluates in registers
@@ -1024,10 +1030,10 @@ int agx_profile_read(agx_detector *det, const char **names, double *ms_total, ui
     HIP_TRY(det, hipSetDevice(det->device));
     HIP_TRY(det, hipStreamSynchronize(det->stream));
     harvest_events(det);
-    for (int k = 0; k < K_COUNT; ++k) {
-        if (names) names[k] = kKernelNames[k];
-        if (ms_total) ms_total[k] = det->prof_ms[k];
-        if (launches) launches[k] = det->prof_launches[k];
+    for (int k = 0; k < AGX_N_KERNELS; ++k) {  // the chain has K_COUNT launches; the entries behind them stay empty
+        if (names) names[k] = k < K_COUNT ? kKernelNames[k] : nullptr;
+        if (ms_total) ms_total[k] = k < K_COUNT ? det->prof_ms[k] : 0.0;
+        if (launches) launches[k] = k < K_COUNT ? det->prof_launches[k] : 0;
     }
     return AGX_OK;
 }
@@ -1131,6 +1137,14 @@ int agx_debug_fetch(agx_detector *det, int frame, int what, void *host_out, size
                     }
             }
         std::memcpy(host_out, v, sizeof v);
+        return AGX_OK;
+    }
+    case 10: {  // wave timeline (debug_ablation & 4096): `frame` selects the kernel (1 = verify, 2 = flood, 3 = refine);
+                // cap_bytes / 16 records of {start, end} (100 MHz ticks), one per workgroup in launch order
+        if (!a.wave_times || frame < 1 || frame > 3) return fail(det, AGX_ERR_STATE, "wave timeline needs debug_ablation & 4096 on the last batch");
+        const size_t n = std::min<size_t>(cap_bytes / 16, WAVE_TIMES_STRIDE);
+        *n_items = n;
+        HIP_TRY(det, hipMemcpy(host_out, a.wave_times + 2 * (size_t)(frame - 1) * WAVE_TIMES_STRIDE, n * 16, hipMemcpyDeviceToHost));
         return AGX_OK;
     }
     case 7: {  // verify statistics (debug_ablation & 128), 20 x uint32

@@ -359,7 +359,7 @@ class TagDetector:
         ms = (C.c_double * _ffi.AGX_N_KERNELS)()
         cnt = (C.c_uint64 * _ffi.AGX_N_KERNELS)()
         self._check(self._lib.agx_profile_read(self._h, names, ms, cnt))
-        return {names[i].decode(): (ms[i], int(cnt[i])) for i in range(_ffi.AGX_N_KERNELS)}
+        return {names[i].decode(): (ms[i], int(cnt[i])) for i in range(_ffi.AGX_N_KERNELS) if names[i]}
 
     def constants(self):
         w = np.zeros(7, np.float32)
@@ -372,7 +372,7 @@ class TagDetector:
         """Intermediate product of the last batch: 'blur', 'resp' (HxW f32; K1's in-register response,
         needs set_option("store_response", 1) before the batch), 'resp_recomputed', 'min' (f32),
         'centers' (cluster table sorted by first pixel), 'refined' (unfiltered saddles)."""
-        code = {"blur": 0, "resp": 1, "min": 2, "centers": 3, "refined": 4, "counters": 5, "resp_recomputed": 6, "verify_stats": 7, "redzones": 8, "luma8": 9}[what]
+        code = {"blur": 0, "resp": 1, "min": 2, "centers": 3, "refined": 4, "counters": 5, "resp_recomputed": 6, "verify_stats": 7, "redzones": 8, "luma8": 9, "wave_times": 10}[what]
         n = C.c_size_t(0)
         if code in (0, 1, 6):
             assert shape is not None
@@ -388,6 +388,8 @@ class TagDetector:
         elif code == 9:
             assert shape is not None
             buf = np.empty(shape, np.uint8)
+        elif code == 10:  # `frame` selects the kernel (1 verify, 2 flood, 3 refine); shape = number of workgroups
+            buf = np.zeros((int(shape), 2), np.uint64)
         elif code == 3:
             buf = np.empty(1 << 20, _CLUSTER_DTYPE)
         else:

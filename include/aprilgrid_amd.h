@@ -286,7 +286,8 @@ int agx_luma8(const void *pixels, int width, int height, size_t row_stride_bytes
 
 /* Per-kernel device time of the chain, from hipEvents recorded on the detector's stream
  * around each launch while profiling is on.  names/ms/launches are arrays of
- * AGX_N_KERNELS entries; ms accumulates since the last reset. */
+ * AGX_N_KERNELS entries (the chain has four launches since round 3: entries behind the last one
+ * carry a NULL name and zeros); ms accumulates since the last reset. */
 #define AGX_N_KERNELS 5
 int agx_profile_enable(agx_detector *det, int on); /* 0 off, 1 = the blur kernel only (2 events per batch), 2 = every kernel */
 int agx_profile_reset(agx_detector *det);
