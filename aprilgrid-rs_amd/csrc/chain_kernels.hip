@@ -866,6 +866,11 @@ constexpr uint32_t VS_SEEDS = 256; // seeds buffered per tile
 // Workgroups of VS_WAVES independent waves (each with its own part of the LDS arrays, no workgroup barrier): the
 // launch used to be 41 000 single-wave workgroups for 256 frames and was bound by the rate at which workgroups
 // are dispatched (~580 per us sustained, half of the wave slots empty); a wave = a slot of its frame as before.
+#ifndef AGX_VS_ATTR
+// k_verify_seeds is a chain of memory round trips: as many waves as possible per SIMD.  Left alone the compiler
+// takes 106 scalar registers (6 waves per SIMD); with 80 it fits 8: 59 -> 54 us for 256 frames.
+#define AGX_VS_ATTR __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8)))
+#endif
 #ifndef AGX_VS_WAVES
 #define AGX_VS_WAVES 1
 #endif
@@ -878,7 +883,7 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__global__ void __launch_bounds__(64 * VS_WAVES) k_verify_seeds(ChainArgs a)
+__global__ void __launch_bounds__(64 * VS_WAVES) AGX_VS_ATTR k_verify_seeds(ChainArgs a)
 {
     __shared__ uint32_t s_keep_all[VS_WAVES][(VS_ROWS + 1) * 64];  // row VS_ROWS: bit 0 = the pixel above the tile's first row
     __shared__ uint32_t s_list_all[VS_WAVES][VS_LIST];  // re-test work list, then the tile's seeds (VS_SEEDS <= VS_LIST)
@@ -893,7 +898,6 @@ __global__ void __launch_bounds__(64 * VS_WAVES) k_verify_seeds(ChainArgs a)
     fs.n_slots *= VS_WAVES;
     const int frame = fs.frame;
     FrameCounters &ctr = a.ctr[frame];
-    const float thr = f32_from_order_key(~ctr.min_key_inv) * 0.05f;
     uint32_t *mask = a.mask + (size_t)frame * (size_t)a.mask_plane;
     const float *blur = a.blur + (size_t)frame * (size_t)a.plane;
     const float *cmax_f = a.cand_max + (size_t)frame * (size_t)a.mask_yb * (size_t)(a.mask_wpr >> 2);
@@ -904,27 +908,51 @@ __global__ void __launch_bounds__(64 * VS_WAVES) k_verify_seeds(ChainArgs a)
     const int tiles = ((n_yb + VS_ROWS - 1) / VS_ROWS) * groups;
     if (lane == 0) s_nseeds = 0u;
     wave_lds_sync();
+    // debug_ablation & 8192: where a wave's time goes -- 10 ns ticks per phase summed into the frame's stats[0..5]
+    // (first loads, block maxima + threshold, work list + re-tests, seeds, list append, rest), tiles in stats[7]
+    const bool phase_on = (a.dbg & 8192) != 0;
+    unsigned long long t_prev = phase_on ? wall_clock64() : 0ull;
+    auto phase = [&](int which) {
+        if (phase_on) {
+            const unsigned long long now = wall_clock64();
+            if (lane == 0) atomicAdd(&ctr.stats[which], (uint32_t)(now - t_prev));
+            t_prev = now;
+        }
+    };
     for (int t = (int)fs.slot; t < tiles; t += (int)fs.n_slots) {  // wave-uniform
         const int ch = t / groups, g = t - ch * groups;
         const int yb0 = ch * VS_ROWS;
-        const int nr = min(VS_ROWS, n_yb - yb0);
         const int x = g * VS_OWN - 1 + lane;  // -1 .. W + 62: inside the mask's zero padding
         uint32_t *wp0 = mask + (size_t)yb0 * wpr + MASK_PAD_X + x;
         const size_t cm_col = (size_t)((MASK_PAD_X + x) >> 2);
-        // round trip 1: the lane's words, the word above the tile, their blocks' maxima
+        // round trip 1: the lane's words, the word above the tile, their blocks' maxima, the frame's minimum -- eleven
+        // loads issued back to back and awaited together.  All of them unconditional: word rows past the image exist and are zero (the
+        // mask plane has mask_yb = H/32 + 4 of them), the maxima of such rows are never looked at (their words are
+        // zero), and the row above the first tile is replaced by the tile's own first row and discarded.  (With a
+        // condition per row the compiler used to wait for each load before it issued the next: five round trips,
+        // 40 % of the launch's wave time.)
         uint32_t m[VS_ROWS];
 #pragma unroll
-        for (int r = 0; r < VS_ROWS; ++r) m[r] = r < nr ? wp0[(size_t)r * wpr] : 0u;
-        const uint32_t uword = yb0 > 0 ? wp0[-wpr] : 0u;
-        // (the block maxima are fetched in the same round trip, needed or not: the plane is small)
+        for (int r = 0; r < VS_ROWS; ++r) m[r] = wp0[(size_t)r * wpr];
+        const int up_row = yb0 > 0 ? -1 : 0;
+        uint32_t uword = wp0[(ptrdiff_t)up_row * wpr];
         float cm_pre[VS_ROWS];
 #pragma unroll
-        for (int r = 0; r < VS_ROWS; ++r) cm_pre[r] = r < nr ? cmax_f[(size_t)(yb0 + r) * (wpr >> 2) + cm_col] : 0.0f;
-        const float cmu_pre = yb0 > 0 ? cmax_f[(size_t)(yb0 - 1) * (wpr >> 2) + cm_col] : 0.0f;
+        for (int r = 0; r < VS_ROWS; ++r) cm_pre[r] = cmax_f[(size_t)(yb0 + r) * (wpr >> 2) + cm_col];
+        float cmu_pre = cmax_f[(size_t)(yb0 + up_row) * (wpr >> 2) + cm_col];
+        uint32_t min_key_inv = ctr.min_key_inv;  // the frame's minimum (K1 is through): in the same round trip
+        asm volatile("" : "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(uword), "+v"(cm_pre[0]), "+v"(cm_pre[1]), "+v"(cm_pre[2]),
+                     "+v"(cm_pre[3]), "+v"(cmu_pre), "+v"(min_key_inv));  // (all consumed here: nothing is left to be loaded behind a branch)
+        const float thr = f32_from_order_key(~min_key_inv) * 0.05f;  // detector.rs:418
+        static_assert(VS_ROWS == 4, "the asm above names the tile's four rows");
+        if (yb0 == 0) uword = 0u;
         uint32_t any = 0u;
 #pragma unroll
         for (int r = 0; r < VS_ROWS; ++r) any |= m[r];
-        if (!__any(any != 0u)) continue;
+        const bool tile_empty = !__any(any != 0u);
+        phase(0);
+        if (phase_on && lane == 0) atomicAdd(&ctr.stats[tile_empty ? 6 : 7], 1u);
+        if (tile_empty) continue;
         // every candidate K1 admitted in a word's 4-column x 32-row block is <= cand_max;
         // if that is below the final threshold they all pass and nothing needs recomputing
         float cm[VS_ROWS];
@@ -938,6 +966,7 @@ __global__ void __launch_bounds__(64 * VS_WAVES) k_verify_seeds(ChainArgs a)
         for (int r = 0; r < VS_ROWS; ++r)
             if (m[r] && !(cm[r] < thr)) needmask |= 1u << r;
         const bool up_retest = up_need && !(cmu < thr);
+        if (phase_on) { (void)__any(needmask != 0u || up_retest); phase(1); }
         if (a.dbg & 128) {  // statistics by word row within the K1 segment (4 word rows of 128 rows)
             const bool own = lane >= 1 && lane <= VS_OWN && x < W;
 #pragma unroll
@@ -1032,6 +1061,7 @@ __global__ void __launch_bounds__(64 * VS_WAVES) k_verify_seeds(ChainArgs a)
                 if (rows_any & (1u << r)) keep[r] = s_keep[r * 64 + lane];
             if (up_retest) upbit = s_keep[VS_ROWS * 64 + lane] & 1u;
         }
+        phase(2);
         const bool owner = lane >= 1 && lane <= VS_OWN && x < W;
 #pragma unroll
         for (int r = 0; r < VS_ROWS; ++r)
@@ -1078,9 +1108,11 @@ __global__ void __launch_bounds__(64 * VS_WAVES) k_verify_seeds(ChainArgs a)
         // append the tile's seeds to the frame's list: one atomic, coalesced stores
         wave_lds_sync();
         const uint32_t ns = min(s_nseeds, VS_SEEDS);
+        phase(3);
         if (ns) {  // wave-uniform
             if (lane == 0) s_base = atomicAdd(&ctr.n_seeds, ns);
             wave_lds_sync();
+            if (phase_on) { (void)__any(s_base == 0xffffffffu); phase(4); }
             for (uint32_t i = (uint32_t)lane; i < ns; i += 64u) {
                 const uint32_t o = s_base + i;
                 if (o < a.cap_roots) a.seeds[(size_t)frame * a.cap_roots + o] = s_seeds[i];
@@ -1090,6 +1122,7 @@ __global__ void __launch_bounds__(64 * VS_WAVES) k_verify_seeds(ChainArgs a)
             if (lane == 0) s_nseeds = 0u;
             wave_lds_sync();
         }
+        phase(5);
     }
 }
 
