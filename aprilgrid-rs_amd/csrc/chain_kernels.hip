@@ -1261,9 +1261,16 @@ __device__ __forceinline__ int flood_lane(const ChainArgs &a, const uint32_t *ma
     const int sh = (int)((sy - 1u) & 31u);
     const uint32_t *wp = mask + (size_t)((sy - 1u) >> 5) * a.mask_wpr + MASK_PAD_X + ((int)sx - FLOOD_SEED_COL);
     uint32_t cand[FLOOD_COLS], comp[FLOOD_COLS];
+    // both word rows of the window in flight together (comp[] holds the second one until the two are combined)
+#pragma unroll
+    for (int c = 0; c < FLOOD_COLS; ++c) cand[c] = wp[c];
+#pragma unroll
+    for (int c = 0; c < FLOOD_COLS; ++c) comp[c] = wp[a.mask_wpr + c];
+#pragma unroll
+    for (int c = 0; c < FLOOD_COLS; ++c) asm volatile("" : "+v"(cand[c]), "+v"(comp[c]));  // (consumed here, all 2 x FLOOD_COLS words)
 #pragma unroll
     for (int c = 0; c < FLOOD_COLS; ++c) {
-        const unsigned long long two = (unsigned long long)wp[c] | ((unsigned long long)wp[a.mask_wpr + c] << 32);
+        const unsigned long long two = (unsigned long long)cand[c] | ((unsigned long long)comp[c] << 32);
         cand[c] = (uint32_t)(two >> sh);  // bit r = row sy-1+r of column sx-16+c
         comp[c] = 0u;
     }
@@ -1624,19 +1631,26 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AGX_FLO
     const FrameSlot fs = frame_slot(a.n_frames, true);  // latest-written blur planes first (cache)
     const int frame = fs.frame;
     FrameCounters &ctr = a.ctr[frame];
-    if (a.force_generic || (ctr.flags & FLAG_CAND_OVERFLOW)) return;  // whole frame: k_rare / reported
-    const uint32_t n = min(ctr.n_seeds, a.cap_roots);
+    if (a.force_generic) return;  // whole frame: k_rare
+    const size_t cbase = (size_t)frame * a.cap_roots;
+    const int lane = threadIdx.x;
+    // the frame's flags and seed count and this lane's first seed in ONE round trip (the seed is fetched before the
+    // count is known: any index below cap_roots is inside the list)
+    uint32_t flags0 = ctr.flags, n_seeds0 = ctr.n_seeds;
+    const uint32_t i0 = fs.slot * 64u + (uint32_t)lane;
+    uint32_t p0 = i0 < a.cap_roots ? a.seeds[cbase + i0] : 0u;
+    asm volatile("" : "+v"(flags0), "+v"(n_seeds0), "+v"(p0));  // (all three consumed here: no load is left behind a branch)
+    if (flags0 & FLAG_CAND_OVERFLOW) return;  // reported
+    const uint32_t n = min(n_seeds0, a.cap_roots);
     const uint32_t *mask = a.mask + (size_t)frame * (size_t)a.mask_plane;
     const float *img = a.blur + (size_t)frame * (size_t)a.plane;
-    const size_t cbase = (size_t)frame * a.cap_roots;
     const uint32_t W = (uint32_t)a.W;
-    const int lane = threadIdx.x;
     for (uint32_t base = fs.slot * 64u; base < n; base += fs.n_slots * 64u) {  // wave-uniform trip count
         const uint32_t i = base + (uint32_t)lane;
         uint32_t p = 0u, cnt = 0, sumx = 0, sumy = 0;
         int what = FLOOD_NONE;
         if (i < n) {
-            p = a.seeds[cbase + i];
+            p = base == fs.slot * 64u ? p0 : a.seeds[cbase + i];
             what = flood_lane(a, mask, W, p, cnt, sumx, sumy);
         }
         // Second tier: components that may leave the lane's window (about 1 % of the seeds on real frames) are

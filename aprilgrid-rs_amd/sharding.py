@@ -116,10 +116,15 @@ class ChainPipeline:
         saddles, tables = pipe.finish()   # results of the LAST batch (lists over ranks on dst)
     """
 
-    def __init__(self, tag_family, n_frames, device, depth=2, params=None, dst=0, group=None, slab_records=SLAB_RECORDS):
-        from .detector import TagDetector
+    def __init__(self, tag_family, n_frames, device, depth=2, params=None, dst=0, group=None, slab_records=SLAB_RECORDS,
+                 detector_cls=None):
+        # detector_cls: a stand-in with TagDetector's enqueue interface (the CPU test of bench.py's N > 1 control flow)
+        if detector_cls is None:
+            from .detector import TagDetector
+        else:
+            TagDetector = detector_cls
         dev = torch.device(device)
-        index = dev.index if dev.index is not None else torch.cuda.current_device()
+        index = dev.index if dev.index is not None else (torch.cuda.current_device() if dev.type == "cuda" else 0)
         self.device = dev
         # (3 or 4 in flight is where the gain levels off; each one holds a full workspace)
         self.depth = min(max(1, int(depth)), 6)

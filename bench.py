@@ -325,6 +325,34 @@ def host_boundary_leg(torch, A, dev, n_frames, width, height, steps):
         torch.cuda.empty_cache()
 
 
+class CudaRuntime:
+    """What main() needs from the device side.  tests/bench_stub.py provides the same interface on the CPU (gloo
+    backend, the oracle behind the detector's enqueue call) so that the N > 1 control flow of main() -- settle-round
+    broadcast, gather, gather_check, all_reduce of the step time -- runs in the CPU test suite; selected by the
+    environment variable AGX_BENCH_STUB=1 and never on a GPU box."""
+    backend = "nccl"
+
+    def __init__(self, torch):
+        self.torch = torch
+        import aprilgrid_rs_amd as A
+        self.A = A
+        self.detector_cls = None  # sharding.ChainPipeline's default: the package's TagDetector
+
+    def device(self, local_rank):
+        assert self.torch.cuda.is_available(), "bench.py needs an MI355X"
+        self.torch.cuda.set_device(local_rank)
+        return self.torch.device("cuda", local_rank)
+
+    def init_process_group(self, dist, dev):
+        dist.init_process_group(self.backend, device_id=dev)
+
+    def synchronize(self, dev):
+        self.torch.cuda.synchronize(dev)
+
+    def event(self):
+        return self.torch.cuda.Event(enable_timing=True)
+
+
 def main():
     args = parse_args()
     if args.images:
@@ -334,8 +362,13 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
-    import aprilgrid_rs_amd as A
     from aprilgrid_rs_amd import sharding
+    if os.environ.get("AGX_BENCH_STUB") == "1":  # CPU test of the N > 1 control flow (tests/test_bench_cpu.py)
+        from tests import bench_stub
+        rt = bench_stub.StubRuntime(torch)
+    else:
+        rt = CudaRuntime(torch)
+    A = rt.A
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -344,12 +377,10 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs the torch.distributed.run launcher (WORLD_SIZE=%d)" % (args.gpus, world))
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev = rt.device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        rt.init_process_group(dist, dev)
 
     W, H, F = args.width, args.height, args.frames
     # ---- synthetic workload: frames [rank*F, rank*F + F) of the seeded generator, rendered
@@ -363,17 +394,18 @@ def main():
     # HBM; for N > 1 they are gathered to rank 0 asynchronously (RCCL over xGMI) -- the one
     # collective of the path -- so the gather of a step overlaps the chain of the next.
     slab = 8192 if args.noise else sharding.SLAB_RECORDS  # pure noise: ~7100 saddles per 1280x800 frame
-    pipe = sharding.ChainPipeline(A.TagFamily.T36H11, F, dev, depth=args.pipeline, dst=0, slab_records=slab)
+    pipe = sharding.ChainPipeline(A.TagFamily.T36H11, F, dev, depth=args.pipeline, dst=0, slab_records=slab,
+                                  detector_cls=rt.detector_cls)
 
     def step():
         pipe.submit(frames)
 
     def fence():
         res = pipe.finish()
-        torch.cuda.synchronize(dev)
+        rt.synchronize(dev)
         if world > 1:
             dist.barrier()
-            torch.cuda.synchronize(dev)
+            rt.synchronize(dev)
         return res
 
     # setup, untimed: first call allocates the workspace; then run until the clocks have settled.
@@ -388,9 +420,9 @@ def main():
     t_round = time.perf_counter() - t_round  # one round of 8 steps, workspace already allocated
     rounds = int(min(128, max(0, args.settle_ms * 1e-3 / max(t_round, 1e-4))))
     if world > 1:
-        rt = torch.tensor([rounds], dtype=torch.int64, device=dev)
-        dist.broadcast(rt, src=0)
-        rounds = int(rt.item())
+        rounds_t = torch.tensor([rounds], dtype=torch.int64, device=dev)
+        dist.broadcast(rounds_t, src=0)
+        rounds = int(rounds_t.item())
     for _ in range(rounds):
         for _ in range(8):
             step()
@@ -413,7 +445,7 @@ def main():
         d.profile_enable(1)
         d.profile_reset()
     serial = pipe.depth == 1
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)] if serial else []
+    evs = [rt.event() for _ in range(args.steps + 1)] if serial else []
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):

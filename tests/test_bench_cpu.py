@@ -26,3 +26,32 @@ def test_bench_refuses_multi_gpu_without_the_launcher():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, env={**os.environ, "WORLD_SIZE": "1"})
     assert r.returncode != 0 and "torch.distributed.run" in (r.stderr + r.stdout)
+
+
+def test_bench_two_rank_control_flow_under_gloo():
+    """bench.main() with WORLD_SIZE = 2, launched exactly as the driver launches it (torch.distributed.run), on the
+    CPU: gloo backend and tests/bench_stub.py behind the detector.  Every rank walks the real control flow -- settle
+    rounds broadcast from rank 0, the double-buffered per-step gathers, the barriers, gather_check with the oracle
+    check of a remote frame, the all_reduce of the step time -- so a collective-sequence mismatch between the ranks
+    hangs or fails here, not on the first 8-GPU run.  Rank 0 prints the one JSON line."""
+    import json
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {**os.environ, "AGX_BENCH_STUB": "1", "PYTHONPATH": ROOT, "OMP_NUM_THREADS": "1"}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--frames", "2", "--width", "192", "--height", "128", "--settle-ms", "30", "--no-extra", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # ONE line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak" and out["unit"] == "Mpix/s"
+    gc = out["gather_check"]
+    assert gc["ranks"] == 2 and gc["frames"] == 4 and gc["saddles"] > 0 and gc["oracle_checked_remote_frames"] == 1
+    # whole-job value: both ranks' pixels over the slowest rank's time
+    assert abs(out["value"] - 2 * 2 * 192 * 128 * 3 / (out["ms_per_step"] * 3 * 1e-3) / 1e6) < 0.02 * out["value"]
+    assert "configs[2]" in out["config"]["workload"] and "chain_frac" in out["roofline"] and "a_min_frac" in out["roofline"]
