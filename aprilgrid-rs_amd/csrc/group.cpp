@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -42,14 +43,27 @@ struct Rccl {
 };
 constexpr int kNcclUint8 = 1;  // ncclUint8 / ncclChar family: 0 = int8, 1 = uint8
 
+// AGX_RCCL_LIBRARY (environment): the library to bind instead of librccl.  The test suite points it at a stand-in
+// (tests/stub_rccl) that moves the bytes with peer copies, so that this file's RCCL branch runs on a one-GPU box --
+// several ranks on one device, which the real library refuses.
+const char *rccl_override()
+{
+    const char *p = getenv("AGX_RCCL_LIBRARY");
+    return (p && *p) ? p : nullptr;
+}
+
 bool load_rccl(Rccl &r, std::string &err)
 {
     if (r.lib) return true;
-    // the soname first: a process that already holds an RCCL (e.g. the one bundled with PyTorch)
-    // gets that copy back instead of a second runtime
-    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-        r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-        if (r.lib) break;
+    if (const char *over = rccl_override()) {
+        r.lib = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+    } else {
+        // the soname first: a process that already holds an RCCL (e.g. the one bundled with PyTorch)
+        // gets that copy back instead of a second runtime
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (r.lib) break;
+        }
     }
     if (!r.lib) {
         err = std::string("dlopen librccl: ") + (dlerror() ? dlerror() : "not found");
@@ -174,7 +188,7 @@ int agx_group_create(int family, const agx_params *params, const int *devices, i
     g->n = n_devices;
     g->transport = transport;
     for (int r = 0; r < n_devices; ++r) g->devices.push_back(devices ? devices[r] : r);
-    if (transport == AGX_GATHER_RCCL)
+    if (transport == AGX_GATHER_RCCL && !rccl_override())
         for (int r = 0; r < n_devices; ++r)
             for (int q = 0; q < r; ++q)
                 if (g->devices[q] == g->devices[r])

@@ -289,3 +289,36 @@ def test_host_tail_decodes_every_family_on_rendered_boards(family):
             assert bits_equal(got[tid], ref[tid])
             err = np.abs(np.sort(got[tid], axis=0) - np.sort(gt[tid].astype(np.float32), axis=0)).max()
             assert err < 0.5, (family, tid, err)
+
+
+def test_rccl_prototypes_group_cpp_binds_by_name():
+    """group.cpp opens librccl with dlopen and calls seven entry points through hand-written function-pointer types
+    (rccl.h is not included: the library is optional at run time).  The installed header must agree with them: the
+    parameter lists, ncclUint8 == 1 (the only data type used) and ncclSuccess == 0 -- and the test suite's stand-in
+    (tests/stub_rccl) must export the same names."""
+    import re
+    hdr = "/opt/rocm/include/rccl/rccl.h"
+    if not os.path.exists(hdr):
+        pytest.skip("no rccl.h in this image")
+    h = re.sub(r"\s+", " ", open(hdr).read())
+    want = {
+        "ncclCommInitAll": "ncclComm_t* comm, int ndev, const int* devlist",
+        "ncclCommDestroy": "ncclComm_t comm",
+        "ncclGroupStart": "",
+        "ncclGroupEnd": "",
+        "ncclSend": "const void* sendbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream",
+        "ncclRecv": "void* recvbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream",
+        "ncclGetErrorString": "ncclResult_t result",
+    }
+    for name, params in want.items():
+        m = re.search(r"[\w\* ]+ %s\(([^)]*)\);" % name, h)
+        assert m, name
+        got = m.group(1).strip()
+        assert got.replace("void", "") .strip() == params or got == params, (name, got)
+    assert re.search(r"ncclUint8 = 1,", h) and re.search(r"ncclSuccess = 0,", h)
+    src = open(os.path.join(ROOT, "aprilgrid-rs_amd", "csrc", "group.cpp")).read()
+    stub = open(os.path.join(ROOT, "tests", "stub_rccl", "stub_rccl.cpp")).read()
+    for name in want:
+        assert 'sym("%s")' % name in src, name
+        assert re.search(r"\b%s\(" % name, stub), name
+    assert "kNcclUint8 = 1" in src

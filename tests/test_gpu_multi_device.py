@@ -127,6 +127,49 @@ def test_group_rccl_transport(oracle):
         A.DetectorGroup("t36h11", [0, 0], transport="rccl")  # duplicate devices: refused, not hung
 
 
+def test_group_rccl_branch_with_stand_in_library(oracle, tmp_path):
+    """group.cpp's RCCL transport -- the dlsym'd prototypes, one ncclGroupStart / ncclGroupEnd bracket per batch with a
+    send pair per non-root rank and the matching receives on the root's communicator, everything enqueued on the
+    ranks' own streams behind their chains -- with THREE ranks on one device: AGX_RCCL_LIBRARY points the loader at
+    tests/stub_rccl (peer copies + events behind librccl's entry points, with the argument checks of the real
+    library).  The gathered lists must equal the oracle's; the stand-in's counters must show exactly the calls the
+    transport is supposed to make.  (No multi-GPU hardware: the real library's first run is the driver's.)"""
+    import ctypes as C
+    import subprocess
+    import torch
+    import aprilgrid_rs_amd as A
+    from tests.util import ROOT
+    so = str(tmp_path / "librccl_stub.so")
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "-O2", "-fPIC", "-shared", "-o", so, os.path.join(ROOT, "tests", "stub_rccl", "stub_rccl.cpp")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    os.environ["AGX_RCCL_LIBRARY"] = so
+    try:
+        ranks, fpr = 3, 3
+        grp = A.DetectorGroup("t36h11", [0] * ranks, transport="rccl")
+        frames = [_frames(90 + fpr * r, fpr, "cuda:0") for r in range(ranks)]
+        torch.cuda.synchronize(0)
+        for rep in range(3):  # slab reuse, one group per batch
+            grp.saddles_enqueue(frames)
+            res, status = grp.saddles_fetch()
+        assert (status == 0).all() and len(res) == ranks * fpr
+        host = np.concatenate([f.cpu().numpy() for f in frames])
+        refs = oracle_saddles_parallel(oracle, host, threads=4)
+        for i in range(len(res)):
+            check_saddles(res[i], refs[i], "global frame %d" % i)
+        stub = C.CDLL(so)
+        st = (C.c_int * 8)()
+        stub.stub_rccl_stats(st)
+        groups, sends, recvs, kib, errors, created, destroyed, max_ops = list(st)
+        assert errors == 0 and groups == 3 and created == ranks and destroyed == 0
+        assert sends == recvs == 3 * 2 * (ranks - 1) and max_ops == 4 * (ranks - 1) and kib > 0
+        grp.close()
+        stub.stub_rccl_stats(st)
+        assert st[6] == ranks and st[4] == 0
+    finally:
+        del os.environ["AGX_RCCL_LIBRARY"]
+
+
 def test_plain_c_group_client(oracle, tmp_path):
     """examples/c_group_client.c -- no Python / torch in that process: 3 ranks round-robin over the
     visible devices with the peer-copy gather, and one rank per device with the RCCL gather; the
