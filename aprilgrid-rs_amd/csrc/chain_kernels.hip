@@ -1528,24 +1528,42 @@ __device__ __forceinline__ void refine_values(const ChainArgs &a, const RefineCo
 #pragma unroll
     for (int q = 0; q < 25; ++q) conv[q] = 0.0f;
     float prm[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    // The window's rows are fetched in two batches (rows 0..4, rows 5..8) with all loads of a batch in flight
+    // together: fetched row by row -- three loads, a wait, the row's arithmetic -- a lane went through nine
+    // dependent memory round trips, which is what a wave that starts late (or runs while the memory system is not
+    // saturated by the others) spends its life on.
+    constexpr int NQ = VEC ? 3 : 9;  // loads per row: 3 x 16 bytes, or 9 floats
+    typedef float rowload_t __attribute__((ext_vector_type(VEC ? 4 : 1)));
+    rowload_t raw[5][NQ];
+    auto fetch = [&](int first, int n) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+            if (k < n) {
+#pragma unroll
+                for (int e = 0; e < NQ; ++e)
+                    raw[k][e] = *reinterpret_cast<const rowload_t *>(win + (size_t)(first + k) * W + (VEC ? 4 * e : e));
+            }
+        asm volatile("" ::: "memory");  // every load of the batch is issued before the first one is waited for
+    };
+    fetch(0, 5);
 #pragma unroll
     for (int wr = 0; wr < 9; ++wr) {
+        if (wr == 5) fetch(5, 4);
         float v[9];
+        const int k = wr < 5 ? wr : wr - 5;
         if (VEC) {
             // three aligned 16-byte loads cover the 9 floats; shift by the misalignment
-            const float4 q0 = *reinterpret_cast<const float4 *>(win + (size_t)wr * W);
-            const float4 q1 = *reinterpret_cast<const float4 *>(win + (size_t)wr * W + 4);
-            const float4 q2 = *reinterpret_cast<const float4 *>(win + (size_t)wr * W + 8);
+            const rowload_t q0 = raw[k][0], q1 = raw[k][1 % NQ], q2 = raw[k][2 % NQ];
             const bool s1 = (al & 1) != 0, s2 = (al & 2) != 0;
             // shift left by 1 if s1, then by 2 if s2 (all indices compile-time)
-            const float u0 = s1 ? q0.y : q0.x, u1 = s1 ? q0.z : q0.y, u2 = s1 ? q0.w : q0.z, u3 = s1 ? q1.x : q0.w;
-            const float u4 = s1 ? q1.y : q1.x, u5 = s1 ? q1.z : q1.y, u6 = s1 ? q1.w : q1.z, u7 = s1 ? q2.x : q1.w;
-            const float u8 = s1 ? q2.y : q2.x, u9 = s1 ? q2.z : q2.y, u10 = s1 ? q2.w : q2.z;
+            const float u0 = s1 ? q0[1 % (VEC ? 4 : 1)] : q0[0], u1 = s1 ? q0[2 % (VEC ? 4 : 1)] : q0[1 % (VEC ? 4 : 1)], u2 = s1 ? q0[3 % (VEC ? 4 : 1)] : q0[2 % (VEC ? 4 : 1)], u3 = s1 ? q1[0] : q0[3 % (VEC ? 4 : 1)];
+            const float u4 = s1 ? q1[1 % (VEC ? 4 : 1)] : q1[0], u5 = s1 ? q1[2 % (VEC ? 4 : 1)] : q1[1 % (VEC ? 4 : 1)], u6 = s1 ? q1[3 % (VEC ? 4 : 1)] : q1[2 % (VEC ? 4 : 1)], u7 = s1 ? q2[0] : q1[3 % (VEC ? 4 : 1)];
+            const float u8 = s1 ? q2[1 % (VEC ? 4 : 1)] : q2[0], u9 = s1 ? q2[2 % (VEC ? 4 : 1)] : q2[1 % (VEC ? 4 : 1)], u10 = s1 ? q2[3 % (VEC ? 4 : 1)] : q2[2 % (VEC ? 4 : 1)];
             v[0] = s2 ? u2 : u0; v[1] = s2 ? u3 : u1; v[2] = s2 ? u4 : u2; v[3] = s2 ? u5 : u3; v[4] = s2 ? u6 : u4;
             v[5] = s2 ? u7 : u5; v[6] = s2 ? u8 : u6; v[7] = s2 ? u9 : u7; v[8] = s2 ? u10 : u8;
         } else {
 #pragma unroll
-            for (int e = 0; e < 9; ++e) v[e] = win[(size_t)wr * W + e];
+            for (int e = 0; e < 9; ++e) v[e] = raw[k][e % NQ][0];
         }
 #pragma unroll
         for (int r = 0; r < 5; ++r) {

@@ -61,7 +61,7 @@ def test_hip_path_reproduces_the_golden_lists_without_the_oracle(name):
         img = load_image(name)
         g = golden(name)
         s = det.refined_saddle_points(img, as_array=True)
-        check_saddle_fields(s[:, 0], s[:, 1], s[:, 2], s[:, 3], s[:, 4], g, name + " (HIP)")
+        check_saddle_fields(s["x"], s["y"], s["k"], s["theta"], s["phi"], g, name + " (HIP)")
         check_tags(det.detect(img), g, name + " (HIP)")
     finally:
         det.close()
