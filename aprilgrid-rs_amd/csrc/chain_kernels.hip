@@ -19,16 +19,16 @@
 //   K2 k_verify_seeds   the exact threshold resp < 0.05*min_frame (detector.rs:418,177) at the set
 //                       bits that can still fail (response recomputed from the blur plane) and the
 //                       flood seeds, in one pass over the mask
-//   K3 k_flood          4-connected components (image_util.rs:208-236) + centroid sums
+//   K3 k_flood_refine   4-connected components (image_util.rs:208-236) + centroid sums
 //                       (detector.rs:421-429): one component per lane, bit-parallel flood fill
 //                       of a 32x32 window of the mask held in registers; oversized components
-//                       by the whole wave in a 128x64 window
-//   K4 k_refine         rochade_refine (detector.rs:194-361), one cluster per lane; the workgroup
-//                       of a frame that finishes last applies the k/phi filter (detector.rs:436-445)
-//                       and emits the frame's saddles in reference order
-//   K5 k_rare           one guarded launch for the rare frames: generic clustering fallback (mask
-//                       -> candidate list -> lock-free union-find -> sums) where a component leaves
-//                       the flood windows, and the large-list sort (> 512 saddles per frame)
+//                       by the whole wave in a 128x64 window; then rochade_refine
+//                       (detector.rs:194-361) of the cluster by the lane that flooded it
+//   K4 k_rare           per frame (1024 threads): the k/phi filter (detector.rs:436-445) and the
+//                       emission of the frame's saddles in reference order; before that, for frames
+//                       where a component leaves the flood windows, the generic clustering fallback
+//                       (mask -> candidate list -> lock-free union-find -> sums) and its refinement;
+//                       the large-list sort (> 1024 refined records per frame)
 #include <hip/hip_runtime.h>
 
 #include "chain_kernels.h"
@@ -1134,7 +1134,7 @@ __global__ void __launch_bounds__(64 * VS_WAVES) AGX_VS_ATTR k_verify_seeds(Chai
 // canonical one iff its component contains no pixel with a smaller raster index: then the lane
 // emits the cluster with exact integer sums.  A component that touches the window's left /
 // right / bottom edge may continue outside: it goes to the second tier (wave_flood_128x64,
-// 128 x 64 window, run by k_refine's first workgroups); a component that leaves that window too
+// 128 x 64 window, by the whole wave that found the seed); a component that leaves that window too
 // sets FLAG_BIG_CLUSTER and the whole frame is redone by the generic path (k_rare).
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t fill_runs(uint32_t s, uint32_t m)
@@ -1703,7 +1703,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AGX_FLO
 }
 
 // ------------------------------------------------------------------------------------------
-// K5: filter (detector.rs:436-445) and emission in the reference's order = ascending first
+// K4: filter (detector.rs:436-445) and emission in the reference's order = ascending first
 // (smallest) pixel index of the cluster.  One workgroup per frame; bitonic sort in LDS.
 // ------------------------------------------------------------------------------------------
 // The k / phi filter (detector.rs:436-445) and the ordered emission of one frame by one workgroup:
@@ -1857,7 +1857,7 @@ __device__ __forceinline__ void emit_wide(const ChainArgs &a, int frame, uint32_
     for (int q = 0; q < 5; ++q) out[(size_t)rank * 5 + q] = __uint_as_float(f[q + 1]);
 }
 
-// K5, the last launch of the chain: a 1024-thread workgroup per frame
+// K4, the last launch of the chain: a 1024-thread workgroup per frame
 //   - filters (detector.rs:436-445) and emits the frame's saddles in the reference's order (emit_wide; lists of
 //     more than TAIL_CAP refined records -- FLAG_LARGE_RESULT -- by the large LDS / global-memory sort);
 //   - before that, for a frame where a component left the flood windows (FLAG_BIG_CLUSTER): clusters it again by

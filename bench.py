@@ -2,7 +2,7 @@
 """bench.py -- throughput of the AprilGrid saddle chain on MI355X.
 
 A "step" is one pass of the hot path (luma -> blur -> Hessian response -> min/threshold ->
-clustering -> rochade_refine -> k/phi filter, kernels K1..K5) over one batch of synthetic
+clustering -> rochade_refine -> k/phi filter, kernels K1..K4) over one batch of synthetic
 1280x800 u8 frames that is already resident in HBM.  N = 1 is BASELINE.json configs[1]
 (256 frames on one MI355X); N > 1 is configs[2]: every rank owns 256 frames (weak scaling,
 2048 frames on 8 GPUs) and the only collective is the per-step RCCL gather of the result
@@ -565,7 +565,7 @@ def main():
             if traffic:
                 roof["traffic_frac_of_copy_this_box"] = round(traffic / (roof["avg_launch_ms"] * 1e-3) / 1e9 / copy_gbps, 4)
         # the CHAIN against the roofline -- bytes the design moves (and A_min beside it) over the
-        # whole step as timed (first launch of K1 to the end of K5, ms_per_step), against 8 TB/s
+        # whole step as timed (first launch of K1 to the end of the last kernel, ms_per_step), against 8 TB/s
         step_s = ms_per_step * 1e-3  # every rank runs its own 256 frames in this time
         roof["chain_design_bytes_per_px"] = a_design
         roof["chain_GBps"] = round(px_per_step_rank * a_design / step_s / 1e9, 1)
