@@ -169,7 +169,10 @@ int agx_detect_planes(agx_detector *det, const float *luma32f, size_t stride32f_
  * clustering -> rochade_refine -> k/phi filter) for n_frames frames on the detector's
  * stream and return without waiting.  d_frames: DEVICE pointer; frame i starts at
  * d_frames + i*frame_stride_bytes.  Any row stride that covers a row is accepted (16-bit pixels
- * 2-byte aligned); rows and frames aligned to 4 bytes with width % 4 == 0 take the fast path. */
+ * 2-byte aligned); rows and frames aligned to 4 bytes with width % 4 == 0 take the fast path.
+ * HIP graphs: the call may be made while the detector's stream is being captured (after one eager
+ * batch of the same geometry, so that the workspace exists); every captured batch then clears its
+ * own counters, so a graph of any number of batches replays correctly any number of times. */
 int agx_saddles_batch_enqueue(agx_detector *det, const void *d_frames, int n_frames, int width,
                               int height, size_t row_stride_bytes, size_t frame_stride_bytes,
                               int format);
