@@ -476,4 +476,6 @@ class DetectorGroup:
         if st != _ffi.AGX_OK and (raise_on_overflow or st != _ffi.AGX_ERR_CAPACITY):
             self._check(st)
         self._keep = None
-        return [out[i, : counts[i]].copy() for i in range(n)], status
+        # a frame whose list is merely longer than cap_per_frame reports its length (status -3): fetch again with room
+        self.last_counts = counts
+        return [out[i, : counts[i]].copy() if status[i] == 0 else out[i, :0].copy() for i in range(n)], status

@@ -102,6 +102,13 @@ def test_group_reports_overflow_per_frame(oracle):
     grp.saddles_enqueue(frames)
     res, status = grp.saddles_fetch()
     assert (status == 0).all() and all(len(r) > 50 for r in res)
+    # a list that is merely longer than the caller's room reports its length, as the single-detector fetch
+    # does, so that the caller can size a retry (a frame whose device-side lists overflowed reports 0)
+    short, st_short = grp.saddles_fetch(cap_per_frame=8, raise_on_overflow=False)
+    assert (st_short == -3).all() and all(len(r) == 0 for r in short)
+    assert [int(c) for c in grp.last_counts] == [len(r) for r in res]
+    again, st_again = grp.saddles_fetch(cap_per_frame=int(grp.last_counts.max()))
+    assert (st_again == 0).all() and all(a.tobytes() == b.tobytes() for a, b in zip(again, res))
     grp.close()
 
 
