@@ -1877,7 +1877,12 @@ __global__ void __launch_bounds__(1024) k_rare(ChainArgs a, RefineConsts rc, uin
         if (frame == 0) reinterpret_cast<uint32_t *>(&a.ctr_next[a.n_frames])[threadIdx.x] = 0u;  // the output cursor's record
     }
     FrameCounters &ctr = a.ctr[frame];
-    const bool generic = frame_is_generic(a, ctr);
+    // the frame's flags, the length of its refined list and the largest k in ONE round trip (one 128-byte line)
+    uint32_t flags0 = __hip_atomic_load(&ctr.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t n_ref0 = __hip_atomic_load(&ctr.n_refined, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t maxk0 = __hip_atomic_load(&ctr.max_k_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" : "+v"(flags0), "+v"(n_ref0), "+v"(maxk0));  // (all three consumed here: no load is left behind a branch)
+    const bool generic = a.force_generic || (flags0 & FLAG_BIG_CLUSTER);
     const size_t cbase = (size_t)frame * a.cap_roots;
     const float *img = a.blur + (size_t)frame * (size_t)a.plane;
     if (generic) {
@@ -1895,10 +1900,15 @@ __global__ void __launch_bounds__(1024) k_rare(ChainArgs a, RefineConsts rc, uin
         }
         phase_barrier();
     }
+    if (generic) {  // the generic path has rewritten all three
+        flags0 = __hip_atomic_load(&ctr.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        n_ref0 = __hip_atomic_load(&ctr.n_refined, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        maxk0 = __hip_atomic_load(&ctr.max_k_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     // a frame whose seed / cluster lists overflowed is reported, not emitted (whatever was refined before the overflow is void)
-    const bool void_frame = (__hip_atomic_load(&ctr.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (FLAG_CAND_OVERFLOW | FLAG_ROOT_OVERFLOW)) != 0;
-    const uint32_t n_ref = void_frame ? 0u : __hip_atomic_load(&ctr.n_refined, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t maxk = __hip_atomic_load(&ctr.max_k_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool void_frame = (flags0 & (FLAG_CAND_OVERFLOW | FLAG_ROOT_OVERFLOW)) != 0;
+    const uint32_t n_ref = void_frame ? 0u : n_ref0;
+    const uint32_t maxk = maxk0;
     if (n_ref <= TAIL_CAP && lds_entries * 2 >= TAIL_CAP + 8) {  // the usual case (lds_entries >= 1024 always: k5_lds_bytes)
         emit_wide(a, frame, n_ref, maxk, lds_u, &s_count);  // (s_count, s_offset: two adjacent words)
         return;
