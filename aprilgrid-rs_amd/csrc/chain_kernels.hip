@@ -1501,18 +1501,19 @@ __global__ void k_debug_resp(const float *__restrict__ blur, float *__restrict__
 // ------------------------------------------------------------------------------------------
 // rochade_refine of cluster s of `frame` (detector.rs:265-359).  Appends a RefinedRec through the
 // counters given (the global per-frame counters, or a workgroup's LDS copies).
-// Core: cluster record s of the frame with first pixel `key`, cn pixels and the integer coordinate sums sx, sy.
+// Core: the cluster with first pixel `key`, cn pixels and the integer coordinate sums sx, sy; the f32 centroid
+// (detector.rs:427) comes back in cx, cy (the caller keeps it in the cluster record for agx_debug_fetch).
 template <bool VEC>
-__device__ __forceinline__ void refine_values(const ChainArgs &a, const RefineConsts &rc, int frame, size_t cbase,
-                                              const float *img, int W, int H, uint32_t s, uint32_t key, uint32_t cn, uint32_t sx,
-                                              uint32_t sy, uint32_t *n_refined, uint32_t *max_k_bits)
+__device__ __forceinline__ void refine_values(const ChainArgs &a, const RefineConsts &rc, int frame, const float *img, int W, int H,
+                                              uint32_t key, uint32_t cn, uint32_t sx, uint32_t sy, uint32_t *n_refined,
+                                              uint32_t *max_k_bits, float &cx, float &cy)
 {
     if (sx >= (1u << 24) || sy >= (1u << 24)) atomicOr(&a.ctr[frame].flags, FLAG_CENTROID_INEXACT);
     const float fn = (float)cn;
     const float initial_x = (float)sx / fn;  // detector.rs:427
     const float initial_y = (float)sy / fn;
-    a.clu_sx[cbase + s] = __float_as_uint(initial_x);  // kept for agx_debug_fetch
-    a.clu_sy[cbase + s] = __float_as_uint(initial_y);
+    cx = initial_x;
+    cy = initial_y;
     const float rxf = roundf(initial_x), ryf = roundf(initial_y);
     const int round_x = (int)rxf, round_y = (int)ryf;
     if (round_y - 4 < 0 || round_y + 4 >= H || round_x - 4 < 0 || round_x + 4 >= W) return;
@@ -1612,9 +1613,12 @@ __device__ __forceinline__ void refine_values(const ChainArgs &a, const RefineCo
     const float PI_F = 3.14159274101257324219f;
     const float phi = acosf(-c5 / k) / 2.0f / PI_F * 180.0f;
     const float theta = atan2f(c3, c4) / 2.0f / PI_F * 180.0f;
-    uint32_t o = atomicAdd(n_refined, 1u);  // o < n_clusters <= cap_roots
-    // The record is handed to another workgroup (the frame's emission tail, possibly on another
-    // CU): write-through stores (sc1) here, bypassing loads there -- no cache-wide release fence.
+    uint32_t o = atomicAdd(n_refined, 1u);
+    // o < n_clusters <= cap_roots -- unless the frame's cluster list has overflowed (the fused flood + refine kernel
+    // refines before it knows its record index): such a frame is void as a whole and nothing is stored for it
+    if (o >= a.cap_roots) return;
+    // The record is read by another launch (k_rare) or, on the generic path, by other waves of the workgroup behind an
+    // agent-scope fence: agent-scope stores.
     uint32_t *rec = reinterpret_cast<uint32_t *>(a.refined + (size_t)frame * a.cap_roots + o);
     const uint32_t f[6] = {key, __float_as_uint(rxf + x0), __float_as_uint(ryf + y0),
                            __float_as_uint(k),  __float_as_uint(theta),     __float_as_uint(phi)};
@@ -1629,8 +1633,11 @@ __device__ __forceinline__ void refine_cluster(const ChainArgs &a, const RefineC
                                                const float *img, int W, int H, uint32_t s, uint32_t *n_refined,
                                                uint32_t *max_k_bits)
 {
-    refine_values<VEC>(a, rc, frame, cbase, img, W, H, s, a.clu_key[cbase + s], a.clu_cnt[cbase + s], a.clu_sx[cbase + s],
-                       a.clu_sy[cbase + s], n_refined, max_k_bits);
+    float cx, cy;
+    refine_values<VEC>(a, rc, frame, img, W, H, a.clu_key[cbase + s], a.clu_cnt[cbase + s], a.clu_sx[cbase + s], a.clu_sy[cbase + s],
+                       n_refined, max_k_bits, cx, cy);
+    a.clu_sx[cbase + s] = __float_as_uint(cx);  // kept for agx_debug_fetch
+    a.clu_sy[cbase + s] = __float_as_uint(cy);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1690,11 +1697,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AGX_FLO
             }
         }
         if (what == FLOOD_CLUSTER) {
+            // the index of the cluster record is only needed when the record is written, behind the refinement: the
+            // atomic's round trip runs under the window loads (a frame whose cluster list overflows is void as a whole)
             const uint32_t o = atomicAdd(&ctr.n_clusters, 1u);
+            float cx, cy;
+            refine_values<VEC>(a, rc, frame, img, a.W, a.H, p, cnt, sumx, sumy, &ctr.n_refined, &ctr.max_k_bits, cx, cy);
             if (o < a.cap_roots) {
                 a.clu_key[cbase + o] = p;
                 a.clu_cnt[cbase + o] = cnt;
-                refine_values<VEC>(a, rc, frame, cbase, img, a.W, a.H, o, p, cnt, sumx, sumy, &ctr.n_refined, &ctr.max_k_bits);
+                a.clu_sx[cbase + o] = __float_as_uint(cx);  // kept for agx_debug_fetch
+                a.clu_sy[cbase + o] = __float_as_uint(cy);
             } else {
                 atomicOr(&ctr.flags, FLAG_ROOT_OVERFLOW);
             }
