@@ -322,3 +322,16 @@ def test_rccl_prototypes_group_cpp_binds_by_name():
         assert 'sym("%s")' % name in src, name
         assert re.search(r"\b%s\(" % name, stub), name
     assert "kNcclUint8 = 1" in src
+
+
+def test_stand_in_rccl_builds_and_exports_the_bound_symbols(tmp_path):
+    """tests/stub_rccl compiles here (host code only) and exports every entry point group.cpp binds."""
+    import subprocess
+    so = str(tmp_path / "librccl_stub.so")
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "-O2", "-fPIC", "-shared", "-o", so, os.path.join(ROOT, "tests", "stub_rccl", "stub_rccl.cpp")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    nm = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True).stdout
+    for name in ("ncclCommInitAll", "ncclCommDestroy", "ncclGroupStart", "ncclGroupEnd", "ncclSend", "ncclRecv", "ncclGetErrorString",
+                 "stub_rccl_stats"):
+        assert re.search(r"\bT %s\b" % name, nm), name
