@@ -1159,11 +1159,12 @@ __device__ __forceinline__ uint32_t bitpos_sum(uint32_t c)
 #ifndef AGX_FLOOD_WPE
 #define AGX_FLOOD_WPE 4  // waves per SIMD the fused flood + refine kernel is compiled for
 #endif
-// First-tier flood window: FLOOD_COLS columns [sx - FLOOD_SEED_COL, ...] x 32 rows [sy - 1, sy + 30].  Both column arrays
+// First-tier flood window: FLOOD_COLS columns [x0, x0 + FLOOD_COLS), x0 = (sx - FLOOD_SEED_LO) rounded down to 4, x 32 rows [sy - 1, sy + 30].  Both column arrays
 // of the window live in registers (32 columns: 4 waves per SIMD; narrower windows were measured -- 24 columns run at 5
 // waves per SIMD but send three times as many seeds to the second tier, and the launch got slower).
 constexpr int FLOOD_COLS = AGX_FLOOD_COLS;
-constexpr int FLOOD_SEED_COL = FLOOD_COLS / 2;
+constexpr int FLOOD_SEED_LO = FLOOD_COLS / 2 - 2;  // the seed sits in window column FLOOD_SEED_LO .. FLOOD_SEED_LO + 3 (aligned window)
+static_assert(FLOOD_COLS % 4 == 0 && MASK_PAD_X % 4 == 0 && MASK_PAD_X >= FLOOD_COLS, "the flood window is fetched as aligned quads");
 
 // Second tier, wave-wide: lane t holds columns sx-64+2t and sx-63+2t of a 128-column x 64-row
 // window [sy-1, sy+62] as two 64-bit words (bit = row); each round ORs the neighbouring columns
@@ -1251,30 +1252,84 @@ __device__ __forceinline__ int wave_flood_128x64(const ChainArgs &a, uint32_t *f
     return FLOOD_CLUSTER;
 }
 
+// debug_ablation & 16384: where the waves of k_flood_refine spend their time -- 10 ns ticks of s_memrealtime per
+// phase, summed over the working waves of a frame into the frame's stats[8..] (tools/flood_phases.py).
+// (A second instantiation of the kernel: the clock's registers would cost the product kernel scratch.)
+struct NoClock {
+    static constexpr bool on = false;
+    __device__ __forceinline__ void start(uint32_t *) {}
+    __device__ __forceinline__ void mark(int) {}
+    __device__ __forceinline__ void join() {}
+};
+struct PhaseClock {
+    static constexpr bool on = true;
+    uint32_t *stats;
+    unsigned long long t;
+    __device__ __forceinline__ void start(uint32_t *st)
+    {
+        stats = st;
+        t = wall_clock64();
+    }
+    __device__ __forceinline__ void mark(int which)  // the first active lane records; every active lane moves on
+    {
+        {
+            const unsigned long long now = wall_clock64();
+            const unsigned long long act = __ballot(true);
+            if ((int)(threadIdx.x & 63) == __ffsll((long long)act) - 1) atomicAdd(&stats[which], (uint32_t)(now - t));
+            t = now;
+        }
+    }
+    __device__ __forceinline__ void join()  // after a divergent stretch: everyone continues from the latest mark
+    {
+        {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const unsigned long long o = ((unsigned long long)__shfl_xor((uint32_t)(t >> 32), off, 64) << 32) | __shfl_xor((uint32_t)t, off, 64);
+                t = o > t ? o : t;
+            }
+        }
+    }
+};
+
 // First flood tier for one seed (one lane): 32 x 32 window.  Returns FLOOD_CLUSTER with the component's exact
 // integer sums if the seed is the canonical one and the component stays inside the window, FLOOD_BIG if the
 // component may continue outside (second tier), FLOOD_NONE if the seed is not the component's first pixel.
+template <typename CLK>
 __device__ __forceinline__ int flood_lane(const ChainArgs &a, const uint32_t *mask, uint32_t W, uint32_t p, uint32_t &cnt_out,
-                                          uint32_t &sumx_out, uint32_t &sumy_out)
+                                          uint32_t &sumx_out, uint32_t &sumy_out, CLK &clk)
 {
     const uint32_t sx = p % W, sy = p / W;
     const int sh = (int)((sy - 1u) & 31u);
-    const uint32_t *wp = mask + (size_t)((sy - 1u) >> 5) * a.mask_wpr + MASK_PAD_X + ((int)sx - FLOOD_SEED_COL);
+    // The window starts at a multiple of four columns, FLOOD_SEED_LO .. FLOOD_SEED_LO + 3 columns left of the seed: its
+    // two word rows are 2 x FLOOD_COLS / 4 aligned 16-byte loads (64 one-word loads of 64 different lines each kept
+    // the CU's L1 busy for most of the launch: the tag look-ups of divergent loads, not the memory behind them).
+    const int x0 = ((int)sx - FLOOD_SEED_LO) & ~3;  // (two's complement: rounds down below zero too; the mask has MASK_PAD_X zero columns)
+    const int sc = (int)sx - x0;                    // the seed's window column, FLOOD_SEED_LO .. FLOOD_SEED_LO + 3
+    const uint4 *wq = reinterpret_cast<const uint4 *>(mask + (size_t)((sy - 1u) >> 5) * a.mask_wpr + MASK_PAD_X + x0);
+    const uint4 *wq1 = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint32_t *>(wq) + a.mask_wpr);
     uint32_t cand[FLOOD_COLS], comp[FLOOD_COLS];
     // both word rows of the window in flight together (comp[] holds the second one until the two are combined)
 #pragma unroll
-    for (int c = 0; c < FLOOD_COLS; ++c) cand[c] = wp[c];
+    for (int q = 0; q < FLOOD_COLS / 4; ++q) {
+        const uint4 v = wq[q];
+        cand[4 * q] = v.x; cand[4 * q + 1] = v.y; cand[4 * q + 2] = v.z; cand[4 * q + 3] = v.w;
+    }
 #pragma unroll
-    for (int c = 0; c < FLOOD_COLS; ++c) comp[c] = wp[a.mask_wpr + c];
+    for (int q = 0; q < FLOOD_COLS / 4; ++q) {
+        const uint4 v = wq1[q];
+        comp[4 * q] = v.x; comp[4 * q + 1] = v.y; comp[4 * q + 2] = v.z; comp[4 * q + 3] = v.w;
+    }
 #pragma unroll
     for (int c = 0; c < FLOOD_COLS; ++c) asm volatile("" : "+v"(cand[c]), "+v"(comp[c]));  // (consumed here, all 2 x FLOOD_COLS words)
+    clk.mark(9);  // the window's words have arrived
 #pragma unroll
     for (int c = 0; c < FLOOD_COLS; ++c) {
         const unsigned long long two = (unsigned long long)cand[c] | ((unsigned long long)comp[c] << 32);
-        cand[c] = (uint32_t)(two >> sh);  // bit r = row sy-1+r of column sx-16+c
+        cand[c] = (uint32_t)(two >> sh);  // bit r = row sy-1+r of column x0+c
         comp[c] = 0u;
     }
-    comp[FLOOD_SEED_COL] = 2u;  // the seed: column sx, row sy
+#pragma unroll
+    for (int c = FLOOD_SEED_LO; c < FLOOD_SEED_LO + 4; ++c) comp[c] = sc == c ? 2u : 0u;  // the seed: column sx, row sy
     // One left-to-right and one right-to-left sweep, then the fixed-point test.  After a sweep every
     // comp[c] is a union of whole vertical runs of cand[c], so the update rule would change column c
     // exactly if a neighbouring column holds a component pixel next to a candidate of c that is not
@@ -1309,7 +1364,8 @@ __device__ __forceinline__ int flood_lane(const ChainArgs &a, const uint32_t *ma
 #pragma unroll
     for (int c = 0; c < FLOOD_COLS; ++c) {
         all |= comp[c];
-        if (c < FLOOD_SEED_COL) left_of_seed |= comp[c];
+        if (c < FLOOD_SEED_LO) left_of_seed |= comp[c];
+        else if (c < FLOOD_SEED_LO + 3) left_of_seed |= c < sc ? comp[c] : 0u;
     }
     // a pixel of the component precedes the seed in raster order -> not the canonical seed
     const bool canonical = !((all & 1u) || (left_of_seed & 2u));
@@ -1326,8 +1382,8 @@ __device__ __forceinline__ int flood_lane(const ChainArgs &a, const uint32_t *ma
                 sumy += bitpos_sum(w);
                 sumx += nc * (uint32_t)c;
             }
-            sumx += cnt * (sx - (uint32_t)FLOOD_SEED_COL);  // window column 0 is image column sx - FLOOD_SEED_COL (mod 2^32 arithmetic)
-            sumy += cnt * (sy - 1u);   // window row 0 is image row sy-1
+            sumx += cnt * (uint32_t)x0;  // window column 0 is image column x0 (mod 2^32 arithmetic)
+            sumy += cnt * (sy - 1u);     // window row 0 is image row sy-1
             cnt_out = cnt;
             sumx_out = sumx;
             sumy_out = sumy;
@@ -1503,10 +1559,10 @@ __global__ void k_debug_resp(const float *__restrict__ blur, float *__restrict__
 // counters given (the global per-frame counters, or a workgroup's LDS copies).
 // Core: the cluster with first pixel `key`, cn pixels and the integer coordinate sums sx, sy; the f32 centroid
 // (detector.rs:427) comes back in cx, cy (the caller keeps it in the cluster record for agx_debug_fetch).
-template <bool VEC>
+template <bool VEC, typename CLK>
 __device__ __forceinline__ void refine_values(const ChainArgs &a, const RefineConsts &rc, int frame, const float *img, int W, int H,
                                               uint32_t key, uint32_t cn, uint32_t sx, uint32_t sy, uint32_t *n_refined,
-                                              uint32_t *max_k_bits, float &cx, float &cy)
+                                              uint32_t *max_k_bits, float &cx, float &cy, CLK &clk)
 {
     if (sx >= (1u << 24) || sy >= (1u << 24)) atomicOr(&a.ctr[frame].flags, FLAG_CENTROID_INEXACT);
     const float fn = (float)cn;
@@ -1547,9 +1603,20 @@ __device__ __forceinline__ void refine_values(const ChainArgs &a, const RefineCo
         asm volatile("" ::: "memory");  // every load of the batch is issued before the first one is waited for
     };
     fetch(0, 5);
+    if (CLK::on) {  // (the timed instantiation only: the wait is normally row by row)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        clk.mark(11);  // rows 0..4 of the window have arrived
+    }
 #pragma unroll
     for (int wr = 0; wr < 9; ++wr) {
-        if (wr == 5) fetch(5, 4);
+        if (wr == 5) {
+            clk.mark(12);  // arithmetic of rows 0..4
+            fetch(5, 4);
+            if (CLK::on) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                clk.mark(13);  // rows 5..8 have arrived
+            }
+        }
         float v[9];
         const int k = wr < 5 ? wr : wr - 5;
         if (VEC) {
@@ -1583,6 +1650,10 @@ __device__ __forceinline__ void refine_values(const ChainArgs &a, const RefineCo
                 for (int j = 0; j < 6; ++j) prm[j] = prm[j] + rc.pmat[(r * 5 + c) * 6 + j] * conv[r * 5 + c];
         }
     }
+    if (CLK::on) {
+        asm volatile("" : "+v"(prm[0]), "+v"(prm[1]), "+v"(prm[2]), "+v"(prm[3]), "+v"(prm[4]), "+v"(prm[5]));
+        clk.mark(16);  // arithmetic of rows 5..8
+    }
     const float a1 = prm[0], a2 = prm[1], a3 = prm[2], a4 = prm[3], a5 = prm[4];
     const float fxx = 2.0f * a1, fyy = 2.0f * a3, fxy = a2;
     const float d = fxx * fyy - fxy * fxy;
@@ -1613,7 +1684,16 @@ __device__ __forceinline__ void refine_values(const ChainArgs &a, const RefineCo
     const float PI_F = 3.14159274101257324219f;
     const float phi = acosf(-c5 / k) / 2.0f / PI_F * 180.0f;
     const float theta = atan2f(c3, c4) / 2.0f / PI_F * 180.0f;
+    if (CLK::on) {
+        float th = theta, ph = phi;
+        asm volatile("" : "+v"(th), "+v"(ph));
+        clk.mark(17);  // the fit: divisions, sqrt, acos, atan2 (lanes that pass)
+    }
     uint32_t o = atomicAdd(n_refined, 1u);
+    if (CLK::on) {
+        asm volatile("" : "+v"(o));
+        clk.mark(15);  // the record's index (atomic round trip)
+    }
     // o < n_clusters <= cap_roots -- unless the frame's cluster list has overflowed (the fused flood + refine kernel
     // refines before it knows its record index): such a frame is void as a whole and nothing is stored for it
     if (o >= a.cap_roots) return;
@@ -1634,8 +1714,9 @@ __device__ __forceinline__ void refine_cluster(const ChainArgs &a, const RefineC
                                                uint32_t *max_k_bits)
 {
     float cx, cy;
+    NoClock clk;
     refine_values<VEC>(a, rc, frame, img, W, H, a.clu_key[cbase + s], a.clu_cnt[cbase + s], a.clu_sx[cbase + s], a.clu_sy[cbase + s],
-                       n_refined, max_k_bits, cx, cy);
+                       n_refined, max_k_bits, cx, cy, clk);
     a.clu_sx[cbase + s] = __float_as_uint(cx);  // kept for agx_debug_fetch
     a.clu_sy[cbase + s] = __float_as_uint(cy);
 }
@@ -1649,7 +1730,7 @@ __device__ __forceinline__ void refine_cluster(const ChainArgs &a, const RefineC
 // run under the window reads of the others.)  Seeds whose component may leave the window go to the frame's
 // second-tier list, which k_rare's workgroup floods wave-wide.
 // ------------------------------------------------------------------------------------------
-template <bool VEC>
+template <bool VEC, typename CLK>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AGX_FLOOD_WPE, 8))) k_flood_refine(ChainArgs a, RefineConsts rc)
 {
     const WaveTimer wt(a, K_FLOOD_REFINE);
@@ -1661,6 +1742,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AGX_FLO
     const int lane = threadIdx.x;
     // the frame's flags and seed count and this lane's first seed in ONE round trip (the seed is fetched before the
     // count is known: any index below cap_roots is inside the list)
+    CLK clk;
+    clk.start(ctr.stats);
     uint32_t flags0 = ctr.flags, n_seeds0 = ctr.n_seeds;
     const uint32_t i0 = fs.slot * 64u + (uint32_t)lane;
     uint32_t p0 = i0 < a.cap_roots ? a.seeds[cbase + i0] : 0u;
@@ -1674,10 +1757,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AGX_FLO
         const uint32_t i = base + (uint32_t)lane;
         uint32_t p = 0u, cnt = 0, sumx = 0, sumy = 0;
         int what = FLOOD_NONE;
+        if (CLK::on && lane == 0) atomicAdd(&ctr.stats[19], 1u);  // chunks
+        clk.mark(8);  // counters + first seed (or the loop's turn-around)
         if (i < n) {
             p = base == fs.slot * 64u ? p0 : a.seeds[cbase + i];
-            what = flood_lane(a, mask, W, p, cnt, sumx, sumy);
+            what = flood_lane(a, mask, W, p, cnt, sumx, sumy, clk);
         }
+        clk.join();
+        clk.mark(10);  // the flood's sweeps
         // Second tier: components that may leave the lane's window (about 1 % of the seeds on real frames) are
         // flooded again by the whole wave in a 128 x 64 window, one after the other; the lane that owns the seed
         // takes the result and refines the cluster together with everyone else below.  (A component that leaves
@@ -1696,12 +1783,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AGX_FLO
                 sumy = y2;
             }
         }
+        clk.mark(14);  // second tier
+        if (CLK::on) {
+            const unsigned long long act = __ballot(what == FLOOD_CLUSTER);
+            if (lane == 0) atomicAdd(&ctr.stats[18], (uint32_t)__popcll(act));  // clusters refined
+        }
         if (what == FLOOD_CLUSTER) {
             // the index of the cluster record is only needed when the record is written, behind the refinement: the
             // atomic's round trip runs under the window loads (a frame whose cluster list overflows is void as a whole)
             const uint32_t o = atomicAdd(&ctr.n_clusters, 1u);
             float cx, cy;
-            refine_values<VEC>(a, rc, frame, img, a.W, a.H, p, cnt, sumx, sumy, &ctr.n_refined, &ctr.max_k_bits, cx, cy);
+            refine_values<VEC>(a, rc, frame, img, a.W, a.H, p, cnt, sumx, sumy, &ctr.n_refined, &ctr.max_k_bits, cx, cy, clk);
             if (o < a.cap_roots) {
                 a.clu_key[cbase + o] = p;
                 a.clu_cnt[cbase + o] = cnt;
@@ -1711,6 +1803,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AGX_FLO
                 atomicOr(&ctr.flags, FLAG_ROOT_OVERFLOW);
             }
         }
+        clk.join();
+        clk.mark(7);  // record stores, lanes without a record
     }
 }
 
@@ -2036,8 +2130,14 @@ int launch_kernel(int which, const ChainArgs &a, const RefineConsts &rc, void *s
     }
     case K_FLOOD_REFINE: {
         dim3 grid((unsigned)sparse_grid_x(a, 48, "AGX_G_FLOOD") * (unsigned)a.n_frames), block(64);  // slot-major, see frame_slot
-        if ((a.W & 3) == 0) hipLaunchKernelGGL(k_flood_refine<true>, grid, block, 0, st, a, rc);
-        else hipLaunchKernelGGL(k_flood_refine<false>, grid, block, 0, st, a, rc);
+        if (a.dbg & 16384) {  // phase timeline (tools/flood_phases.py)
+            if ((a.W & 3) == 0) hipLaunchKernelGGL((k_flood_refine<true, PhaseClock>), grid, block, 0, st, a, rc);
+            else hipLaunchKernelGGL((k_flood_refine<false, PhaseClock>), grid, block, 0, st, a, rc);
+        } else if ((a.W & 3) == 0) {
+            hipLaunchKernelGGL((k_flood_refine<true, NoClock>), grid, block, 0, st, a, rc);
+        } else {
+            hipLaunchKernelGGL((k_flood_refine<false, NoClock>), grid, block, 0, st, a, rc);
+        }
         return hipGetLastError();
     }
     case K_RARE: {

@@ -35,6 +35,8 @@ for k, name in ((1, "k_verify_seeds"), (2, "k_flood_refine"), (3, "k_rare_emit")
     span = end.max()
     print("%s: %d waves, span %.1f us, last start at %.1f us, lifetimes us: median %.2f  p90 %.2f  p99 %.2f  max %.2f, sum %.0f us (= %.0f resident waves on average)"
           % (name, n, span, start.max(), np.median(dur), np.percentile(dur, 90), np.percentile(dur, 99), dur.max(), dur.sum(), dur.sum() / span))
+    hist_edges = [0, 1, 2, 4, 6, 8, 12, 16, 24, 32, 48, 64, 1e9]
+    print("   lifetime histogram (us):", ", ".join("<%g: %d" % (b, int(((dur >= a) & (dur < b)).sum())) for a, b in zip(hist_edges[:-1], hist_edges[1:])))
     edges = np.linspace(0, span, 11)
     occ = [int(((start < b) & (end > a)).sum()) for a, b in zip(edges[:-1], edges[1:])]
     print("   waves alive in each tenth of the span:", occ)
