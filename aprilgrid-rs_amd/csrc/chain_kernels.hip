@@ -301,8 +301,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((A4 &&
             // nearly final value from their first row on (a wave that starts with nothing known admits
             // every noise-level negative response of its first rows, all of which K2 has to re-test).
             const int per_seg = a.n_strips * a.n_frames;
-            seg = u / per_seg;
-            const int r = u - seg * per_seg;
+            const int k = u / per_seg;
+            const int r = u - k * per_seg;
+            // ... and the segments from the middle of the frame outwards (3, 4, 2, 5, 1, 6, 0 for seven): the waves
+            // of the first round all start with nothing known, and the rows most likely to show a strong corner
+            // early -- whose minima then tighten everyone's threshold -- are not the frame's top rows
+            const int mid = (n_full - 1) >> 1, dist = (k + 1) >> 1;
+            seg = (a.dbg & 32768) ? k : ((k & 1) ? mid + dist : mid - dist);  // (32768: A/B, ascending)
             frame = r / a.n_strips;
             strip = r - frame * a.n_strips;
         }
