@@ -226,6 +226,32 @@ def test_batch_matches_oracle_and_is_deterministic(det, oracle):
             assert np.min(np.hypot(*(g - p).T)) < 0.5
 
 
+@pytest.mark.parametrize("bits", [16384, 32768, 4096, 8192])
+def test_diagnostic_instantiations_do_not_change_results(det, bits):
+    """debug_ablation 16384 runs the flood + refine kernel's second instantiation (phase clock), 32768 K1's ascending
+    segment order (the A/B of the middle-outwards dispatch), 4096 / 8192 the wave and phase timers: the superset K1
+    leaves depends on the order in which its waves learn the frame's minimum, the results must not."""
+    import aprilgrid_rs_amd as A
+    synth = synth_module()
+    frames, _ = synth.render_batch(40, 5, 1280, 800, device="cuda")
+    det.saddles_batch_enqueue(frames)
+    res, status = det.saddles_batch_fetch()
+    assert (status == 0).all()
+    d2 = A.TagDetector(A.TagFamily.T36H11, None, device=0)
+    try:
+        d2.set_option("debug_ablation", bits)
+        d2.saddles_batch_enqueue(frames)
+        res2, status2 = d2.saddles_batch_fetch()
+        assert (status2 == 0).all()
+        for a, b in zip(res, res2):
+            assert a.tobytes() == b.tobytes()
+        if bits == 16384:  # the clock has run: chunks counted, time recorded in every phase of a working wave
+            st = d2.debug_fetch(0, "verify_stats").astype(np.int64)
+            assert st[19] > 0 and st[18] > 0 and all(st[k] > 0 for k in (8, 9, 10, 11, 13, 16, 7))
+    finally:
+        d2.close()
+
+
 @pytest.mark.parametrize("depth", [1, 2, 3])
 def test_chain_pipeline_batches_in_flight(det, oracle, depth):
     """Several batches in flight on separate streams (sharding.ChainPipeline): every batch's
