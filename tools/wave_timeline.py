@@ -23,12 +23,14 @@ for _ in range(4):
 det.sync()
 TICK_US = 0.01  # s_memrealtime: 100 MHz
 grids = {1: int(os.environ.get("AGX_G_VERIFY", "0")) or None, 2: None, 3: None}
+bounds = {}
 for k, name in ((1, "k_verify_seeds"), (2, "k_flood_refine"), (3, "k_rare_emit")):
     t = det.debug_fetch(k, "wave_times", 1 << 20).astype(np.int64)
     live = t[:, 1] > 0
     n = int(np.nonzero(live)[0].max()) + 1 if live.any() else 0
     t = t[:n]
     t0 = t[:, 0].min()
+    bounds[k] = (int(t[:, 0].min()), int(t[:, 1].max()))
     start = (t[:, 0] - t0) * TICK_US
     end = (t[:, 1] - t0) * TICK_US
     dur = end - start
@@ -51,3 +53,5 @@ for k, name in ((1, "k_verify_seeds"), (2, "k_flood_refine"), (3, "k_rare_emit")
     print("   longest:", ", ".join("slot %d frame %d: %.1f us from %.1f" % (ident(i) + (dur[i], start[i])) for i in order))
     late = np.argsort(-end)[:5]
     print("   last to end:", ", ".join("slot %d frame %d: started %.1f ran %.1f" % (ident(i) + (start[i], dur[i])) for i in late))
+# between the launches: the last wave of one kernel ends -> the first wave of the next starts (same clock)
+print("gaps: verify -> flood_refine %.2f us, flood_refine -> rare %.2f us" % ((bounds[2][0] - bounds[1][1]) * TICK_US, (bounds[3][0] - bounds[2][1]) * TICK_US))
