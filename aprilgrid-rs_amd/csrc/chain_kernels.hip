@@ -254,7 +254,11 @@ __device__ __forceinline__ int H_full_segs(const ChainArgs &a) { return a.H / a.
 // RESP: debug instantiation (agx_detector_set_option "store_response") that also stores the
 // determinant this kernel evaluates in registers, for the parity tests (AGX_DBG_RESP).
 #ifndef AGX_BLUR_STORE_AUX
-#define AGX_BLUR_STORE_AUX 0  // cache policy bits of the blur plane's buffer stores (A/B builds: -DAGX_BLUR_STORE_AUX=2 = nt)
+#define AGX_BLUR_STORE_AUX 2  // cache policy bits of the blur plane's buffer stores: 2 = nt (the plane is written once and read
+// sparsely two launches later; kept out of the caches' way, the sparse kernels' misses do not have to evict it first)
+#endif
+#ifndef AGX_IN_LOAD_AUX
+#define AGX_IN_LOAD_AUX 0  // cache policy bits of the frame's buffer loads
 #endif
 template <int FMT, bool A4, bool RESP = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((A4 && !RESP && AGX_K1_WPE) ? ((FMT == 0 || FMT == 1) ? 5 : 4) : 1, 8))) k_blur_hessian(ChainArgs a)
@@ -438,22 +442,22 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((A4 &&
         const int rr = r < 0 ? 0 : (r > H - 1 ? H - 1 : r);
         if (FMT == 3) {
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_in, cc * 4, rr * a.row_stride, 0);
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_in, cc * 4, rr * a.row_stride, AGX_IN_LOAD_AUX);
             dst[0] = v.x;
             dst[RW > 1 ? 1 : 0] = v.y;
             dst[RW > 2 ? 2 : 0] = v.z;
             dst[RW > 3 ? 3 : 0] = v.w;
         } else if (FMT == 2) {
-            const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(rs_in, cc * 3, rr * a.row_stride, 0);
+            const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(rs_in, cc * 3, rr * a.row_stride, AGX_IN_LOAD_AUX);
             dst[0] = v.x;
             dst[RW > 1 ? 1 : 0] = v.y;
             dst[RW > 2 ? 2 : 0] = v.z;
         } else if (FMT == 1) {
-            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs_in, cc * 2, rr * a.row_stride, 0);
+            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs_in, cc * 2, rr * a.row_stride, AGX_IN_LOAD_AUX);
             dst[0] = v.x;
             dst[RW > 1 ? 1 : 0] = v.y;
         } else {
-            dst[0] = __builtin_amdgcn_raw_buffer_load_b32(rs_in, cc, rr * a.row_stride, 0);
+            dst[0] = __builtin_amdgcn_raw_buffer_load_b32(rs_in, cc, rr * a.row_stride, AGX_IN_LOAD_AUX);
         }
     };
     // L16 edge lanes: 16-bit selectors of v_perm_b32 over (dword1:dword0) -- identity, or the first /
@@ -586,7 +590,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((A4 &&
                     float *dst = (b >= ys && b < ye) ? blur_f + (size_t)((a.dbg & 8) ? (b & 7) : b) * W + c0 : a.dummy + c0;
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        if (c0 + j < W) dst[j] = bc[j];
+                        if (c0 + j < W) __builtin_nontemporal_store(bc[j], &dst[j]);
                 }
             }
             // Hessian determinant of row y = b-1 (rows b-2, b-1, b), image_util.rs:88-106
