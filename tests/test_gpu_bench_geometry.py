@@ -1,9 +1,9 @@
 """GPU parity on the geometry bench.py times (VERDICT r1 "parity-test what you benchmark").
 
 The blur kernel's tiling depends on the batch: agx::plan_k1 picks the rows one wave walks
-(32 .. 128) from the number of frames, so a small batch of 1280x800 frames runs 32-row segments
-while the 256-frame bench batch runs 128-row segments (6 full + 1 short per strip, dispatched
-"full segments first, short ones last").  These tests compare the HIP chain with the oracle on
+(32 .. 96) from the number of frames, so a small batch of 1280x800 frames runs 32-row segments
+while the 256-frame bench batch runs 96-row segments (8 full + 1 short per strip, dispatched
+"full segments first -- from the middle of the frame outwards --, short ones last").  These tests compare the HIP chain with the oracle on
 exactly those paths: the bench's own 256-frame batch, a sweep of forced segment heights on
 heights that are / are not multiples of the segment and of the 32-row mask words, 3840x2160,
 and RGB8 / L16 at 1280x800.  Every test also reads the response the blur kernel evaluated in its
@@ -59,14 +59,14 @@ def run_batch(d, frames, rows=0):
 
 def test_bench_batch_256_frames_every_frame(det, det_resp, oracle):
     """BASELINE configs[1] exactly as bench.py builds it (256 distinct 1280x800 L8 frames, automatic
-    tiling = 128-row segments): every frame's saddle list against the oracle, all intermediate
+    tiling = 96-row segments): every frame's saddle list against the oracle, all intermediate
     products for four frames at different batch positions."""
     import torch
     import bench
     frames, uniq = bench.make_workload(0, 256, 1280, 800, "L8", 0, False, torch.device("cuda", 0))
     assert uniq == 256 and tuple(frames.shape) == (256, 800, 1280)
     res = run_batch(det, frames)
-    assert det.get_option("k1_rows_per_segment") == 128 and det.get_option("k1_segments") == 7
+    assert det.get_option("k1_rows_per_segment") == 96 and det.get_option("k1_segments") == 9
     host = host_frames(frames, "L8")
     refs = oracle_saddles_parallel(oracle, host, threads=16)
     for i in range(256):
@@ -75,7 +75,7 @@ def test_bench_batch_256_frames_every_frame(det, det_resp, oracle):
         check_frame(det, oracle, host[i], i, "bench frame %d" % i)
     # the blur kernel's own response, same batch geometry
     res2 = run_batch(det_resp, frames)
-    assert det_resp.get_option("k1_rows_per_segment") == 128
+    assert det_resp.get_option("k1_rows_per_segment") == 96
     for i in (1, 254):
         check_frame(det_resp, oracle, host[i], i, "bench frame %d (stored response)" % i)
     for a, b in zip(res, res2):
@@ -98,10 +98,10 @@ def test_segment_height_sweep(det_resp, oracle, rows, height):
     det_resp.set_option("k1_rows_per_segment", 0)
 
 
-@pytest.mark.parametrize("rows", [0, 128])
+@pytest.mark.parametrize("rows", [0, 96, 128])
 def test_4k_frames(det, det_resp, oracle, rows):
-    """BASELINE configs[3]: 3840x2160 (16 strips; 2160 is not a multiple of 32).  rows = 128 is the
-    tiling the 32-frame bench batch gets; 0 = what a 2-frame batch gets by itself."""
+    """BASELINE configs[3]: 3840x2160 (16 strips; 2160 is not a multiple of 32).  rows = 96 is the
+    tiling the 32-frame bench batch gets (128 until round 3); 0 = what a 2-frame batch gets by itself."""
     synth = synth_module()
     frames, _ = synth.render_batch(900, 2, 3840, 2160, device="cuda")
     host = host_frames(frames, "L8")
@@ -119,7 +119,7 @@ def test_4k_frames(det, det_resp, oracle, rows):
 @pytest.mark.parametrize("fmt", ["RGB8", "L16"])
 def test_other_formats_full_size(det, det_resp, oracle, fmt):
     """BASELINE configs[4] (RGB8, kornia front-end layout) and L16 at 1280x800: a 64-frame batch with
-    automatic tiling, and the 128-row tiling of the 256-frame bench batch forced on 8 frames."""
+    automatic tiling, and the 96-row tiling of the 256-frame bench batch forced on 8 frames."""
     synth = synth_module()
     frames, _ = synth.render_batch(2000, 64, 1280, 800, device="cuda", fmt=fmt)
     host = host_frames(frames, fmt)
@@ -130,12 +130,12 @@ def test_other_formats_full_size(det, det_resp, oracle, fmt):
     for i in (0, 63):
         check_frame(det, oracle, host[i], i, "%s frame %d" % (fmt, i))
     sub = frames[:8].contiguous()
-    res = run_batch(det_resp, sub, 128)
-    assert det_resp.get_option("k1_rows_per_segment") == 128
+    res = run_batch(det_resp, sub, 96)
+    assert det_resp.get_option("k1_rows_per_segment") == 96
     for i in range(8):
-        check_saddles(res[i], refs[i], "%s frame %d rows 128" % (fmt, i))
+        check_saddles(res[i], refs[i], "%s frame %d rows 96" % (fmt, i))
     for i in (0, 7):
-        check_frame(det_resp, oracle, host[i], i, "%s frame %d rows 128" % (fmt, i))
+        check_frame(det_resp, oracle, host[i], i, "%s frame %d rows 96" % (fmt, i))
     det_resp.set_option("k1_rows_per_segment", 0)
 
 
