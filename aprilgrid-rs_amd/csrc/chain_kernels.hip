@@ -2141,7 +2141,10 @@ int launch_kernel(int which, const ChainArgs &a, const RefineConsts &rc, void *s
         return hipGetLastError();
     }
     case K_FLOOD_REFINE: {
-        dim3 grid((unsigned)sparse_grid_x(a, 48, "AGX_G_FLOOD") * (unsigned)a.n_frames), block(64);  // slot-major, see frame_slot
+        // 16 workgroups per frame at 256 frames = the chip's 4 096 wave slots at 128 registers: a frame's waves loop over its
+        // chunks of 64 seeds (17 on the bench's frames) instead of 48 workgroups per frame of which 31 find nothing to do
+        // (72 -> 68 us, tools/env_sweep.py)
+        dim3 grid((unsigned)sparse_grid_x(a, 16, "AGX_G_FLOOD") * (unsigned)a.n_frames), block(64);  // slot-major, see frame_slot
         if (a.dbg & 16384) {  // phase timeline (tools/flood_phases.py)
             if ((a.W & 3) == 0) hipLaunchKernelGGL((k_flood_refine<true, PhaseClock>), grid, block, 0, st, a, rc);
             else hipLaunchKernelGGL((k_flood_refine<false, PhaseClock>), grid, block, 0, st, a, rc);
