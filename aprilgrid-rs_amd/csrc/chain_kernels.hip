@@ -124,6 +124,9 @@ __device__ __forceinline__ int lane_id_here()
 // Measured (round 3, 256 x 1280x800, 8 alternating runs per build on one box): K2's re-tests 5 760 -> 2 870 per
 // frame, K2 64 -> 61 us -- but K1 300 -> 307 us (29 KB of LDS per workgroup and the extra branches in the row
 // loop), a net loss; the parity suite passes with it on.
+#ifndef AGX_K1_WPE_MAX
+#define AGX_K1_WPE_MAX 8  // A/B builds: -DAGX_K1_WPE_MAX=4 holds K1 at four waves per SIMD
+#endif
 #ifndef AGX_K1_WPE
 #define AGX_K1_WPE 1  // A/B builds: -DAGX_K1_WPE=0 leaves the register budget of K1 to the compiler
 #endif
@@ -261,7 +264,7 @@ __device__ __forceinline__ int H_full_segs(const ChainArgs &a) { return a.H / a.
 #define AGX_IN_LOAD_AUX 0  // cache policy bits of the frame's buffer loads
 #endif
 template <int FMT, bool A4, bool RESP = false>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((A4 && !RESP && AGX_K1_WPE) ? ((FMT == 0 || FMT == 1) ? 5 : 4) : 1, 8))) k_blur_hessian(ChainArgs a)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((A4 && !RESP && AGX_K1_WPE) ? ((FMT == 0 || FMT == 1) ? (AGX_K1_WPE_MAX < 5 ? AGX_K1_WPE_MAX : 5) : 4) : 1, AGX_K1_WPE_MAX))) k_blur_hessian(ChainArgs a)
 {
     const int lane = threadIdx.x & 63;
     // u8 -> the pixel's four distinct tap products of the horizontal pass: entry v holds
