@@ -41,7 +41,7 @@ struct FrameCounters {
     uint32_t n_roots;      // generic path: union-find roots
     uint32_t n_big;        // seeds handed to the wave-wide second flood tier
     uint32_t refine_done;  // (unused since the emission moved into k_rare)
-    uint32_t n_clusters2;  // cluster records the second flood tier (k_rare) appends behind them
+    uint32_t n_clusters2;  // (unused since the second flood tier runs inside k_flood_refine; always 0)
     uint32_t stats[20];    // debug_ablation & 128: verify statistics by word row within a 128-row segment
 };
 static_assert(sizeof(FrameCounters) == 256, "FrameCounters is cleared as 64 dwords");

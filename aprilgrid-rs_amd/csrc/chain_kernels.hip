@@ -1739,8 +1739,8 @@ __device__ __forceinline__ void refine_cluster(const ChainArgs &a, const RefineC
 // component's cluster record and its rochade_refine right behind it, from the sums still in registers.
 // (Two launches until round 3: the flood, bound by its slowest waves with a quarter of the wave slots in use,
 // and the refinement, bound by the random sector reads of the 9 x 9 windows; fused, the floods of some waves
-// run under the window reads of the others.)  Seeds whose component may leave the window go to the frame's
-// second-tier list, which k_rare's workgroup floods wave-wide.
+// run under the window reads of the others.)  Seeds whose component may leave the window are flooded again by
+// the whole wave (128 x 64 window) before the refinement; what leaves that window too sends the frame to k_rare.
 // ------------------------------------------------------------------------------------------
 template <bool VEC, typename CLK>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AGX_FLOOD_WPE, 8))) k_flood_refine(ChainArgs a, RefineConsts rc)
