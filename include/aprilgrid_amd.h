@@ -127,7 +127,11 @@ int agx_detector_set_limits(agx_detector *det, uint32_t max_candidates, uint32_t
  *                          detector.rs:611-625, in waves of n, merged in the reference's order: same result;
  *                          latency of a single detect, at the price of host cores).  Default 1, like the
  *                          reference; agx_detect_batch parallelises over frames instead
- *   "debug_ablation"       timing experiments only -- results are INVALID when non-zero */
+ *   "debug_ablation"       measurement switches of the kernels (tools/): bits 1 .. 1024 remove parts of the blur kernel's
+ *                          work -- timing experiments, results are INVALID; bits 128 / 2048 / 8192 / 16384 collect
+ *                          statistics and phase times (AGX_DBG_VERIFY_STATS), 4096 the start and end of every wave of
+ *                          the sparse kernels (AGX_DBG_WAVE_TIMES), 32768 selects the blur kernel's former ascending
+ *                          segment order: results unchanged (tests/test_gpu_parity.py) */
 int agx_detector_set_option(agx_detector *det, const char *name, int value);
 /* Read an option back; additionally the tiling the blur kernel used for the last enqueued batch:
  * "k1_rows_per_segment" (effective value), "k1_segments", "k1_strips", "k1_strip_columns". */
@@ -309,9 +313,13 @@ enum { AGX_DBG_BLUR = 0, AGX_DBG_RESP = 1, AGX_DBG_MIN = 2, AGX_DBG_CENTERS = 3,
                                 clusters, generic-path candidates, generic-path roots, refined, saddles */
        AGX_DBG_RESP_RECOMPUTED = 6, /* width*height floats: the response recomputed from the stored blur
                                        plane by a separate kernel (cross-check of AGX_DBG_RESP) */
-       AGX_DBG_VERIFY_STATS = 7,    /* 20 x uint32: re-test statistics of K2 (debug_ablation bits 128 / 2048) */
+       AGX_DBG_VERIFY_STATS = 7,    /* 20 x uint32: re-test statistics of K2 (debug_ablation bits 128 / 2048), phase times of
+                                       K2 (8192) / of the flood + refine kernel (16384) in 10 ns ticks */
        AGX_DBG_LUMA8 = 9,   /* width*height bytes: to_luma8 as the device computed it for the last agx_detect on an
                                L16 / RGB8 image (agx_detect converts on the device; agx_luma8 is the host's) */
+       AGX_DBG_WAVE_TIMES = 10, /* pairs of uint64 (start, end; 10 ns ticks of s_memrealtime) of every wave of one sparse
+                                   kernel of the last batch; `frame` selects the kernel (1 verify, 2 flood + refine, 3 rare);
+                                   needs debug_ablation & 4096 (tools/wave_timeline.py) */
        AGX_DBG_REDZONES = 8 /* 6 x uint32: workspace buffers, damaged guard bytes, first damaged buffer, its byte
                                offset from the payload start (int32), device address of buffer 0 (lo, hi: for the
                                check of the check).  Guard bytes exist only in handles created with
