@@ -3,10 +3,13 @@ sys.path.insert(0, ".")
 import torch
 import aprilgrid_rs_amd as A
 from aprilgrid_rs_amd import synth
-frames, _ = synth.render_batch(0, 256, 1280, 800, device="cuda")
+W_, H_, F_ = int(os.environ.get("WIDTH", "1280")), int(os.environ.get("HEIGHT", "800")), int(os.environ.get("FRAMES", "256"))
+U_ = int(os.environ.get("UNIQUE", str(F_)))
+base, _ = synth.render_batch(0, U_, W_, H_, device="cuda", fmt=os.environ.get("FORMAT", "L8"))
+frames = base.repeat((F_ // U_ + 1,) + (1,) * (base.dim() - 1))[:F_].contiguous()
 det = A.TagDetector("t36h11")
 def run(env):
-    for k in ("AGX_G_FLOOD", "AGX_G_VERIFY"):
+    for k in ("AGX_G_FLOOD", "AGX_G_VERIFY", "AGX_K1_STRIP_COLS", "AGX_K1_ROWS"):
         os.environ.pop(k, None)
     os.environ.update(env)
     for _ in range(5): det.saddles_batch_enqueue(frames)
@@ -17,7 +20,7 @@ def run(env):
     for _ in range(10): det.saddles_batch_enqueue(frames)
     det.sync(); p = det.profile_read(); det.profile_enable(False)
     return wall, {k: v[0] / v[1] for k, v in p.items()}
-configs = [{}, {"AGX_G_FLOOD": "48"}, {"AGX_G_VERIFY": "120"}, {"AGX_G_VERIFY": "140"}]
+configs = [{}, {"AGX_K1_STRIP_COLS": "216"}, {"AGX_K1_STRIP_COLS": "224"}]
 res = {i: [] for i in range(len(configs))}
 for rnd in range(6):
     order = range(len(configs)) if rnd % 2 == 0 else reversed(range(len(configs)))
