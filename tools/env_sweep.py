@@ -20,7 +20,7 @@ def run(env):
     for _ in range(10): det.saddles_batch_enqueue(frames)
     det.sync(); p = det.profile_read(); det.profile_enable(False)
     return wall, {k: v[0] / v[1] for k, v in p.items()}
-configs = [{}, {"AGX_K1_STRIP_COLS": "216"}, {"AGX_K1_STRIP_COLS": "224"}]
+configs = [{}, {"AGX_K1_ROWS": "64"}, {"AGX_K1_ROWS": "128"}, {"AGX_K1_ROWS": "160"}]
 res = {i: [] for i in range(len(configs))}
 for rnd in range(6):
     order = range(len(configs)) if rnd % 2 == 0 else reversed(range(len(configs)))
