@@ -67,6 +67,8 @@ def test_bench_batch_256_frames_every_frame(det, det_resp, oracle):
     assert uniq == 256 and tuple(frames.shape) == (256, 800, 1280)
     res = run_batch(det, frames)
     assert det.get_option("k1_rows_per_segment") == 96 and det.get_option("k1_segments") == 9
+    # strips on 128-byte lines of the blur plane where that costs no extra strip: 6 x 224 columns (the last one 160)
+    assert det.get_option("k1_strips") == 6 and det.get_option("k1_strip_columns") == 224
     host = host_frames(frames, "L8")
     refs = oracle_saddles_parallel(oracle, host, threads=16)
     for i in range(256):
@@ -109,7 +111,7 @@ def test_4k_frames(det, det_resp, oracle, rows):
         res = run_batch(d, frames, rows)
         if rows:
             assert d.get_option("k1_rows_per_segment") == rows
-        assert d.get_option("k1_strips") == 16
+        assert d.get_option("k1_strips") == 16 and d.get_option("k1_strip_columns") == 240  # 224 would need 18 strips
         for i in range(2):
             ref = check_frame(d, oracle, host[i], i, "4K frame %d rows %d" % (i, rows))
             check_saddles(res[i], ref, "4K frame %d rows %d" % (i, rows))
