@@ -75,6 +75,9 @@ struct agx_detector {
     float *h_out = nullptr;
     size_t h_out_records = 0;
     float *d_out_internal = nullptr;  // workspace copy of args.out
+    float *h_out_dev = nullptr;       // device address of h_out (mapped pinned memory): a single frame's list is written there directly
+    bool out_in_host = false;         // last batch's compact output went straight to h_out
+    uint32_t *h_table = nullptr, *h_table_dev = nullptr;  // mapped pinned [4]: the single frame's count, offset, status, clusters
     size_t mask_words = 0;
     bool external_out = false;       // last batch wrote into caller-owned device memory
 
@@ -295,7 +298,13 @@ int ensure_workspace(agx_detector *d, int n_frames, int W, int H)
     HIP_TRY(d, hipHostMalloc((void **)&d->h_ctr, (F + 1) * sizeof(FrameCounters), hipHostMallocDefault));
     d->h_total = (uint32_t *)(d->h_ctr + F);
     d->h_ctr_frames = F;
-    HIP_TRY(d, hipHostMalloc((void **)&d->h_out, F * cap_out * 5 * sizeof(float), hipHostMallocDefault));
+    HIP_TRY(d, hipHostMalloc((void **)&d->h_out, F * cap_out * 5 * sizeof(float), hipHostMallocMapped));
+    d->h_out_dev = nullptr;
+    if (hipHostGetDevicePointer((void **)&d->h_out_dev, d->h_out, 0) != hipSuccess) d->h_out_dev = nullptr;
+    if (!d->h_table) {
+        HIP_TRY(d, hipHostMalloc((void **)&d->h_table, 4 * sizeof(uint32_t), hipHostMallocMapped));
+        if (hipHostGetDevicePointer((void **)&d->h_table_dev, d->h_table, 0) != hipSuccess) d->h_table_dev = nullptr;
+    }
     d->h_out_records = F * cap_out;
     d->cap_frames = F;
     d->cap_plane = plane;
@@ -605,6 +614,7 @@ void agx_detector_destroy(agx_detector *det)
     if (det->d_stage) (void)hipFree(det->d_stage);
     if (det->d_luma) (void)hipFree(det->d_luma);
     if (det->h_luma) (void)hipHostFree(det->h_luma);
+    if (det->h_table) (void)hipHostFree(det->h_table);
     if (det->d_dbg_resp) (void)hipFree(det->d_dbg_resp);
     if (det->d_resp_store) (void)hipFree(det->d_resp_store);
     if (det->own_stream) (void)hipStreamDestroy(det->own_stream);
@@ -730,9 +740,12 @@ static int batch_enqueue_impl(agx_detector *det, const void *d_frames, int n_fra
         a.frame_table = (uint32_t *)d_frame_table;
         det->external_out = true;
     } else {
-        a.out = det->d_out_internal;
+        // One frame (the reference's own use): the list goes straight to the pinned host mirror over PCIe -- a few KB of
+        // posted writes -- and the fetch needs no second copy behind the counters' (one wait less per call).
+        det->out_in_host = n_frames == 1 && det->h_out_dev != nullptr && det->h_table_dev != nullptr;
+        a.out = det->out_in_host ? det->h_out_dev : det->d_out_internal;
         a.out_total_cap = (uint32_t)std::min<size_t>((size_t)n_frames * a.cap_out, 0xffffffffu);
-        a.frame_table = nullptr;
+        a.frame_table = det->out_in_host ? det->h_table_dev : nullptr;  // ... and so do its count, offset, status
         det->external_out = false;
     }
     a.force_generic = det->force_generic;
@@ -786,13 +799,30 @@ int agx_saddles_batch_fetch(agx_detector *det, agx_saddle *out, uint32_t cap_per
     HIP_TRY(det, hipSetDevice(det->device));
     const ChainArgs &a = det->args;
     const size_t F = (size_t)a.n_frames;
-    HIP_TRY(det, hipMemcpyAsync(det->h_ctr, a.ctr, F * sizeof(FrameCounters), hipMemcpyDeviceToHost, det->stream));
-    HIP_TRY(det, hipMemcpyAsync(det->h_total, a.total_out, sizeof(uint32_t), hipMemcpyDeviceToHost, det->stream));
-    HIP_TRY(det, hipStreamSynchronize(det->stream));
+    bool have_counters = false;
+    if (det->out_in_host) {  // one frame: list and table row are in host memory when the stream is through -- no copy at all
+        HIP_TRY(det, hipStreamSynchronize(det->stream));
+        const uint32_t *row = det->h_table;
+        if (!(row[2] & (FLAG_CAND_OVERFLOW | FLAG_ROOT_OVERFLOW | FLAG_OUT_OVERFLOW))) {
+            FrameCounters &c = det->h_ctr[0];
+            std::memset(&c, 0, sizeof c);
+            c.n_out = row[0];
+            c.out_offset = row[1];
+            c.flags = row[2];
+            c.n_clusters = row[3];
+            *det->h_total = row[0] + row[1];
+            have_counters = true;
+        }  // else: the full record below (sizes of the overflowing lists for the error message)
+    }
+    if (!have_counters) {
+        HIP_TRY(det, hipMemcpyAsync(det->h_ctr, a.ctr, F * sizeof(FrameCounters), hipMemcpyDeviceToHost, det->stream));
+        HIP_TRY(det, hipMemcpyAsync(det->h_total, a.total_out, sizeof(uint32_t), hipMemcpyDeviceToHost, det->stream));
+        HIP_TRY(det, hipStreamSynchronize(det->stream));
+    }
     harvest_events(det);
     const uint32_t total = *det->h_total;
     if (total > det->h_out_records) return fail(det, AGX_ERR_HIP, "compact output counter out of range");
-    if (total) {
+    if (total && !det->out_in_host) {
         HIP_TRY(det, hipMemcpyAsync(det->h_out, a.out, (size_t)total * 5 * sizeof(float), hipMemcpyDeviceToHost,
                                     det->stream));
         HIP_TRY(det, hipStreamSynchronize(det->stream));
