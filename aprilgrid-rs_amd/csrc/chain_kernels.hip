@@ -124,6 +124,12 @@ __device__ __forceinline__ int lane_id_here()
 // Measured (round 3, 256 x 1280x800, 8 alternating runs per build on one box): K2's re-tests 5 760 -> 2 870 per
 // frame, K2 64 -> 61 us -- but K1 300 -> 307 us (29 KB of LDS per workgroup and the extra branches in the row
 // loop), a net loss; the parity suite passes with it on.
+#ifndef AGX_K1_SYNC_GAP_MAX
+#define AGX_K1_SYNC_GAP_MAX 16  // rows between two refreshes of the running threshold at most (128: K2 +5 us, frames whose strips see no corner for long: 1.5x the re-tests)
+#endif
+#ifndef AGX_K1_SYNC_GAP_LATE
+#define AGX_K1_SYNC_GAP_LATE 64  // ... for waves that find a published minimum when they start
+#endif
 #ifndef AGX_K1_WPE_MAX
 #define AGX_K1_WPE_MAX 8  // A/B builds: -DAGX_K1_WPE_MAX=4 holds K1 at four waves per SIMD
 #endif
@@ -376,7 +382,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((A4 &&
     uint32_t *mask_f = a.mask + (size_t)frame * (size_t)a.mask_plane;
     // wave-uniform; kept as bit patterns so that they live in scalar registers
     int thr_run_bits = 0, published_bits = 0;  // 0.0f
-    int rows_to_sync = 0, sync_gap = 1;
+    int rows_to_sync = 0, sync_gap = 1, gap_cap = AGX_K1_SYNC_GAP_MAX;
     // ctr.min_key_inv as fetched at the previous sync point.  The first fetch is issued right here, at
     // the start of the wave, and awaited at the first sync point seven warm-up rows later: a wave that
     // starts when other waves of its frame have already published (the later segments under the
@@ -657,6 +663,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((A4 &&
                         if (polled_pending) {  // the fetch issued at the start of the wave
                             asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(polled) : : "memory");
                             polled_pending = false;
+                            // a wave that starts when the frame has already published a minimum (the later dispatch rounds)
+                            // refreshes less often: what it would learn it mostly knows
+                            if (polled && !(a.dbg & 65536)) gap_cap = AGX_K1_SYNC_GAP_LATE;
                         }
                         const float gmin = polled ? f32_from_order_key(~polled) : 0.0f;  // 0 = nothing seen yet
                         // Every wave of a frame publishes to ONE word, and atomics on one L2 line serialise
@@ -677,10 +686,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((A4 &&
                         // not have to drain its blur stores (vmcnt) to read one word
                         asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(polled) : "s"(&ctr.min_key_inv) : "memory");
                         rows_to_sync = sync_gap;
-#ifndef AGX_K1_SYNC_GAP_MAX
-#define AGX_K1_SYNC_GAP_MAX 16  // rows between two refreshes of the running threshold at most (128: K2 +5 us, frames whose strips see no corner for long: 1.5x the re-tests)
-#endif
-                        sync_gap = min(sync_gap * 2, AGX_K1_SYNC_GAP_MAX);
+                        sync_gap = min(sync_gap * 2, gap_cap);
                     }
                     --rows_to_sync;
                     // Candidate bit of this row: compare -> lane mask (SGPR pair), restricted to the

@@ -131,7 +131,7 @@ int agx_detector_set_limits(agx_detector *det, uint32_t max_candidates, uint32_t
  *                          work -- timing experiments, results are INVALID; bits 128 / 2048 / 8192 / 16384 collect
  *                          statistics and phase times (AGX_DBG_VERIFY_STATS), 4096 the start and end of every wave of
  *                          the sparse kernels (AGX_DBG_WAVE_TIMES), 32768 selects the blur kernel's former ascending
- *                          segment order: results unchanged (tests/test_gpu_parity.py) */
+ *                          segment order, 65536 its former refresh interval: results unchanged (tests/test_gpu_parity.py) */
 int agx_detector_set_option(agx_detector *det, const char *name, int value);
 /* Read an option back; additionally the tiling the blur kernel used for the last enqueued batch:
  * "k1_rows_per_segment" (effective value), "k1_segments", "k1_strips", "k1_strip_columns". */

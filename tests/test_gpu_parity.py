@@ -226,10 +226,10 @@ def test_batch_matches_oracle_and_is_deterministic(det, oracle):
             assert np.min(np.hypot(*(g - p).T)) < 0.5
 
 
-@pytest.mark.parametrize("bits", [16384, 32768, 4096, 8192])
+@pytest.mark.parametrize("bits", [16384, 32768, 65536, 4096, 8192])
 def test_diagnostic_instantiations_do_not_change_results(det, bits):
     """debug_ablation 16384 runs the flood + refine kernel's second instantiation (phase clock), 32768 K1's ascending
-    segment order (the A/B of the middle-outwards dispatch), 4096 / 8192 the wave and phase timers: the superset K1
+    segment order (the A/B of the middle-outwards dispatch), 65536 the uniform refresh interval of its threshold, 4096 / 8192 the wave and phase timers: the superset K1
     leaves depends on the order in which its waves learn the frame's minimum, the results must not."""
     import aprilgrid_rs_amd as A
     synth = synth_module()
