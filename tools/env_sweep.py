@@ -1,4 +1,7 @@
-import os, sys, time, statistics
+"""Per-kernel times of the chain for a list of tuning environments, alternating in ONE process (6 rounds, the order
+reversed every other round).  usage: python tools/env_sweep.py ['{"AGX_G_FLOOD": "20"}' '{}' ...]   (each argument one
+environment as JSON; default: today's defaults against the settings they replaced; env WIDTH, HEIGHT, FRAMES, UNIQUE, FORMAT)"""
+import json, os, sys, time, statistics
 sys.path.insert(0, ".")
 import torch
 import aprilgrid_rs_amd as A
@@ -20,7 +23,7 @@ def run(env):
     for _ in range(10): det.saddles_batch_enqueue(frames)
     det.sync(); p = det.profile_read(); det.profile_enable(False)
     return wall, {k: v[0] / v[1] for k, v in p.items()}
-configs = [{}, {"AGX_K1_ROWS": "64"}, {"AGX_K1_ROWS": "128"}, {"AGX_K1_ROWS": "160"}]
+configs = [json.loads(x) for x in sys.argv[1:]] or [{}, {"AGX_G_FLOOD": "48"}, {"AGX_K1_STRIP_COLS": "216"}, {"AGX_K1_ROWS": "128"}]
 res = {i: [] for i in range(len(configs))}
 for rnd in range(6):
     order = range(len(configs)) if rnd % 2 == 0 else reversed(range(len(configs)))
