@@ -76,6 +76,7 @@ struct ChainArgs {
     int strip_cols;     // columns per strip (multiple of 4)
     int rows_per_seg;   // output rows per workgroup
     int n_segs;
+    int k1_group;       // frames per dispatch group of K1 (0 or >= n_frames: the whole batch segment-major)
     float publish_factor;  // a wave publishes its running minimum m only if m < factor * the frame's known minimum
     float w[7];  // blur taps
     // dense planes [n_frames][H][W]

@@ -301,7 +301,26 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((A4 &&
     const int per_frame_full = a.n_strips * n_full;
     const int total_full = per_frame_full * a.n_frames;
     int frame, strip, seg;
-    if (u < total_full) {
+    if (a.k1_group > 0 && a.k1_group < a.n_frames) {
+        // Frame groups: the batch's frames in groups of k1_group, group after group; inside a group segment-major,
+        // the full segments from the middle outwards, the short last segment behind them.  The frames of a group are
+        // complete when the group's waves are, long before the launch ends: the sparse stages of those frames can run
+        // under the blur of the groups that follow.
+        const int per_frame = a.n_strips * a.n_segs;
+        const int per_group = per_frame * a.k1_group;
+        if (u >= per_frame * a.n_frames) return;  // whole wave: padding of the last workgroup
+        const int g = u / per_group;
+        const int gbase = g * a.k1_group;
+        const int ng = min(a.k1_group, a.n_frames - gbase);
+        const int ur = u - g * per_group;
+        const int per_seg = a.n_strips * ng;
+        const int k = ur / per_seg;
+        const int r = ur - k * per_seg;
+        const int mid = (n_full - 1) >> 1, dist = (k + 1) >> 1;
+        seg = k >= n_full ? k : ((k & 1) ? mid + dist : mid - dist);
+        frame = gbase + r / a.n_strips;
+        strip = r - (r / a.n_strips) * a.n_strips;
+    } else if (u < total_full) {
         if (a.dbg & 1024) {  // A/B: the former frame-major order
             frame = u / per_frame_full;
             const int r = u - frame * per_frame_full;
@@ -2098,6 +2117,7 @@ bool plan_k1(ChainArgs &a, int override_rows_per_seg)
     a.rows_per_seg = rps;
     a.n_segs = (H + rps - 1) / rps;
     a.publish_factor = a.n_strips * a.n_segs > 128 ? 1.5f : 1.0f;  // see the publish step of K1
+    a.k1_group = env_int("AGX_K1_GROUP", 0);
     return true;
 }
 
@@ -2113,14 +2133,15 @@ static hipError_t launch_k1(const ChainArgs &a, hipStream_t st)
 {
     const long long units = (long long)a.n_strips * a.n_segs * a.n_frames;
     dim3 grid((unsigned)((units + 3) / 4)), block(256);
+    const size_t k1_lds = (size_t)env_int("AGX_K1_LDS_KB", 0) * 1024;  // experiment: dynamic LDS caps the workgroups per CU
     // the aligned form addresses a frame and its blur plane with 32-bit buffer offsets
     const bool small = a.plane * 4 < (1ll << 31) && (long long)a.H * a.row_stride < (1ll << 31);
     const bool a4 = (a.W & 3) == 0 && small && !a.byte_rows;
     if (a.resp_dbg) {  // parity-test instantiation: also stores the response it evaluates
-        if (a4) hipLaunchKernelGGL((k_blur_hessian<FMT, true, true>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((k_blur_hessian<FMT, false, true>), grid, block, 0, st, a);
-    } else if (a4) hipLaunchKernelGGL((k_blur_hessian<FMT, true>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((k_blur_hessian<FMT, false>), grid, block, 0, st, a);
+        if (a4) hipLaunchKernelGGL((k_blur_hessian<FMT, true, true>), grid, block, k1_lds, st, a);
+        else hipLaunchKernelGGL((k_blur_hessian<FMT, false, true>), grid, block, k1_lds, st, a);
+    } else if (a4) hipLaunchKernelGGL((k_blur_hessian<FMT, true>), grid, block, k1_lds, st, a);
+    else hipLaunchKernelGGL((k_blur_hessian<FMT, false>), grid, block, k1_lds, st, a);
     return hipGetLastError();
 }
 

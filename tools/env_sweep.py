@@ -12,7 +12,7 @@ base, _ = synth.render_batch(0, U_, W_, H_, device="cuda", fmt=os.environ.get("F
 frames = base.repeat((F_ // U_ + 1,) + (1,) * (base.dim() - 1))[:F_].contiguous()
 det = A.TagDetector("t36h11")
 def run(env):
-    for k in ("AGX_G_FLOOD", "AGX_G_VERIFY", "AGX_K1_STRIP_COLS", "AGX_K1_ROWS"):
+    for k in [k for k in os.environ if k.startswith(("AGX_G_", "AGX_K1_", "AGX_SP_"))]:
         os.environ.pop(k, None)
     os.environ.update(env)
     for _ in range(5): det.saddles_batch_enqueue(frames)
