@@ -16,7 +16,9 @@ enum Kernel : int {
     K_RARE = 3,          // K4: per frame: second flood tier (128x64 per wave), generic clustering fallback for frames
                          //     with larger components, k/phi filter and reference-order emission; clears the
                          //     next batch's counters
-    K_COUNT = 4
+    K_SPARSE = 4,        // K2 + K3 + K4 of one frame in one 1024-thread workgroup (k_sparse_frame): batches that fill the chip
+                         //     with one workgroup per frame run K1 + K_SPARSE, the others K1 .. K4
+    K_COUNT = 5
 };
 
 // One record of K4's output list.

@@ -920,20 +920,23 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__global__ void __launch_bounds__(64 * VS_WAVES) AGX_VS_ATTR k_verify_seeds(ChainArgs a)
+// The frame's seed list as the fused sparse kernel (k_sparse_frame) keeps it: the first SEED_LDS_CAP seeds in LDS, the rest
+// (noise frames) in the frame's global list behind them; the counters and flags of the frame in LDS.
+constexpr uint32_t SEED_LDS_CAP = 4096;
+struct FrameLds {
+    uint32_t *n_seeds, *flags;  // LDS words
+    uint32_t *seeds;            // LDS [SEED_LDS_CAP]
+};
+
+// Tiles first_tile, first_tile + tile_stride, ... of `frame` by one wave.  FUSED = false: k_verify_seeds (the tile's seeds
+// are collected in the wave's LDS and appended to the frame's global list with one atomic per tile; s_nseeds / s_base are
+// the wave's own words).  FUSED = true: k_sparse_frame (seeds go straight into the workgroup's list `fl`).
+template <bool FUSED>
+__device__ __forceinline__ void verify_tiles(const ChainArgs &a, int frame, int first_tile, int tile_stride, uint32_t *s_keep,
+                                             uint32_t *s_list, uint32_t *s_nseeds_p, uint32_t *s_base_p, const FrameLds &fl)
 {
-    __shared__ uint32_t s_keep_all[VS_WAVES][(VS_ROWS + 1) * 64];  // row VS_ROWS: bit 0 = the pixel above the tile's first row
-    __shared__ uint32_t s_list_all[VS_WAVES][VS_LIST];  // re-test work list, then the tile's seeds (VS_SEEDS <= VS_LIST)
-    __shared__ uint32_t s_nseeds_all[VS_WAVES], s_base_all[VS_WAVES];
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    uint32_t *s_keep = s_keep_all[wv], *s_list = s_list_all[wv];
     uint32_t *s_seeds = s_list;
-    uint32_t &s_nseeds = s_nseeds_all[wv], &s_base = s_base_all[wv];
-    const WaveTimer wt(a, K_THRESHOLD);
-    FrameSlot fs = frame_slot(a.n_frames, true);  // latest-written blur planes first (cache)
-    fs.slot = fs.slot * VS_WAVES + (uint32_t)wv;  // this wave's slot of the frame
-    fs.n_slots *= VS_WAVES;
-    const int frame = fs.frame;
+    uint32_t &s_nseeds = *s_nseeds_p, &s_base = *s_base_p;
     FrameCounters &ctr = a.ctr[frame];
     uint32_t *mask = a.mask + (size_t)frame * (size_t)a.mask_plane;
     const float *blur = a.blur + (size_t)frame * (size_t)a.plane;
@@ -943,8 +946,10 @@ __global__ void __launch_bounds__(64 * VS_WAVES) AGX_VS_ATTR k_verify_seeds(Chai
     const int n_yb = (a.H + 31) >> 5;
     const int groups = (W + VS_OWN - 1) / VS_OWN;
     const int tiles = ((n_yb + VS_ROWS - 1) / VS_ROWS) * groups;
-    if (lane == 0) s_nseeds = 0u;
-    wave_lds_sync();
+    if (!FUSED) {
+        if (lane == 0) s_nseeds = 0u;
+        wave_lds_sync();
+    }
     // debug_ablation & 8192: where a wave's time goes -- 10 ns ticks per phase summed into the frame's stats[0..5]
     // (first loads, block maxima + threshold, work list + re-tests, seeds, list append, rest), tiles in stats[7]
     const bool phase_on = (a.dbg & 8192) != 0;
@@ -956,7 +961,7 @@ __global__ void __launch_bounds__(64 * VS_WAVES) AGX_VS_ATTR k_verify_seeds(Chai
             t_prev = now;
         }
     };
-    for (int t = (int)fs.slot; t < tiles; t += (int)fs.n_slots) {  // wave-uniform
+    for (int t = first_tile; t < tiles; t += tile_stride) {  // wave-uniform
         const int ch = t / groups, g = t - ch * groups;
         const int yb0 = ch * VS_ROWS;
         const int x = g * VS_OWN - 1 + lane;  // -1 .. W + 62: inside the mask's zero padding
@@ -1132,6 +1137,13 @@ __global__ void __launch_bounds__(64 * VS_WAVES) AGX_VS_ATTR k_verify_seeds(Chai
                 const int b = __ffs(sd) - 1;
                 sd &= sd - 1;
                 const uint32_t pix = (uint32_t)((yb0 + r) * 32 + b) * (uint32_t)W + (uint32_t)x;
+                if (FUSED) {  // the workgroup's list: LDS first, the frame's global list behind it
+                    const uint32_t i = atomicAdd(fl.n_seeds, 1u);
+                    if (i >= a.cap_roots) atomicOr(fl.flags, FLAG_CAND_OVERFLOW);
+                    else if (i < SEED_LDS_CAP) fl.seeds[i] = pix;
+                    else a.seeds[(size_t)frame * a.cap_roots + i] = pix;
+                    continue;
+                }
                 const uint32_t i = atomicAdd(&s_nseeds, 1u);
                 if (i < VS_SEEDS) {
                     s_seeds[i] = pix;
@@ -1141,6 +1153,10 @@ __global__ void __launch_bounds__(64 * VS_WAVES) AGX_VS_ATTR k_verify_seeds(Chai
                     else atomicOr(&ctr.flags, FLAG_CAND_OVERFLOW);
                 }
             }
+        }
+        if (FUSED) {
+            phase(3);
+            continue;
         }
         // append the tile's seeds to the frame's list: one atomic, coalesced stores
         wave_lds_sync();
@@ -1161,6 +1177,20 @@ __global__ void __launch_bounds__(64 * VS_WAVES) AGX_VS_ATTR k_verify_seeds(Chai
         }
         phase(5);
     }
+}
+
+__global__ void __launch_bounds__(64 * VS_WAVES) AGX_VS_ATTR k_verify_seeds(ChainArgs a)
+{
+    __shared__ uint32_t s_keep_all[VS_WAVES][(VS_ROWS + 1) * 64];  // row VS_ROWS: bit 0 = the pixel above the tile's first row
+    __shared__ uint32_t s_list_all[VS_WAVES][VS_LIST];  // re-test work list, then the tile's seeds (VS_SEEDS <= VS_LIST)
+    __shared__ uint32_t s_nseeds_all[VS_WAVES], s_base_all[VS_WAVES];
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const WaveTimer wt(a, K_THRESHOLD);
+    FrameSlot fs = frame_slot(a.n_frames, true);  // latest-written blur planes first (cache)
+    fs.slot = fs.slot * VS_WAVES + (uint32_t)wv;  // this wave's slot of the frame
+    fs.n_slots *= VS_WAVES;
+    verify_tiles<false>(a, fs.frame, (int)fs.slot, (int)fs.n_slots, s_keep_all[wv], s_list_all[wv], &s_nseeds_all[wv], &s_base_all[wv],
+                        FrameLds{nullptr, nullptr, nullptr});
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1596,12 +1626,42 @@ __global__ void k_debug_resp(const float *__restrict__ blur, float *__restrict__
 // counters given (the global per-frame counters, or a workgroup's LDS copies).
 // Core: the cluster with first pixel `key`, cn pixels and the integer coordinate sums sx, sy; the f32 centroid
 // (detector.rs:427) comes back in cx, cy (the caller keeps it in the cluster record for agx_debug_fetch).
-template <bool VEC, typename CLK>
+// Where a refined record goes.  RecSinkGlobal: the frame's global list through the frame's global counters (k_flood_refine,
+// the generic path).  RecSinkLds (k_sparse_frame): the workgroup's counters in LDS, the first TAIL_CAP records in LDS as six
+// arrays of TAIL_CAP words, every record also in the frame's global list (agx_debug_fetch, and the large-list emission).
+constexpr uint32_t TAIL_CAP = 1024;
+struct RecSinkGlobal {
+    uint32_t *n_refined, *max_k_bits, *flags;
+    __device__ __forceinline__ void put(const ChainArgs &a, int frame, uint32_t o, const uint32_t (&f)[6]) const
+    {
+        // The record is read by another launch (k_rare) or, on the generic path, by other waves of the workgroup behind an
+        // agent-scope fence: agent-scope stores.
+        uint32_t *rec = reinterpret_cast<uint32_t *>(a.refined + (size_t)frame * a.cap_roots + o);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) __hip_atomic_store(rec + q, f[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+};
+struct RecSinkLds {
+    uint32_t *n_refined, *max_k_bits, *flags;  // LDS words
+    uint32_t *rec;                             // LDS [6][TAIL_CAP]
+    __device__ __forceinline__ void put(const ChainArgs &a, int frame, uint32_t o, const uint32_t (&f)[6]) const
+    {
+        if (o < TAIL_CAP) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) rec[q * TAIL_CAP + o] = f[q];
+        }
+        uint32_t *g = reinterpret_cast<uint32_t *>(a.refined + (size_t)frame * a.cap_roots + o);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) g[q] = f[q];  // (read by this workgroup behind a barrier, or by the host)
+    }
+};
+
+template <bool VEC, typename CLK, typename SINK>
 __device__ __forceinline__ void refine_values(const ChainArgs &a, const RefineConsts &rc, int frame, const float *img, int W, int H,
-                                              uint32_t key, uint32_t cn, uint32_t sx, uint32_t sy, uint32_t *n_refined,
-                                              uint32_t *max_k_bits, float &cx, float &cy, CLK &clk)
+                                              uint32_t key, uint32_t cn, uint32_t sx, uint32_t sy, const SINK &sink, float &cx,
+                                              float &cy, CLK &clk)
 {
-    if (sx >= (1u << 24) || sy >= (1u << 24)) atomicOr(&a.ctr[frame].flags, FLAG_CENTROID_INEXACT);
+    if (sx >= (1u << 24) || sy >= (1u << 24)) atomicOr(sink.flags, FLAG_CENTROID_INEXACT);
     const float fn = (float)cn;
     const float initial_x = (float)sx / fn;  // detector.rs:427
     const float initial_y = (float)sy / fn;
@@ -1726,7 +1786,7 @@ __device__ __forceinline__ void refine_values(const ChainArgs &a, const RefineCo
         asm volatile("" : "+v"(th), "+v"(ph));
         clk.mark(17);  // the fit: divisions, sqrt, acos, atan2 (lanes that pass)
     }
-    uint32_t o = atomicAdd(n_refined, 1u);
+    uint32_t o = atomicAdd(sink.n_refined, 1u);
     if (CLK::on) {
         asm volatile("" : "+v"(o));
         clk.mark(15);  // the record's index (atomic round trip)
@@ -1734,14 +1794,10 @@ __device__ __forceinline__ void refine_values(const ChainArgs &a, const RefineCo
     // o < n_clusters <= cap_roots -- unless the frame's cluster list has overflowed (the fused flood + refine kernel
     // refines before it knows its record index): such a frame is void as a whole and nothing is stored for it
     if (o >= a.cap_roots) return;
-    // The record is read by another launch (k_rare) or, on the generic path, by other waves of the workgroup behind an
-    // agent-scope fence: agent-scope stores.
-    uint32_t *rec = reinterpret_cast<uint32_t *>(a.refined + (size_t)frame * a.cap_roots + o);
     const uint32_t f[6] = {key, __float_as_uint(rxf + x0), __float_as_uint(ryf + y0),
                            __float_as_uint(k),  __float_as_uint(theta),     __float_as_uint(phi)};
-#pragma unroll
-    for (int q = 0; q < 6; ++q) __hip_atomic_store(rec + q, f[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    atomicMax(max_k_bits, __float_as_uint(k));
+    sink.put(a, frame, o, f);
+    atomicMax(sink.max_k_bits, __float_as_uint(k));
 }
 
 // rochade_refine of cluster record s of `frame` as it stands in the cluster table.
@@ -1752,8 +1808,9 @@ __device__ __forceinline__ void refine_cluster(const ChainArgs &a, const RefineC
 {
     float cx, cy;
     NoClock clk;
+    const RecSinkGlobal sink{n_refined, max_k_bits, &a.ctr[frame].flags};
     refine_values<VEC>(a, rc, frame, img, W, H, a.clu_key[cbase + s], a.clu_cnt[cbase + s], a.clu_sx[cbase + s], a.clu_sy[cbase + s],
-                       n_refined, max_k_bits, cx, cy, clk);
+                       sink, cx, cy, clk);
     a.clu_sx[cbase + s] = __float_as_uint(cx);  // kept for agx_debug_fetch
     a.clu_sy[cbase + s] = __float_as_uint(cy);
 }
@@ -1830,7 +1887,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AGX_FLO
             // atomic's round trip runs under the window loads (a frame whose cluster list overflows is void as a whole)
             const uint32_t o = atomicAdd(&ctr.n_clusters, 1u);
             float cx, cy;
-            refine_values<VEC>(a, rc, frame, img, a.W, a.H, p, cnt, sumx, sumy, &ctr.n_refined, &ctr.max_k_bits, cx, cy, clk);
+            const RecSinkGlobal sink{&ctr.n_refined, &ctr.max_k_bits, &ctr.flags};
+            refine_values<VEC>(a, rc, frame, img, a.W, a.H, p, cnt, sumx, sumy, sink, cx, cy, clk);
             if (o < a.cap_roots) {
                 a.clu_key[cbase + o] = p;
                 a.clu_cnt[cbase + o] = cnt;
@@ -1943,8 +2001,6 @@ __device__ __forceinline__ void filter_sort_emit(const ChainArgs &a, int frame, 
 // frame's 1024-thread workgroup of k_rare: thread t holds record t, rejected records get the key 0xffffffff, and a
 // surviving record's output position is its rank = the number of smaller keys (keys are distinct: the first pixel
 // of distinct clusters) -- no sort passes, one memory round trip for the records and one for the output.
-constexpr uint32_t TAIL_CAP = 1024;
-
 __device__ __forceinline__ void emit_wide(const ChainArgs &a, int frame, uint32_t n, uint32_t max_k_bits, uint32_t *keys,
                                           uint32_t *s_misc)
 {
@@ -2000,25 +2056,71 @@ __device__ __forceinline__ void emit_wide(const ChainArgs &a, int frame, uint32_
     for (int q = 0; q < 5; ++q) out[(size_t)rank * 5 + q] = __uint_as_float(f[q + 1]);
 }
 
-// K4, the last launch of the chain: a 1024-thread workgroup per frame
-//   - filters (detector.rs:436-445) and emits the frame's saddles in the reference's order (emit_wide; lists of
-//     more than TAIL_CAP refined records -- FLAG_LARGE_RESULT -- by the large LDS / global-memory sort);
-//   - before that, for a frame where a component left the flood windows (FLAG_BIG_CLUSTER): clusters it again by
-//     the generic union-find path and refines it;
-//   - clears the other counter set for the next batch.
-__global__ void __launch_bounds__(1024) k_rare(ChainArgs a, RefineConsts rc, uint32_t lds_entries)
+// Filter and ordered emission of one frame whose refined records (n <= TAIL_CAP of them) are in LDS as six arrays of
+// TAIL_CAP words (k_sparse_frame): as emit_wide, without a memory round trip for the records.  flags_lds: the frame's flag
+// word in LDS; n_clusters: for the frame table.
+__device__ __forceinline__ void emit_wide_lds(const ChainArgs &a, int frame, uint32_t n, uint32_t max_k_bits, const uint32_t *rec,
+                                              uint32_t *keys, uint32_t *s_misc, uint32_t *flags_lds, uint32_t n_clusters)
 {
-    extern __shared__ uint32_t lds_u[];
-    __shared__ uint32_t s_misc3[3];
-    uint32_t &s_count = s_misc3[0], &s_offset = s_misc3[1], &s_fits = s_misc3[2];
-    const WaveTimer wt(a, K_RARE);
-    const int frame = blockIdx.x;
-    // The last launch of the batch also clears the OTHER counter set for the next batch (the two sets
-    // alternate): a memset between the batches costs a fill kernel and two ~5 us gaps on the stream.
-    if (a.ctr_next && threadIdx.x < 64) {
-        reinterpret_cast<uint32_t *>(&a.ctr_next[frame])[threadIdx.x] = 0u;
-        if (frame == 0) reinterpret_cast<uint32_t *>(&a.ctr_next[a.n_frames])[threadIdx.x] = 0u;  // the output cursor's record
+    const uint32_t t = threadIdx.x;  // 1024 threads, n <= TAIL_CAP
+    FrameCounters &ctr = a.ctr[frame];
+    const float s_max_k = __uint_as_float(max_k_bits) / 10.0f;  // detector.rs:436
+    uint32_t f[6] = {0xffffffffu, 0u, 0u, 0u, 0u, 0u};
+    bool pass = false;
+    if (t < n) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) f[q] = rec[q * TAIL_CAP + t];
+        const float k = __uint_as_float(f[3]), phi = __uint_as_float(f[5]);
+        pass = k >= s_max_k && phi >= a.min_angle && phi <= a.max_angle;
     }
+    keys[t] = pass ? f[0] : 0xffffffffu;
+    if (t < 4) keys[TAIL_CAP + t] = 0xffffffffu;  // (padding for the 16-byte reads of the rank loop)
+    const uint32_t nf = (uint32_t)__syncthreads_count(pass ? 1 : 0);
+    if (t == 0) {
+        uint32_t off = 0, fits = 1;
+        const bool ok = nf <= a.cap_out;
+        if (ok && nf) {
+            off = atomicAdd(a.total_out, nf);
+            if (off + nf > a.out_total_cap) fits = 0;  // caller's buffer is full
+        }
+        if (!ok || !fits) *flags_lds |= FLAG_OUT_OVERFLOW;
+        s_misc[0] = off;
+        s_misc[1] = (ok && fits) ? 1u : 0u;
+        ctr.n_out = nf;
+        ctr.out_offset = off;
+        if (a.frame_table) {
+            uint32_t *row = a.frame_table + (size_t)frame * 4;
+            const uint32_t flags = *flags_lds;
+            const bool bad = (flags & (FLAG_CAND_OVERFLOW | FLAG_ROOT_OVERFLOW | FLAG_OUT_OVERFLOW)) != 0;
+            row[0] = bad ? 0u : nf;
+            row[1] = off;
+            row[2] = flags;
+            row[3] = n_clusters;
+        }
+    }
+    __syncthreads();
+    if (!pass || !s_misc[1]) return;
+    float *out = a.out + (size_t)s_misc[0] * 5;
+    const uint32_t n4 = (n + 3u) >> 2;
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < n4; ++j) {  // every lane reads the same 16 bytes: LDS broadcast
+        const uint4 q = reinterpret_cast<const uint4 *>(keys)[j];
+        rank += (q.x < f[0] ? 1u : 0u) + (q.y < f[0] ? 1u : 0u) + (q.z < f[0] ? 1u : 0u) + (q.w < f[0] ? 1u : 0u);
+    }
+#pragma unroll
+    for (int q = 0; q < 5; ++q) out[(size_t)rank * 5 + q] = __uint_as_float(f[q + 1]);
+}
+
+// The rare work and the emission of one frame from the frame's GLOBAL lists and counters, by a 1024-thread workgroup:
+//   - for a frame where a component left the flood windows (FLAG_BIG_CLUSTER): clusters it again by the generic
+//     union-find path and refines it;
+//   - filters (detector.rs:436-445) and emits the frame's saddles in the reference's order (emit_wide; lists of
+//     more than TAIL_CAP refined records -- FLAG_LARGE_RESULT -- by the large LDS / global-memory sort).
+// lds_u: lds_entries * 2 words of LDS (16-byte aligned), s_misc3: three more.
+__device__ __forceinline__ void rare_frame(const ChainArgs &a, const RefineConsts &rc, int frame, uint32_t *lds_u, uint32_t lds_entries,
+                                           uint32_t *s_misc3)
+{
+    uint32_t &s_count = s_misc3[0], &s_offset = s_misc3[1], &s_fits = s_misc3[2];
     FrameCounters &ctr = a.ctr[frame];
     // the frame's flags, the length of its refined list and the largest k in ONE round trip (one 128-byte line)
     uint32_t flags0 = __hip_atomic_load(&ctr.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2071,6 +2173,141 @@ __global__ void __launch_bounds__(1024) k_rare(ChainArgs a, RefineConsts rc, uin
     }
 }
 
+// The last launch of a batch also clears the OTHER counter set for the next batch (the two sets alternate): a memset
+// between the batches costs a fill kernel and two ~5 us gaps on the stream.  (One workgroup per frame.)
+__device__ __forceinline__ void clear_next_counters(const ChainArgs &a, int frame)
+{
+    if (a.ctr_next && threadIdx.x < 64) {
+        reinterpret_cast<uint32_t *>(&a.ctr_next[frame])[threadIdx.x] = 0u;
+        if (frame == 0) reinterpret_cast<uint32_t *>(&a.ctr_next[a.n_frames])[threadIdx.x] = 0u;  // the output cursor's record
+    }
+}
+
+// K4, the last launch of the multi-launch chain: a 1024-thread workgroup per frame (rare_frame).
+__global__ void __launch_bounds__(1024) k_rare(ChainArgs a, RefineConsts rc, uint32_t lds_entries)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];  // (emit_wide reads its keys 16 bytes at a time)
+    __shared__ uint32_t s_misc3[3];
+    const WaveTimer wt(a, K_RARE);
+    const int frame = blockIdx.x;
+    clear_next_counters(a, frame);
+    rare_frame(a, rc, frame, lds_u, lds_entries, s_misc3);
+}
+
+// ------------------------------------------------------------------------------------------
+// K_SPARSE: the whole sparse phase of ONE frame in ONE 1024-thread workgroup -- what K2, K3 and K4 do in three
+// batch-wide launches.  The reference's barrier between the stages is per frame (the minimum of the frame's response,
+// detector.rs:414-418; its clusters and their refinement, :420-445), so the frame's sixteen waves go from stage to
+// stage behind workgroup barriers, and the frames (one per CU, 256 CUs) drift apart as their work differs: one
+// frame's latency chains run while another's flood keeps the vector ALUs busy.  The frame's lists live in LDS:
+//   verify  the frame's tiles, wave by wave (verify_tiles); seeds into the LDS list
+//   flood   one seed per lane (flood_lane / wave_flood_128x64), the cluster refined by the lane that flooded it;
+//           cluster count, refined records (first TAIL_CAP), largest k in LDS
+//   emit    filter + rank + store from LDS (emit_wide_lds)
+// Frames with a component beyond the flood windows, or with more than TAIL_CAP refined records, continue on the
+// global-memory path (rare_frame), as under k_rare.  Used for batches that fill the chip with one workgroup per frame;
+// smaller batches keep the three launches (plan: launch_kernel / use_sparse_frame).
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t SF_MISC = 16;                                   // LDS words: counters (below)
+constexpr uint32_t SF_SEEDS = SF_MISC;                             // [SEED_LDS_CAP]
+constexpr uint32_t SF_REC = SF_SEEDS + SEED_LDS_CAP;               // [6][TAIL_CAP]
+constexpr uint32_t SF_WAVE = SF_REC + 6 * TAIL_CAP;                // per wave: keep words, re-test list
+constexpr uint32_t SF_WAVE_WORDS = (VS_ROWS + 1) * 64 + VS_LIST;
+constexpr uint32_t SF_WORDS = SF_WAVE + 16 * SF_WAVE_WORDS;
+static_assert(16 * SF_WAVE_WORDS >= TAIL_CAP + 8, "the emission's keys reuse the waves' verify scratch");
+static_assert(SF_SEEDS % 4 == 0 && SF_REC % 4 == 0 && SF_WAVE % 4 == 0, "16-byte aligned parts");
+enum : int { SFM_SEEDS = 0, SFM_FLAGS = 1, SFM_CLUSTERS = 2, SFM_REFINED = 3, SFM_MAXK = 4, SFM_BIG = 5, SFM_EMIT = 8, SFM_RARE = 12 };
+
+template <bool VEC>
+__global__ void __launch_bounds__(1024) k_sparse_frame(ChainArgs a, RefineConsts rc, uint32_t lds_entries)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
+    const int frame = a.n_frames - 1 - (int)blockIdx.x;  // latest-written blur planes first (cache)
+    const uint32_t t = threadIdx.x;
+    const int lane = (int)(t & 63u);
+    const int wv = __builtin_amdgcn_readfirstlane((int)(t >> 6));
+    clear_next_counters(a, frame);
+    uint32_t *misc = lds_u;
+    if (t < SF_MISC) misc[t] = 0u;
+    __syncthreads();
+    FrameCounters &ctr = a.ctr[frame];
+    const FrameLds fl{&misc[SFM_SEEDS], &misc[SFM_FLAGS], lds_u + SF_SEEDS};
+    const size_t cbase = (size_t)frame * a.cap_roots;
+    // ---- verify: the frame's tiles, sixteen at a time ----
+    {
+        uint32_t *wave_lds = lds_u + SF_WAVE + (uint32_t)wv * SF_WAVE_WORDS;
+        verify_tiles<true>(a, frame, wv, 16, wave_lds, wave_lds + (VS_ROWS + 1) * 64, nullptr, nullptr, fl);
+    }
+    __syncthreads();  // the verified mask (global, this CU's stores) and the seed list are complete
+    // ---- flood + refine: one seed per lane ----
+    const uint32_t n_seeds_raw = misc[SFM_SEEDS];
+    if (!a.force_generic && n_seeds_raw <= a.cap_roots && !(misc[SFM_FLAGS] & FLAG_CAND_OVERFLOW)) {
+        const uint32_t n = n_seeds_raw;
+        const uint32_t *mask = a.mask + (size_t)frame * (size_t)a.mask_plane;
+        const float *img = a.blur + (size_t)frame * (size_t)a.plane;
+        const uint32_t W = (uint32_t)a.W;
+        const RecSinkLds sink{&misc[SFM_REFINED], &misc[SFM_MAXK], &misc[SFM_FLAGS], lds_u + SF_REC};
+        NoClock clk;
+        for (uint32_t base = (uint32_t)wv * 64u; base < n; base += 1024u) {  // wave-uniform trip count
+            const uint32_t i = base + (uint32_t)lane;
+            uint32_t p = 0u, cnt = 0, sumx = 0, sumy = 0;
+            int what = FLOOD_NONE;
+            if (i < n) {
+                p = i < SEED_LDS_CAP ? fl.seeds[i] : a.seeds[cbase + i];
+                what = flood_lane(a, mask, W, p, cnt, sumx, sumy, clk);
+            }
+            // second tier: see k_flood_refine
+            unsigned long long big = __ballot(what == FLOOD_BIG);
+            if (big && lane == 0) atomicAdd(&misc[SFM_BIG], (uint32_t)__popcll(big));
+            while (big) {  // wave-uniform
+                const int src = __ffsll((long long)big) - 1;
+                big &= big - 1ull;
+                uint32_t c2 = 0, x2 = 0, y2 = 0;
+                const int w2 = wave_flood_128x64(a, &misc[SFM_FLAGS], mask, (uint32_t)__builtin_amdgcn_readlane((int)p, src), lane, c2, x2, y2);
+                if (lane == src) {
+                    what = w2 == FLOOD_CLUSTER ? FLOOD_CLUSTER : FLOOD_NONE;
+                    cnt = c2;
+                    sumx = x2;
+                    sumy = y2;
+                }
+            }
+            if (what == FLOOD_CLUSTER) {
+                const uint32_t o = atomicAdd(&misc[SFM_CLUSTERS], 1u);
+                float cx, cy;
+                refine_values<VEC>(a, rc, frame, img, a.W, a.H, p, cnt, sumx, sumy, sink, cx, cy, clk);
+                if (o < a.cap_roots) {  // the cluster table (agx_debug_fetch)
+                    a.clu_key[cbase + o] = p;
+                    a.clu_cnt[cbase + o] = cnt;
+                    a.clu_sx[cbase + o] = __float_as_uint(cx);
+                    a.clu_sy[cbase + o] = __float_as_uint(cy);
+                } else {
+                    atomicOr(&misc[SFM_FLAGS], FLAG_ROOT_OVERFLOW);
+                }
+            }
+        }
+    }  // (a seed list beyond cap_roots has set FLAG_CAND_OVERFLOW in verify_tiles: the frame is reported, not processed)
+    __syncthreads();
+    const uint32_t flags = misc[SFM_FLAGS], n_ref = misc[SFM_REFINED], n_clu = min(misc[SFM_CLUSTERS], a.cap_roots);
+    const bool void_frame = (flags & (FLAG_CAND_OVERFLOW | FLAG_ROOT_OVERFLOW)) != 0;
+    const bool generic = a.force_generic || (flags & FLAG_BIG_CLUSTER);
+    if (t == 0) {  // the frame's counters as the host (and agx_debug_fetch) reads them
+        ctr.n_seeds = min(n_seeds_raw, a.cap_roots);
+        ctr.n_big = misc[SFM_BIG];
+        ctr.n_clusters = n_clu;
+        ctr.n_refined = n_ref;
+        ctr.max_k_bits = misc[SFM_MAXK];
+    }
+    if (generic || (!void_frame && n_ref > TAIL_CAP)) {
+        // the global-memory path: its counters and lists are in global memory (every record is mirrored there)
+        if (t == 0) atomicOr(&ctr.flags, flags);
+        phase_barrier();
+        rare_frame(a, rc, frame, lds_u + SF_MISC, lds_entries, &misc[SFM_RARE]);  // (everything behind the counters is free now)
+        return;
+    }
+    emit_wide_lds(a, frame, void_frame ? 0u : n_ref, misc[SFM_MAXK], lds_u + SF_REC, lds_u + SF_WAVE, &misc[SFM_EMIT], &misc[SFM_FLAGS], n_clu);
+    if (t == 0) ctr.flags = misc[SFM_FLAGS];  // (behind emit_wide_lds's last barrier: OUT_OVERFLOW included)
+}
+
 // ------------------------------------------------------------------------------------------
 // host side: tiling plan and launches
 // ------------------------------------------------------------------------------------------
@@ -2119,6 +2356,12 @@ bool plan_k1(ChainArgs &a, int override_rows_per_seg)
     a.publish_factor = a.n_strips * a.n_segs > 128 ? 1.5f : 1.0f;  // see the publish step of K1
     a.k1_group = env_int("AGX_K1_GROUP", 0);
     return true;
+}
+
+// Dynamic LDS of k_sparse_frame: its own lists, or the counters + the large-list sort of rare_frame.
+size_t sparse_frame_lds_bytes(const ChainArgs &a)
+{
+    return std::max<size_t>((size_t)SF_WORDS * 4, (size_t)SF_MISC * 4 + k5_lds_bytes(a));
 }
 
 size_t k5_lds_bytes(const ChainArgs &a)
@@ -2198,6 +2441,13 @@ int launch_kernel(int which, const ChainArgs &a, const RefineConsts &rc, void *s
         hipLaunchKernelGGL(k_rare, grid, block, lds, st, a, rc, (uint32_t)(lds / 8));
         return hipGetLastError();
     }
+    case K_SPARSE: {
+        const size_t lds = sparse_frame_lds_bytes(a);
+        dim3 grid(a.n_frames), block(1024);
+        if ((a.W & 3) == 0) hipLaunchKernelGGL((k_sparse_frame<true>), grid, block, lds, st, a, rc, (uint32_t)(k5_lds_bytes(a) / 8));
+        else hipLaunchKernelGGL((k_sparse_frame<false>), grid, block, lds, st, a, rc, (uint32_t)(k5_lds_bytes(a) / 8));
+        return hipGetLastError();
+    }
     default:
         return hipErrorInvalidValue;
     }
@@ -2207,7 +2457,10 @@ int launch_kernel(int which, const ChainArgs &a, const RefineConsts &rc, void *s
 // agx_detector_create after hipSetDevice, once per handle (any number of devices per process).
 int init_device_kernels()
 {
-    return hipFuncSetAttribute((const void *)k_rare, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+    hipError_t e = hipFuncSetAttribute((const void *)k_rare, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_sparse_frame<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_sparse_frame<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+    return e;
 }
 
 // to_luma8 of one staged frame (detector.rs:507; image 0.25.9: Luma16 -> (v + 128) / 257, Rgb8 ->

@@ -21,7 +21,7 @@ using namespace agx;
 
 namespace {
 
-const char *kKernelNames[K_COUNT] = {"k_blur_hessian", "k_verify_seeds", "k_flood_refine", "k_rare_emit"};
+const char *kKernelNames[K_COUNT] = {"k_blur_hessian", "k_verify_seeds", "k_flood_refine", "k_rare_emit", "k_sparse_frame"};
 
 struct EventPair {
     hipEvent_t a, b;
@@ -42,6 +42,8 @@ struct agx_detector {
     uint32_t lim_cand = 0, lim_roots = 0, lim_out = 0;
     int force_generic = 0;
     int k1_rows = 0;
+    int sparse_path = 0;  // option "sparse_path": 0 = by batch size, 1 = K2 + K3 + K4 (three launches), 2 = k_sparse_frame (one)
+    bool last_sparse_frame = false;  // the last batch ran K1 + K_SPARSE
     int dbg = 0;
     float *d_dbg_resp = nullptr;  // lazily allocated plane for agx_debug_fetch(AGX_DBG_RESP_RECOMPUTED)
     long long dbg_resp_plane = 0;
@@ -369,7 +371,18 @@ int enqueue_chunk(agx_detector *d, int f0, int nf, hipStream_t st)
     a.roots += F0 * a.cap_roots;
     a.refined += F0 * a.cap_roots;
     if (a.frame_table) a.frame_table += F0 * 4;
-    for (int k = 0; k < K_COUNT; ++k) {
+    // The sparse phase: one workgroup per frame doing all of it (k_sparse_frame) when the batch fills the chip that way,
+    // else the three batch-wide launches.  (Timing ablations and the wave timeline instrument the three launches.)
+    int path = d->sparse_path;
+    if (const char *e = getenv("AGX_SPARSE_PATH")) path = atoi(e);
+    const int sparse_dbg = 32 | 64 | 128 | 256 | 2048 | 4096 | 8192 | 16384;  // debug_ablation bits that instrument K2 / K3 / K4
+    const bool fused = (path == 2 || (path == 0 && nf >= 192)) && !(a.dbg & sparse_dbg);
+    d->last_sparse_frame = fused;
+    const int plan_fused[] = {K_BLUR_HESSIAN, K_SPARSE}, plan_multi[] = {K_BLUR_HESSIAN, K_THRESHOLD, K_FLOOD_REFINE, K_RARE};
+    const int *plan = fused ? plan_fused : plan_multi;
+    const int n_plan = fused ? 2 : 4;
+    for (int pi = 0; pi < n_plan; ++pi) {
+        const int k = plan[pi];
         EventPair ev{nullptr, nullptr, k};
         // (an event pair costs the stream two ~5 us gaps around the kernel: level 1 can sample)
         const bool timed = d->profiling >= 2 || (d->profiling == 1 && k == d->prof_kernel && d->prof_batches % (uint64_t)d->prof_stride == (uint64_t)d->prof_stride - 1);  // the last of each group: never the first batch after an idle stream
@@ -658,6 +671,7 @@ int agx_detector_set_option(agx_detector *det, const char *name, int value)
     if (!det || !name) return AGX_ERR_ARG;
     if (!std::strcmp(name, "force_generic")) det->force_generic = value != 0;
     else if (!std::strcmp(name, "k1_rows_per_segment")) det->k1_rows = value > 0 ? value : 0;
+    else if (!std::strcmp(name, "sparse_path")) det->sparse_path = value >= 0 && value <= 2 ? value : 0;
     else if (!std::strcmp(name, "debug_ablation")) det->dbg = value;  // timing only, results invalid
     else if (!std::strcmp(name, "store_response")) det->store_resp = value != 0;
     else if (!std::strcmp(name, "profile_stride")) det->prof_stride = value > 1 ? value : 1;
@@ -683,6 +697,8 @@ int agx_detector_get_option(const agx_detector *det, const char *name, int *valu
     else if (!std::strcmp(name, "tail_threads")) *value = det->tail_threads;
     // the blur kernel's tiling of the last enqueued batch (0 before the first one)
     else if (!std::strcmp(name, "k1_rows_per_segment")) *value = a.rows_per_seg;
+    else if (!std::strcmp(name, "sparse_path")) *value = det->sparse_path;
+    else if (!std::strcmp(name, "last_sparse_path")) *value = det->last_sparse_frame ? 2 : 1;
     else if (!std::strcmp(name, "k1_segments")) *value = a.n_segs;
     else if (!std::strcmp(name, "k1_strips")) *value = a.n_strips;
     else if (!std::strcmp(name, "k1_strip_columns")) *value = a.strip_cols;

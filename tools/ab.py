@@ -27,7 +27,7 @@ for _ in range(40):
     det.saddles_batch_enqueue(frames)
 det.sync()
 p = det.profile_read()
-out = {k: v[0] / v[1] for k, v in p.items()}
+out = {k: v[0] / max(v[1], 1) for k, v in p.items()}
 out["wall"] = wall
 print("AB " + json.dumps(out))
 ''' % ROOT

@@ -22,7 +22,7 @@ def run(env):
     det.profile_enable(True); det.profile_reset()
     for _ in range(10): det.saddles_batch_enqueue(frames)
     det.sync(); p = det.profile_read(); det.profile_enable(False)
-    return wall, {k: v[0] / v[1] for k, v in p.items()}
+    return wall, {k: v[0] / max(v[1], 1) for k, v in p.items()}
 configs = [json.loads(x) for x in sys.argv[1:]] or [{}, {"AGX_G_FLOOD": "48"}, {"AGX_K1_STRIP_COLS": "216"}, {"AGX_K1_ROWS": "128"}]
 res = {i: [] for i in range(len(configs))}
 for rnd in range(6):
