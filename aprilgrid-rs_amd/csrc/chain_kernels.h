@@ -98,6 +98,7 @@ struct ChainArgs {
     int mask_yb;             // word rows: H/32 + 4
     long long mask_plane;    // words per frame = mask_wpr * mask_yb
     int force_generic;       // test hook: treat every frame as FLAG_BIG_CLUSTER
+    int sparse_after_verify; // k_sparse_frame runs behind k_verify_seeds (sparse path 3): it skips its own verify stage
     // debug_ablation & 4096: every wave of the sparse kernels records when it started and ended (100 MHz
     // constant clock, s_memrealtime) -- record (kernel - 1) * WAVE_TIMES_STRIDE + blockIdx.x of this array
     // (two 64-bit words each; the generic path's slot plane serves as storage).  Else null.

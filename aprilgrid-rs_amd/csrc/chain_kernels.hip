@@ -928,12 +928,30 @@ struct FrameLds {
     uint32_t *seeds;            // LDS [SEED_LDS_CAP]
 };
 
-// Tiles first_tile, first_tile + tile_stride, ... of `frame` by one wave.  FUSED = false: k_verify_seeds (the tile's seeds
-// are collected in the wave's LDS and appended to the frame's global list with one atomic per tile; s_nseeds / s_base are
-// the wave's own words).  FUSED = true: k_sparse_frame (seeds go straight into the workgroup's list `fl`).
-template <bool FUSED>
+// Seeds of one word row (lane = column): kw = the lane's verified word, upw = bit q set where the pixel above (column,
+// row q) is a candidate.  A seed is a candidate with no candidate to its left and none above, minus those whose run along
+// the row reaches (within 7 columns) a pixel with a candidate above it (see k_verify_seeds).  Valid in lanes 1 .. 56 of
+// a 64-lane tile (1 left halo lane, 7 look-ahead lanes).
+__device__ __forceinline__ uint32_t seed_bits(uint32_t kw, uint32_t upw)
+{
+    uint32_t sd = kw & ~from_left_u(kw) & ~upw;
+    uint32_t alive = sd, mk = kw, uk = upw;  // rows whose run still continues and has not met a pixel with one above
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+        mk = from_right_u(mk);
+        uk = from_right_u(uk);
+        alive &= mk;
+        const uint32_t kill = alive & uk;
+        sd &= ~kill;
+        alive &= ~kill;
+    }
+    return sd;
+}
+
+// Tiles first_tile, first_tile + tile_stride, ... of `frame` by one wave of k_verify_seeds (the tile's seeds are collected
+// in the wave's LDS and appended to the frame's global list with one atomic per tile; s_nseeds / s_base: the wave's own words).
 __device__ __forceinline__ void verify_tiles(const ChainArgs &a, int frame, int first_tile, int tile_stride, uint32_t *s_keep,
-                                             uint32_t *s_list, uint32_t *s_nseeds_p, uint32_t *s_base_p, const FrameLds &fl)
+                                             uint32_t *s_list, uint32_t *s_nseeds_p, uint32_t *s_base_p)
 {
     uint32_t *s_seeds = s_list;
     uint32_t &s_nseeds = *s_nseeds_p, &s_base = *s_base_p;
@@ -946,10 +964,8 @@ __device__ __forceinline__ void verify_tiles(const ChainArgs &a, int frame, int 
     const int n_yb = (a.H + 31) >> 5;
     const int groups = (W + VS_OWN - 1) / VS_OWN;
     const int tiles = ((n_yb + VS_ROWS - 1) / VS_ROWS) * groups;
-    if (!FUSED) {
-        if (lane == 0) s_nseeds = 0u;
-        wave_lds_sync();
-    }
+    if (lane == 0) s_nseeds = 0u;
+    wave_lds_sync();
     // debug_ablation & 8192: where a wave's time goes -- 10 ns ticks per phase summed into the frame's stats[0..5]
     // (first loads, block maxima + threshold, work list + re-tests, seeds, list append, rest), tiles in stats[7]
     const bool phase_on = (a.dbg & 8192) != 0;
@@ -1121,29 +1137,12 @@ __device__ __forceinline__ void verify_tiles(const ChainArgs &a, int frame, int 
             const uint32_t kw = keep[r];  // rows past the tile's end hold no bits
             const uint32_t upw = (kw << 1) | carry;  // bit q: the pixel above (column, row q) is a candidate
             carry = kw >> 31;
-            uint32_t sd = kw & ~from_left_u(kw) & ~upw;
-            uint32_t alive = sd, mk = kw, uk = upw;  // rows whose run still continues and has not met a pixel with one above
-#pragma unroll
-            for (int k = 1; k < 8; ++k) {
-                mk = from_right_u(mk);
-                uk = from_right_u(uk);
-                alive &= mk;
-                const uint32_t kill = alive & uk;
-                sd &= ~kill;
-                alive &= ~kill;
-            }
+            uint32_t sd = seed_bits(kw, upw);
             if (!owner) sd = 0u;
             while (sd) {
                 const int b = __ffs(sd) - 1;
                 sd &= sd - 1;
                 const uint32_t pix = (uint32_t)((yb0 + r) * 32 + b) * (uint32_t)W + (uint32_t)x;
-                if (FUSED) {  // the workgroup's list: LDS first, the frame's global list behind it
-                    const uint32_t i = atomicAdd(fl.n_seeds, 1u);
-                    if (i >= a.cap_roots) atomicOr(fl.flags, FLAG_CAND_OVERFLOW);
-                    else if (i < SEED_LDS_CAP) fl.seeds[i] = pix;
-                    else a.seeds[(size_t)frame * a.cap_roots + i] = pix;
-                    continue;
-                }
                 const uint32_t i = atomicAdd(&s_nseeds, 1u);
                 if (i < VS_SEEDS) {
                     s_seeds[i] = pix;
@@ -1153,10 +1152,6 @@ __device__ __forceinline__ void verify_tiles(const ChainArgs &a, int frame, int 
                     else atomicOr(&ctr.flags, FLAG_CAND_OVERFLOW);
                 }
             }
-        }
-        if (FUSED) {
-            phase(3);
-            continue;
         }
         // append the tile's seeds to the frame's list: one atomic, coalesced stores
         wave_lds_sync();
@@ -1189,8 +1184,479 @@ __global__ void __launch_bounds__(64 * VS_WAVES) AGX_VS_ATTR k_verify_seeds(Chai
     FrameSlot fs = frame_slot(a.n_frames, true);  // latest-written blur planes first (cache)
     fs.slot = fs.slot * VS_WAVES + (uint32_t)wv;  // this wave's slot of the frame
     fs.n_slots *= VS_WAVES;
-    verify_tiles<false>(a, fs.frame, (int)fs.slot, (int)fs.n_slots, s_keep_all[wv], s_list_all[wv], &s_nseeds_all[wv], &s_base_all[wv],
-                        FrameLds{nullptr, nullptr, nullptr});
+    verify_tiles(a, fs.frame, (int)fs.slot, (int)fs.n_slots, s_keep_all[wv], s_list_all[wv], &s_nseeds_all[wv], &s_base_all[wv]);
+}
+
+// ------------------------------------------------------------------------------------------
+// The verify + seed stage of ONE frame by the sixteen waves of a 1024-thread workgroup (k_sparse_frame) -- the same
+// results as k_verify_seeds' tiles, organised by round trips instead of by tiles:
+//   1  lane = column, tiles of 64 columns x VS_ROWS word rows, VF_TB tiles of a wave in flight together: the words and
+//      their blocks' weakest admitted candidates in one round trip; a word that needs the blur plane gets a slot (word
+//      index, pixel index of its bit 0, keep bits) in the wave's LDS and its set bits go into the wave's work list in
+//      ROW-MAJOR order (one ballot per (word row, bit) that any lane needs, as in k_verify_seeds);
+//   2  the wave's list -- all of its tiles' bits together, four per lane and round, 36 loads in flight --: failures
+//      clear their bit in the slot; the slots go back to the mask with plain stores (this CU's L1 stays coherent);
+// (The frame's clusters then come from frame_clusters; frames that do not fit its lists take frame_seeds + the floods.)
+// A frame's tiles are no longer a chain of two to three dependent round trips each (ten tiles per wave: 39 us per frame
+// with sixteen waves per frame) but about eight round trips per wave.
+// ------------------------------------------------------------------------------------------
+constexpr int VF_TB = 4;               // tiles in flight per wave
+constexpr uint32_t VFW_SLOTS = 256;    // re-tested words per wave and pass
+constexpr uint32_t VFW_LIST = 512;     // re-tested bits per wave and pass
+constexpr uint32_t VFW_WORDS = 3 * VFW_SLOTS + VFW_LIST;  // LDS words per wave
+struct VerifyLds {  // this wave's part
+    uint32_t *idx, *pix, *keep;  // [VFW_SLOTS]: word index in the frame's mask plane, pixel index of its bit 0, surviving bits
+    uint32_t *list;              // [VFW_LIST]: slot << 5 | bit
+};
+
+__device__ __forceinline__ void verify_frame(const ChainArgs &a, int frame, const VerifyLds &vl)
+{
+    const uint32_t t = threadIdx.x;
+    const int lane = (int)(t & 63u);
+    const int wv = __builtin_amdgcn_readfirstlane((int)(t >> 6));
+    FrameCounters &ctr = a.ctr[frame];
+    uint32_t *mask = a.mask + (size_t)frame * (size_t)a.mask_plane;
+    const float *blur = a.blur + (size_t)frame * (size_t)a.plane;
+    const float *cmax_f = a.cand_max + (size_t)frame * (size_t)a.mask_yb * (size_t)(a.mask_wpr >> 2);
+    const int W = a.W, wpr = a.mask_wpr;
+    const int n_yb = (a.H + 31) >> 5;
+    const int n_ch = (n_yb + VS_ROWS - 1) / VS_ROWS;
+    const float thr = f32_from_order_key(~ctr.min_key_inv) * 0.05f;  // detector.rs:418 (K1 is through)
+    auto stamp = [&](int which) {  // debug_ablation & 131072 (see k_sparse_frame)
+        if ((a.dbg & 131072) && t == 0) ctr.stats[which] = (uint32_t)wall_clock64();
+    };
+    // debug_ablation & 131072: where wave 0 spends the stage -- 10 ns ticks summed into the frame's stats[8..11]: waiting for the
+    // tiles' words, slots + work list, the list's re-tests, write-back
+    const bool wclk = (a.dbg & 131072) && wv == 0;
+    unsigned long long t_prev = wclk ? wall_clock64() : 0ull;
+    auto wphase = [&](int which) {
+        if (wclk) {
+            const unsigned long long now = wall_clock64();
+            if (lane == 0) ctr.stats[8 + which] += (uint32_t)(now - t_prev);
+            t_prev = now;
+        }
+    };
+    // ---- 1 + 2: the words that need the blur plane ----
+    uint32_t n_list = 0, n_slots = 0;  // wave-uniform
+    auto run_list = [&]() {
+        wphase(1);
+        wave_lds_sync();
+        constexpr int EB = 4;  // bits in flight per lane: 36 loads
+        for (uint32_t e0 = 0; e0 < n_list; e0 += 64u * EB) {
+            float d[EB];
+            uint32_t ent[EB];
+            bool on[EB];
+#pragma unroll
+            for (int k = 0; k < EB; ++k) {
+                const uint32_t e = e0 + (uint32_t)k * 64u + (uint32_t)lane;
+                on[k] = e < n_list;
+                ent[k] = vl.list[on[k] ? e : 0u];
+                d[k] = (a.dbg & 256) ? 0.0f : det_at(blur + (size_t)vl.pix[ent[k] >> 5] + (size_t)(ent[k] & 31u) * W, W);
+            }
+#pragma unroll
+            for (int k = 0; k < EB; ++k)
+                if (on[k] && !(d[k] < thr)) atomicAnd(&vl.keep[ent[k] >> 5], ~(1u << (ent[k] & 31u)));
+        }
+        wave_lds_sync();
+        n_list = 0;
+        wphase(2);
+    };
+    auto flush_slots = [&]() {
+        run_list();
+        for (uint32_t sl = (uint32_t)lane; sl < n_slots; sl += 64u) mask[vl.idx[sl]] = vl.keep[sl];
+        wave_lds_sync();
+        n_slots = 0;
+        wphase(3);
+    };
+    auto push = [&](bool mine, uint32_t entry) {  // one ballot: the lanes that have this (row, bit)
+        const unsigned long long bal = __ballot(mine);
+        const uint32_t k = (uint32_t)__popcll(bal);
+        if (n_list + k > VFW_LIST) run_list();
+        if ((a.dbg & 131072) && lane == 0) atomicAdd(&ctr.stats[14], k);  // re-tested bits of the frame
+        if (mine) vl.list[n_list + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = entry;
+        n_list += k;
+    };
+    {
+        const int groups = (W + 63) >> 6;  // tiles of 64 columns (no halo: every word belongs to one lane)
+        const int tiles = n_ch * groups;
+        for (int tb = wv; tb < tiles && !(a.dbg & 32); tb += 16 * VF_TB) {  // wave-uniform
+            uint32_t m[VF_TB][VS_ROWS];
+            float cm[VF_TB][VS_ROWS];
+#pragma unroll
+            for (int k = 0; k < VF_TB; ++k) {
+                const int tl = tb + 16 * k;
+                const bool tile_on = tl < tiles;  // wave-uniform
+                const int ch = tile_on ? tl / groups : 0, g = tile_on ? tl - ch * groups : 0;
+                const int x = g * 64 + lane;  // < W + 63: inside the mask's zero padding
+                const uint32_t *wp0 = mask + (size_t)(ch * VS_ROWS) * wpr + MASK_PAD_X + x;
+                const float *cp0 = cmax_f + (size_t)(ch * VS_ROWS) * (wpr >> 2) + ((MASK_PAD_X + x) >> 2);
+#pragma unroll
+                for (int r = 0; r < VS_ROWS; ++r) {  // (word rows past the image exist and are zero; their maxima are never looked at)
+                    m[k][r] = tile_on ? wp0[(size_t)r * wpr] : 0u;
+                    cm[k][r] = cp0[(size_t)r * (wpr >> 2)];
+                }
+            }
+            if (wclk) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                wphase(0);
+            }
+#pragma unroll
+            for (int k = 0; k < VF_TB; ++k) {
+                const int tl = tb + 16 * k;
+                if (tl >= tiles) break;  // wave-uniform
+                const int ch = tl / groups, g = tl - ch * groups;
+                const int yb0 = ch * VS_ROWS;
+                const int x = g * 64 + lane;
+                unsigned long long bal[VS_ROWS];
+                uint32_t nw = 0;
+#pragma unroll
+                for (int r = 0; r < VS_ROWS; ++r) {
+                    bal[r] = __ballot(m[k][r] != 0u && !(cm[k][r] < thr));
+                    nw += (uint32_t)__popcll(bal[r]);
+                }
+                if (nw == 0) continue;  // wave-uniform: nothing to re-test in this tile
+                if (n_slots + nw > VFW_SLOTS) flush_slots();
+#pragma unroll
+                for (int r = 0; r < VS_ROWS; ++r) {
+                    if (!bal[r]) continue;  // wave-uniform
+                    const bool need = (bal[r] >> lane) & 1ull;
+                    const uint32_t slot = n_slots + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal[r] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal[r], 0u));
+                    n_slots += (uint32_t)__popcll(bal[r]);
+                    const uint32_t mr = need ? m[k][r] : 0u;
+                    if (need) {
+                        vl.idx[slot] = (uint32_t)((yb0 + r) * wpr + MASK_PAD_X + x);
+                        vl.pix[slot] = (uint32_t)((yb0 + r) * 32) * (uint32_t)W + (uint32_t)x;
+                        vl.keep[slot] = mr;
+                    }
+                    uint32_t bits_any = mr;
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) bits_any |= __shfl_xor(bits_any, off, 64);
+                    bits_any = __builtin_amdgcn_readfirstlane(bits_any);
+                    while (bits_any) {  // scalar loop over the image rows of this word row that any lane needs
+                        const int b = __builtin_ctz(bits_any);
+                        bits_any &= bits_any - 1;
+                        push((mr >> b) & 1u, (slot << 5) | (uint32_t)b);
+                    }
+                }
+            }
+        }
+        flush_slots();
+    }
+    wphase(1);
+    __syncthreads();  // (workgroup scope: this CU's stores before this CU's loads)
+    stamp(4);
+}
+
+// Stage 3 of the flood path of k_sparse_frame (frames whose components do not fit frame_clusters' lists): the flood seeds
+// of the frame from its verified mask, tile by tile as in k_verify_seeds (lane = column, 1 + 7 halo lanes, DPP neighbours),
+// VF_TB tiles of a wave in flight, into the frame's seed list in LDS.
+__device__ __forceinline__ void frame_seeds(const ChainArgs &a, int frame, const FrameLds &fl)
+{
+    const uint32_t t = threadIdx.x;
+    const int lane = (int)(t & 63u);
+    const int wv = __builtin_amdgcn_readfirstlane((int)(t >> 6));
+    const uint32_t *mask = a.mask + (size_t)frame * (size_t)a.mask_plane;
+    const int W = a.W, wpr = a.mask_wpr;
+    const int n_ch = (((a.H + 31) >> 5) + VS_ROWS - 1) / VS_ROWS;
+    if (a.dbg & 64) return;
+    const int groups = (W + VS_OWN - 1) / VS_OWN;
+    const int tiles = n_ch * groups;
+    for (int tb = wv; tb < tiles; tb += 16 * VF_TB) {  // wave-uniform
+        uint32_t m[VF_TB][VS_ROWS], uw[VF_TB];
+#pragma unroll
+        for (int k = 0; k < VF_TB; ++k) {
+            const int tl = tb + 16 * k;
+            const bool tile_on = tl < tiles;
+            const int ch = tile_on ? tl / groups : 0, g = tile_on ? tl - ch * groups : 0;
+            const int yb0 = ch * VS_ROWS;
+            const int x = g * VS_OWN - 1 + lane;  // -1 .. W + 62: inside the mask's zero padding
+            const uint32_t *wp0 = mask + (size_t)yb0 * wpr + MASK_PAD_X + x;
+#pragma unroll
+            for (int r = 0; r < VS_ROWS; ++r) m[k][r] = tile_on ? wp0[(size_t)r * wpr] : 0u;
+            uw[k] = wp0[(ptrdiff_t)(yb0 > 0 ? -1 : 0) * wpr];
+        }
+#pragma unroll
+        for (int k = 0; k < VF_TB; ++k) {
+            const int tl = tb + 16 * k;
+            if (tl >= tiles) break;  // wave-uniform
+            const int ch = tl / groups, g = tl - ch * groups;
+            const int yb0 = ch * VS_ROWS;
+            const int x = g * VS_OWN - 1 + lane;
+            const bool owner = lane >= 1 && lane <= VS_OWN && x < W;
+            uint32_t carry = yb0 > 0 ? (uw[k] >> 31) : 0u;  // the pixel above row 0 of the tile: bit 31 of the word above
+#pragma unroll
+            for (int r = 0; r < VS_ROWS; ++r) {
+                const uint32_t kw = m[k][r];
+                const uint32_t upw = (kw << 1) | carry;  // bit q: the pixel above (column, row q) is a candidate
+                carry = kw >> 31;
+                if (!__any(kw != 0u)) continue;  // wave-uniform: most word rows of most tiles hold nothing
+                uint32_t sd = seed_bits(kw, upw);
+                if (!owner) sd = 0u;
+                while (sd) {
+                    const int b = __ffs(sd) - 1;
+                    sd &= sd - 1;
+                    const uint32_t pix = (uint32_t)((yb0 + r) * 32 + b) * (uint32_t)W + (uint32_t)x;
+                    const uint32_t i = atomicAdd(fl.n_seeds, 1u);  // the workgroup's list: LDS first, the frame's global list behind it
+                    if (i >= a.cap_roots) atomicOr(fl.flags, FLAG_CAND_OVERFLOW);
+                    else if (i < SEED_LDS_CAP) fl.seeds[i] = pix;
+                    else a.seeds[(size_t)frame * a.cap_roots + i] = pix;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// The clusters of ONE frame by connected-component labelling in LDS (k_sparse_frame) -- init_saddle_clusters
+// (detector.rs:171-187: the 4-connected components of the candidates, image_util.rs:208-236) and their centroid sums
+// (:421-429) without seeds and without floods.  With a workgroup per frame the frame's whole (sparse) mask fits LDS as
+// a sorted list of its non-zero words, so components are labelled directly:
+//   1  the sixteen waves scan the verified mask in address order (64 consecutive words per load, all of a wave's words
+//      in registers): count the non-zero words and their vertical runs; a second pass over the same registers writes
+//      the words, in order, into the list (word index | first run id, bits) and initialises one union-find node per run
+//      (ballot / bit-sliced prefix sums, no atomics);
+//   2  one thread per word: runs that touch a run of the word to the left (the previous list entry, if it is the
+//      neighbouring column) or the run that ends the word above (binary search in the list) are united -- lock-free
+//      union-find on LDS words, links from the larger id to the smaller;
+//   3  every run finds its root, roots take cluster slots, and every run adds its pixel count, coordinate sums and first
+//      pixel to its root's slot (LDS atomics): the cluster table (first pixel in raster order = the reference's emission
+//      rank, exact integer sums) that the flood path produces seed by seed.
+// Returns false (workgroup-uniform) when the frame does not fit the lists: the caller takes the flood path.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t CCL_NW = 6144;   // non-zero words
+constexpr uint32_t CCL_NR = 12288;  // runs (union-find nodes)
+constexpr uint32_t CCL_NC = 2048;   // clusters
+constexpr uint32_t CCL_NV = CCL_NC; // words whose first row continues a run of the word above, per pass of the vertical links
+constexpr int CCL_MAXG = 36;        // groups of 64 words per wave: frames of up to 36 864 mask words (1280 x 800: 35 200)
+constexpr int CCL_K = (int)(CCL_NW / 1024);  // list entries per thread in the prefix sum of the runs
+constexpr uint32_t CCL_IDX_BITS = 18, CCL_IDX_MASK = (1u << CCL_IDX_BITS) - 1u;  // list entry: word index | first run id << 18
+static_assert(CCL_NR <= (1u << (32 - CCL_IDX_BITS)), "run ids fit the entry");
+static_assert(CCL_NW % 1024 == 0, "whole entries per thread");
+struct CclLds {
+    uint32_t *ent, *bits;                 // [CCL_NW]
+    uint32_t *parent;                     // [CCL_NR]
+    uint32_t *s_n, *s_sx, *s_sy, *s_key;  // [CCL_NC]  (s_n doubles as the list of the vertical links before the slots are in use)
+    uint32_t *wave_tot;                   // [16]
+    uint32_t *n_clusters, *n_vert;
+};
+
+// inclusive prefix sum over the wave's lanes (DPP: four shifts within the rows of 16, two broadcasts across them)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+__device__ __forceinline__ uint32_t lds_find(uint32_t *parent, uint32_t x)
+{
+    for (;;) {
+        const uint32_t p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (p == x) return x;
+        x = p;
+    }
+}
+__device__ __forceinline__ void lds_unite(uint32_t *parent, uint32_t x, uint32_t y)
+{
+    for (;;) {
+        x = lds_find(parent, x);
+        y = lds_find(parent, y);
+        if (x == y) return;
+        if (x < y) {
+            const uint32_t tmp = x; x = y; y = tmp;
+        }
+        const uint32_t old = atomicCAS(&parent[x], x, y);
+        if (old == x) return;
+        x = old;
+    }
+}
+
+__device__ __forceinline__ bool frame_clusters(const ChainArgs &a, int frame, const CclLds &cl, uint32_t &n_clusters_out)
+{
+    const uint32_t t = threadIdx.x;
+    const int lane = (int)(t & 63u);
+    const int wv = __builtin_amdgcn_readfirstlane((int)(t >> 6));
+    const uint32_t *mask = a.mask + (size_t)frame * (size_t)a.mask_plane;
+    const uint32_t wpr = (uint32_t)a.mask_wpr, W = (uint32_t)a.W;
+    const uint32_t total = (uint32_t)((a.H + 31) >> 5) * wpr;  // the image's word rows, padding columns included (they are zero)
+    const uint32_t per_wave = (total + 1023u) >> 10;           // groups of 64 words per wave
+    if (per_wave > (uint32_t)CCL_MAXG || (uint64_t)a.mask_plane >= (1ull << CCL_IDX_BITS) || a.W >= 32768 || a.H >= 32768) return false;
+    const uint32_t base0 = (uint32_t)wv * per_wave * 64u;
+    FrameCounters &ctr = a.ctr[frame];
+    auto stamp = [&](int which) {  // debug_ablation & 131072 (see k_sparse_frame)
+        if ((a.dbg & 131072) && t == 0) ctr.stats[which] = (uint32_t)wall_clock64();
+    };
+    // 1a: the wave's words (address order), its number of non-zero ones
+    uint32_t w[CCL_MAXG];
+#pragma unroll
+    for (int g = 0; g < CCL_MAXG; ++g) {
+        const uint32_t idx = base0 + (uint32_t)g * 64u + (uint32_t)lane;
+        w[g] = ((uint32_t)g < per_wave && idx < total) ? mask[idx] : 0u;
+    }
+    uint32_t c_nz = 0;  // wave-uniform
+#pragma unroll
+    for (int g = 0; g < CCL_MAXG; ++g) c_nz += (uint32_t)__popcll(__ballot(w[g] != 0u));
+    if (lane == 0) cl.wave_tot[wv] = c_nz;
+    if (t == 0) {
+        *cl.n_clusters = 0u;
+        *cl.n_vert = 0u;
+    }
+    __syncthreads();
+    uint32_t off_nz = 0, n_words = 0;  // wave-uniform
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const uint32_t a0 = cl.wave_tot[v];
+        if (v < wv) off_nz += a0;
+        n_words += a0;
+    }
+    off_nz = __builtin_amdgcn_readfirstlane(off_nz);
+    n_words = __builtin_amdgcn_readfirstlane(n_words);
+    if ((a.dbg & 131072) && t == 0) ctr.stats[12] = n_words;
+    stamp(6);
+    if (n_words > CCL_NW) return false;  // workgroup-uniform
+    // 1b: the non-zero words into the list, in address order
+#pragma unroll
+    for (int g = 0; g < CCL_MAXG; ++g) {
+        const unsigned long long bz = __ballot(w[g] != 0u);
+        if (w[g]) {
+            const uint32_t pos = off_nz + __builtin_amdgcn_mbcnt_hi((uint32_t)(bz >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bz, 0u));
+            cl.ent[pos] = base0 + (uint32_t)g * 64u + (uint32_t)lane;
+            cl.bits[pos] = w[g];
+        }
+        off_nz += (uint32_t)__popcll(bz);
+    }
+    __syncthreads();
+    // 1c: run ids = prefix sum of the words' run counts in list order (CCL_K consecutive entries per thread); one union-find
+    // node per run
+    uint32_t n_runs;
+    {
+        uint32_t nr[CCL_K], mine = 0;
+#pragma unroll
+        for (int j = 0; j < CCL_K; ++j) {
+            const uint32_t e = t * (uint32_t)CCL_K + (uint32_t)j;
+            const uint32_t b = e < n_words ? cl.bits[e] : 0u;
+            nr[j] = (uint32_t)__popc(b & ~(b << 1));
+            mine += nr[j];
+        }
+        const uint32_t incl = wave_incl_scan(mine);
+        if (lane == 63) cl.wave_tot[16 + wv] = incl;
+        __syncthreads();
+        uint32_t off = 0, all = 0;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const uint32_t a0 = cl.wave_tot[16 + v];
+            if (v < wv) off += a0;
+            all += a0;
+        }
+        n_runs = __builtin_amdgcn_readfirstlane(all);
+        if ((a.dbg & 131072) && t == 0) ctr.stats[13] = n_runs;
+        if (n_runs > CCL_NR) return false;  // workgroup-uniform
+        uint32_t rb = off + incl - mine;
+#pragma unroll
+        for (int j = 0; j < CCL_K; ++j) {
+            const uint32_t e = t * (uint32_t)CCL_K + (uint32_t)j;
+            if (e < n_words) cl.ent[e] |= rb << CCL_IDX_BITS;
+            for (uint32_t k = 0; k < nr[j]; ++k) cl.parent[rb + k] = rb + k;
+            rb += nr[j];
+        }
+    }
+    __syncthreads();
+    stamp(7);
+    // 2a: links to the column on the left: the previous entry, if it is the neighbouring word (rows are separated by zero
+    // padding); the words whose first row may continue a run of the word above go into a list of their own
+    for (uint32_t e = t; e < n_words; e += 1024u) {
+        const uint32_t en = cl.ent[e], A = cl.bits[e];
+        const uint32_t wa = en & CCL_IDX_MASK, rb = en >> CCL_IDX_BITS;
+        if (e > 0) {
+            const uint32_t ep = cl.ent[e - 1];
+            if ((ep & CCL_IDX_MASK) == wa - 1u) {
+                const uint32_t B = cl.bits[e - 1], rbB = ep >> CCL_IDX_BITS;
+                const uint32_t sA = A & ~(A << 1), sB = B & ~(B << 1);
+                uint32_t c = A & B;  // every run of A & B joins one run of A and one run of B
+                while (c) {
+                    const uint32_t low = c & (0u - c), upto = low | (low - 1u);
+                    lds_unite(cl.parent, rb + (uint32_t)__popc(sA & upto) - 1u, rbB + (uint32_t)__popc(sB & upto) - 1u);
+                    c &= c + low;  // clears the lowest run
+                }
+            }
+        }
+        if ((A & 1u) && wa >= wpr) {
+            const uint32_t v = atomicAdd(cl.n_vert, 1u);
+            if (v < CCL_NV) cl.s_n[v] = e;
+        }
+    }
+    __syncthreads();
+    stamp(15);
+    // 2b: links to the word above (its last row is this word's row -1): binary search in the list, which is in address order
+    const uint32_t n_vert = *cl.n_vert;
+    if (n_vert > CCL_NV) return false;  // workgroup-uniform
+    for (uint32_t v = t; v < n_vert; v += 1024u) {
+        const uint32_t e = cl.s_n[v];
+        const uint32_t en = cl.ent[e];
+        const uint32_t target = (en & CCL_IDX_MASK) - wpr;
+        uint32_t lo = 0, hi = e;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if ((cl.ent[mid] & CCL_IDX_MASK) < target) lo = mid + 1;
+            else hi = mid;
+        }
+        if (lo < e) {
+            const uint32_t ef = cl.ent[lo];
+            if ((ef & CCL_IDX_MASK) == target) {
+                const uint32_t B = cl.bits[lo];
+                if (B >> 31) lds_unite(cl.parent, en >> CCL_IDX_BITS, (ef >> CCL_IDX_BITS) + (uint32_t)__popc(B & ~(B << 1)) - 1u);
+            }
+        }
+    }
+    __syncthreads();
+    stamp(16);
+    // 3a: every run points at its root (safe while others still search: a link only ever moves towards the root); roots take
+    // cluster slots behind a barrier (tagged in place); the slots' sums are cleared
+    for (uint32_t r = t; r < n_runs; r += 1024u) {
+        const uint32_t root = lds_find(cl.parent, r);
+        __hip_atomic_store(&cl.parent[r], root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    for (uint32_t sl = t; sl < CCL_NC; sl += 1024u) {
+        cl.s_n[sl] = 0u;
+        cl.s_sx[sl] = 0u;
+        cl.s_sy[sl] = 0u;
+        cl.s_key[sl] = 0xffffffffu;
+    }
+    __syncthreads();
+    for (uint32_t r = t; r < n_runs; r += 1024u)
+        if (cl.parent[r] == r) cl.parent[r] = 0x80000000u | atomicAdd(cl.n_clusters, 1u);
+    __syncthreads();
+    stamp(17);
+    const uint32_t nc = *cl.n_clusters;
+    if (nc > CCL_NC) return false;  // workgroup-uniform
+    // 3b: pixel count, coordinate sums and first pixel of every run into its root's slot
+    for (uint32_t e = t; e < n_words; e += 1024u) {
+        const uint32_t en = cl.ent[e];
+        const uint32_t wa = en & CCL_IDX_MASK, rb = en >> CCL_IDX_BITS;
+        const uint32_t yb = wa / wpr, x = wa - yb * wpr - (uint32_t)MASK_PAD_X;
+        uint32_t m = cl.bits[e], k = 0;
+        while (m) {
+            const uint32_t low = m & (0u - m), next = m + low;
+            const uint32_t run = m & ~next;  // the lowest run
+            m &= next;
+            const uint32_t L = (uint32_t)__popc(run), row0 = yb * 32u + (uint32_t)(__ffs(low) - 1);
+            const uint32_t pr = cl.parent[rb + k];
+            const uint32_t sl = ((pr & 0x80000000u) ? pr : cl.parent[pr]) & 0x7fffffffu;
+            atomicAdd(&cl.s_n[sl], L);
+            atomicAdd(&cl.s_sx[sl], L * x);
+            atomicAdd(&cl.s_sy[sl], L * row0 + ((L * (L - 1u)) >> 1));
+            atomicMin(&cl.s_key[sl], row0 * W + x);
+            ++k;
+        }
+    }
+    __syncthreads();
+    stamp(18);
+    n_clusters_out = nc;
+    return true;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2208,17 +2674,19 @@ __global__ void __launch_bounds__(1024) k_rare(ChainArgs a, RefineConsts rc, uin
 // global-memory path (rare_frame), as under k_rare.  Used for batches that fill the chip with one workgroup per frame;
 // smaller batches keep the three launches (plan: launch_kernel / use_sparse_frame).
 // ------------------------------------------------------------------------------------------
-constexpr uint32_t SF_MISC = 16;                                   // LDS words: counters (below)
-constexpr uint32_t SF_SEEDS = SF_MISC;                             // [SEED_LDS_CAP]
-constexpr uint32_t SF_REC = SF_SEEDS + SEED_LDS_CAP;               // [6][TAIL_CAP]
-constexpr uint32_t SF_WAVE = SF_REC + 6 * TAIL_CAP;                // per wave: keep words, re-test list
-constexpr uint32_t SF_WAVE_WORDS = (VS_ROWS + 1) * 64 + VS_LIST;
-constexpr uint32_t SF_WORDS = SF_WAVE + 16 * SF_WAVE_WORDS;
-static_assert(16 * SF_WAVE_WORDS >= TAIL_CAP + 8, "the emission's keys reuse the waves' verify scratch");
-static_assert(SF_SEEDS % 4 == 0 && SF_REC % 4 == 0 && SF_WAVE % 4 == 0, "16-byte aligned parts");
-enum : int { SFM_SEEDS = 0, SFM_FLAGS = 1, SFM_CLUSTERS = 2, SFM_REFINED = 3, SFM_MAXK = 4, SFM_BIG = 5, SFM_EMIT = 8, SFM_RARE = 12 };
+constexpr uint32_t SF_MISC = 64;                                   // LDS words: counters (below), per-wave totals of frame_clusters
+constexpr uint32_t SF_REC = SF_MISC;                               // refined records [6][TAIL_CAP]
+constexpr uint32_t SF_R = SF_REC + 6 * TAIL_CAP;                   // one region, used in turn by: verify_frame (VFW_WORDS per wave),
+                                                                   // frame_clusters' lists -- or the flood path's seeds --, the emission's keys
+constexpr uint32_t SF_CCL_WORDS = 2 * CCL_NW + CCL_NR + 4 * CCL_NC;
+constexpr uint32_t SF_R_WORDS = 16 * VFW_WORDS > SF_CCL_WORDS ? 16 * VFW_WORDS : SF_CCL_WORDS;
+constexpr uint32_t SF_WORDS = SF_R + SF_R_WORDS;
+static_assert(SF_R_WORDS >= TAIL_CAP + 8 && SF_R_WORDS >= SEED_LDS_CAP, "the emission's keys and the flood path's seeds fit the shared region");
+static_assert(SF_REC % 4 == 0 && SF_R % 4 == 0, "16-byte aligned parts");
+static_assert(SF_WORDS * 4 <= 160 * 1024 - 1024, "fits a CU's LDS");
+enum : int { SFM_SEEDS = 0, SFM_FLAGS = 1, SFM_CLUSTERS = 2, SFM_REFINED = 3, SFM_MAXK = 4, SFM_BIG = 5, SFM_CCL_N = 6, SFM_CCL_V = 7, SFM_EMIT = 8, SFM_RARE = 12, SFM_WAVE_TOT = 16 };
 
-template <bool VEC>
+template <bool VEC, typename CLK>
 __global__ void __launch_bounds__(1024) k_sparse_frame(ChainArgs a, RefineConsts rc, uint32_t lds_entries)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
@@ -2231,31 +2699,82 @@ __global__ void __launch_bounds__(1024) k_sparse_frame(ChainArgs a, RefineConsts
     if (t < SF_MISC) misc[t] = 0u;
     __syncthreads();
     FrameCounters &ctr = a.ctr[frame];
-    const FrameLds fl{&misc[SFM_SEEDS], &misc[SFM_FLAGS], lds_u + SF_SEEDS};
+    // debug_ablation & 131072: when the frame's workgroup passed its stages (10 ns ticks of the constant clock, low 32 bits)
+    // into the frame's stats[0..4]: start, verify done, flood + refine done, end (tools/sparse_frame_phases.py)
+    auto stamp = [&](int which) {
+        if ((a.dbg & 131072) && t == 0) ctr.stats[which] = (uint32_t)wall_clock64();
+    };
+    stamp(0);
+    const FrameLds fl{&misc[SFM_SEEDS], &misc[SFM_FLAGS], lds_u + SF_R};
     const size_t cbase = (size_t)frame * a.cap_roots;
-    // ---- verify: the frame's tiles, sixteen at a time ----
-    {
-        uint32_t *wave_lds = lds_u + SF_WAVE + (uint32_t)wv * SF_WAVE_WORDS;
-        verify_tiles<true>(a, frame, wv, 16, wave_lds, wave_lds + (VS_ROWS + 1) * 64, nullptr, nullptr, fl);
+    const float *img = a.blur + (size_t)frame * (size_t)a.plane;
+    const RecSinkLds sink{&misc[SFM_REFINED], &misc[SFM_MAXK], &misc[SFM_FLAGS], lds_u + SF_REC};
+    // ---- verify ----
+    if (a.sparse_after_verify) {  // k_verify_seeds has run as a launch of its own: the frame's seeds are in its global list
+        if (t == 0) {
+            misc[SFM_SEEDS] = __hip_atomic_load(&ctr.n_seeds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            misc[SFM_FLAGS] = __hip_atomic_load(&ctr.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+    } else {
+        uint32_t *wl = lds_u + SF_R + (uint32_t)wv * VFW_WORDS;
+        verify_frame(a, frame, VerifyLds{wl, wl + VFW_SLOTS, wl + 2 * VFW_SLOTS, wl + 3 * VFW_SLOTS});  // (ends with a barrier: the mask is final)
     }
-    __syncthreads();  // the verified mask (global, this CU's stores) and the seed list are complete
-    // ---- flood + refine: one seed per lane ----
-    const uint32_t n_seeds_raw = misc[SFM_SEEDS];
-    if (!a.force_generic && n_seeds_raw <= a.cap_roots && !(misc[SFM_FLAGS] & FLAG_CAND_OVERFLOW)) {
+    stamp(1);
+    // ---- clusters: labelled in LDS ... ----
+    uint32_t n_ccl = 0;
+    bool ccl = false;
+    if (!a.force_generic && !a.sparse_after_verify && !(a.dbg & 524288)) {  // (524288: A/B, the flood path for every frame)
+        uint32_t *r = lds_u + SF_R;
+        const CclLds cl{r, r + CCL_NW, r + 2 * CCL_NW, r + 2 * CCL_NW + CCL_NR, r + 2 * CCL_NW + CCL_NR + CCL_NC,
+                        r + 2 * CCL_NW + CCL_NR + 2 * CCL_NC, r + 2 * CCL_NW + CCL_NR + 3 * CCL_NC, &misc[SFM_WAVE_TOT], &misc[SFM_CCL_N], &misc[SFM_CCL_V]};
+        ccl = frame_clusters(a, frame, cl, n_ccl);
+        stamp(5);
+        if (ccl && n_ccl <= a.cap_roots) {  // ... and refined, one cluster per lane
+            NoClock clk;
+            for (uint32_t base = (uint32_t)wv * 64u; base < n_ccl; base += 1024u) {  // wave-uniform trip count
+                const uint32_t sl = base + (uint32_t)lane;
+                if (sl < n_ccl) {
+                    const uint32_t key = cl.s_key[sl], cnt = cl.s_n[sl];
+                    float cx, cy;
+                    refine_values<VEC>(a, rc, frame, img, a.W, a.H, key, cnt, cl.s_sx[sl], cl.s_sy[sl], sink, cx, cy, clk);
+                    a.clu_key[cbase + sl] = key;  // the cluster table (agx_debug_fetch)
+                    a.clu_cnt[cbase + sl] = cnt;
+                    a.clu_sx[cbase + sl] = __float_as_uint(cx);
+                    a.clu_sy[cbase + sl] = __float_as_uint(cy);
+                }
+            }
+            if (t == 0) misc[SFM_CLUSTERS] = n_ccl;
+        } else if (ccl && t == 0) {
+            misc[SFM_CLUSTERS] = n_ccl;
+            misc[SFM_FLAGS] |= FLAG_ROOT_OVERFLOW;
+        }
+    }
+    // ---- ... or, for frames beyond its lists, flood seeds + one flood per lane ----
+    if (!ccl && !a.sparse_after_verify) {
+        __syncthreads();  // (frame_clusters' lists are dead: the seeds take their place)
+        frame_seeds(a, frame, fl);
+        __syncthreads();  // the seed list is complete
+    }
+    const uint32_t n_seeds_raw = ccl ? 0u : misc[SFM_SEEDS];
+    if (!ccl && !a.force_generic && n_seeds_raw <= a.cap_roots && !(misc[SFM_FLAGS] & FLAG_CAND_OVERFLOW)) {
         const uint32_t n = n_seeds_raw;
         const uint32_t *mask = a.mask + (size_t)frame * (size_t)a.mask_plane;
-        const float *img = a.blur + (size_t)frame * (size_t)a.plane;
         const uint32_t W = (uint32_t)a.W;
-        const RecSinkLds sink{&misc[SFM_REFINED], &misc[SFM_MAXK], &misc[SFM_FLAGS], lds_u + SF_REC};
-        NoClock clk;
+        CLK clk;  // (debug_ablation & 262144: the PhaseClock instantiation, tools/flood_phases.py)
+        clk.start(ctr.stats);
         for (uint32_t base = (uint32_t)wv * 64u; base < n; base += 1024u) {  // wave-uniform trip count
             const uint32_t i = base + (uint32_t)lane;
             uint32_t p = 0u, cnt = 0, sumx = 0, sumy = 0;
             int what = FLOOD_NONE;
+            if (CLK::on && lane == 0) atomicAdd(&ctr.stats[19], 1u);  // chunks
+            clk.mark(8);
             if (i < n) {
-                p = i < SEED_LDS_CAP ? fl.seeds[i] : a.seeds[cbase + i];
+                p = (i < SEED_LDS_CAP && !a.sparse_after_verify) ? fl.seeds[i] : a.seeds[cbase + i];
                 what = flood_lane(a, mask, W, p, cnt, sumx, sumy, clk);
             }
+            clk.join();
+            clk.mark(10);  // the flood's sweeps
             // second tier: see k_flood_refine
             unsigned long long big = __ballot(what == FLOOD_BIG);
             if (big && lane == 0) atomicAdd(&misc[SFM_BIG], (uint32_t)__popcll(big));
@@ -2271,6 +2790,11 @@ __global__ void __launch_bounds__(1024) k_sparse_frame(ChainArgs a, RefineConsts
                     sumy = y2;
                 }
             }
+            clk.mark(14);  // second tier
+            if (CLK::on) {
+                const unsigned long long act = __ballot(what == FLOOD_CLUSTER);
+                if (lane == 0) atomicAdd(&ctr.stats[18], (uint32_t)__popcll(act));  // clusters refined
+            }
             if (what == FLOOD_CLUSTER) {
                 const uint32_t o = atomicAdd(&misc[SFM_CLUSTERS], 1u);
                 float cx, cy;
@@ -2284,9 +2808,12 @@ __global__ void __launch_bounds__(1024) k_sparse_frame(ChainArgs a, RefineConsts
                     atomicOr(&misc[SFM_FLAGS], FLAG_ROOT_OVERFLOW);
                 }
             }
+            clk.join();
+            clk.mark(7);  // record stores, lanes without a record
         }
     }  // (a seed list beyond cap_roots has set FLAG_CAND_OVERFLOW in verify_tiles: the frame is reported, not processed)
     __syncthreads();
+    stamp(2);
     const uint32_t flags = misc[SFM_FLAGS], n_ref = misc[SFM_REFINED], n_clu = min(misc[SFM_CLUSTERS], a.cap_roots);
     const bool void_frame = (flags & (FLAG_CAND_OVERFLOW | FLAG_ROOT_OVERFLOW)) != 0;
     const bool generic = a.force_generic || (flags & FLAG_BIG_CLUSTER);
@@ -2304,8 +2831,9 @@ __global__ void __launch_bounds__(1024) k_sparse_frame(ChainArgs a, RefineConsts
         rare_frame(a, rc, frame, lds_u + SF_MISC, lds_entries, &misc[SFM_RARE]);  // (everything behind the counters is free now)
         return;
     }
-    emit_wide_lds(a, frame, void_frame ? 0u : n_ref, misc[SFM_MAXK], lds_u + SF_REC, lds_u + SF_WAVE, &misc[SFM_EMIT], &misc[SFM_FLAGS], n_clu);
+    emit_wide_lds(a, frame, void_frame ? 0u : n_ref, misc[SFM_MAXK], lds_u + SF_REC, lds_u + SF_R, &misc[SFM_EMIT], &misc[SFM_FLAGS], n_clu);
     if (t == 0) ctr.flags = misc[SFM_FLAGS];  // (behind emit_wide_lds's last barrier: OUT_OVERFLOW included)
+    stamp(3);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2444,8 +2972,12 @@ int launch_kernel(int which, const ChainArgs &a, const RefineConsts &rc, void *s
     case K_SPARSE: {
         const size_t lds = sparse_frame_lds_bytes(a);
         dim3 grid(a.n_frames), block(1024);
-        if ((a.W & 3) == 0) hipLaunchKernelGGL((k_sparse_frame<true>), grid, block, lds, st, a, rc, (uint32_t)(k5_lds_bytes(a) / 8));
-        else hipLaunchKernelGGL((k_sparse_frame<false>), grid, block, lds, st, a, rc, (uint32_t)(k5_lds_bytes(a) / 8));
+        const uint32_t le = (uint32_t)(k5_lds_bytes(a) / 8);
+        if (a.dbg & 262144) {  // phase timeline of the flood + refine stage (tools/flood_phases.py)
+            if ((a.W & 3) == 0) hipLaunchKernelGGL((k_sparse_frame<true, PhaseClock>), grid, block, lds, st, a, rc, le);
+            else hipLaunchKernelGGL((k_sparse_frame<false, PhaseClock>), grid, block, lds, st, a, rc, le);
+        } else if ((a.W & 3) == 0) hipLaunchKernelGGL((k_sparse_frame<true, NoClock>), grid, block, lds, st, a, rc, le);
+        else hipLaunchKernelGGL((k_sparse_frame<false, NoClock>), grid, block, lds, st, a, rc, le);
         return hipGetLastError();
     }
     default:
@@ -2458,8 +2990,10 @@ int launch_kernel(int which, const ChainArgs &a, const RefineConsts &rc, void *s
 int init_device_kernels()
 {
     hipError_t e = hipFuncSetAttribute((const void *)k_rare, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_sparse_frame<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_sparse_frame<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_sparse_frame<true, NoClock>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_sparse_frame<false, NoClock>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_sparse_frame<true, PhaseClock>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_sparse_frame<false, PhaseClock>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
     return e;
 }
 

@@ -376,11 +376,13 @@ int enqueue_chunk(agx_detector *d, int f0, int nf, hipStream_t st)
     int path = d->sparse_path;
     if (const char *e = getenv("AGX_SPARSE_PATH")) path = atoi(e);
     const int sparse_dbg = 32 | 64 | 128 | 256 | 2048 | 4096 | 8192 | 16384;  // debug_ablation bits that instrument K2 / K3 / K4
-    const bool fused = (path == 2 || (path == 0 && nf >= 192)) && !(a.dbg & sparse_dbg);
+    const bool fused = (path == 2 || path == 3 || (path == 0 && nf >= 192)) && !(a.dbg & sparse_dbg);
     d->last_sparse_frame = fused;
-    const int plan_fused[] = {K_BLUR_HESSIAN, K_SPARSE}, plan_multi[] = {K_BLUR_HESSIAN, K_THRESHOLD, K_FLOOD_REFINE, K_RARE};
-    const int *plan = fused ? plan_fused : plan_multi;
-    const int n_plan = fused ? 2 : 4;
+    a.sparse_after_verify = fused && path == 3;
+    const int plan_fused[] = {K_BLUR_HESSIAN, K_SPARSE}, plan_multi[] = {K_BLUR_HESSIAN, K_THRESHOLD, K_FLOOD_REFINE, K_RARE},
+              plan_v_fe[] = {K_BLUR_HESSIAN, K_THRESHOLD, K_SPARSE};
+    const int *plan = fused ? (path == 3 ? plan_v_fe : plan_fused) : plan_multi;
+    const int n_plan = fused ? (path == 3 ? 3 : 2) : 4;
     for (int pi = 0; pi < n_plan; ++pi) {
         const int k = plan[pi];
         EventPair ev{nullptr, nullptr, k};
@@ -671,7 +673,7 @@ int agx_detector_set_option(agx_detector *det, const char *name, int value)
     if (!det || !name) return AGX_ERR_ARG;
     if (!std::strcmp(name, "force_generic")) det->force_generic = value != 0;
     else if (!std::strcmp(name, "k1_rows_per_segment")) det->k1_rows = value > 0 ? value : 0;
-    else if (!std::strcmp(name, "sparse_path")) det->sparse_path = value >= 0 && value <= 2 ? value : 0;
+    else if (!std::strcmp(name, "sparse_path")) det->sparse_path = value >= 0 && value <= 3 ? value : 0;
     else if (!std::strcmp(name, "debug_ablation")) det->dbg = value;  // timing only, results invalid
     else if (!std::strcmp(name, "store_response")) det->store_resp = value != 0;
     else if (!std::strcmp(name, "profile_stride")) det->prof_stride = value > 1 ? value : 1;

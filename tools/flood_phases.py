@@ -8,7 +8,9 @@ from aprilgrid_rs_amd import synth
 F = int(os.environ.get("FRAMES", "256"))
 frames, _ = synth.render_batch(0, F, 1280, 800, device="cuda")
 det = A.TagDetector("t36h11")
-det.set_option("debug_ablation", 16384)
+FUSED = os.environ.get("FUSED", "0") == "1"  # the flood + refine stage of k_sparse_frame instead of k_flood_refine
+det.set_option("sparse_path", 2 if FUSED else 1)
+det.set_option("debug_ablation", 262144 if FUSED else 16384)
 for _ in range(3):
     det.saddles_batch_enqueue(frames); det.sync()
 tot = np.zeros(20, np.int64)
