@@ -1196,7 +1196,8 @@ __global__ void __launch_bounds__(64 * VS_WAVES) AGX_VS_ATTR k_verify_seeds(Chai
 //      ROW-MAJOR order (one ballot per (word row, bit) that any lane needs, as in k_verify_seeds);
 //   2  the wave's list -- all of its tiles' bits together, four per lane and round, 36 loads in flight --: failures
 //      clear their bit in the slot; the slots go back to the mask with plain stores (this CU's L1 stays coherent);
-// (The frame's clusters then come from frame_clusters; frames that do not fit its lists take frame_seeds + the floods.)
+// The seeds then come from frame_seeds (a pass of its own over the verified mask: a seed depends on the verified words of up to
+// eight neighbouring columns and the row above, which other waves own).
 // A frame's tiles are no longer a chain of two to three dependent round trips each (ten tiles per wave: 39 us per frame
 // with sixteen waves per frame) but about eight round trips per wave.
 // ------------------------------------------------------------------------------------------
@@ -1347,7 +1348,7 @@ __device__ __forceinline__ void verify_frame(const ChainArgs &a, int frame, cons
     stamp(4);
 }
 
-// Stage 3 of the flood path of k_sparse_frame (frames whose components do not fit frame_clusters' lists): the flood seeds
+// Stage 3 of k_sparse_frame: the flood seeds
 // of the frame from its verified mask, tile by tile as in k_verify_seeds (lane = column, 1 + 7 halo lanes, DPP neighbours),
 // VF_TB tiles of a wave in flight, into the frame's seed list in LDS.
 __device__ __forceinline__ void frame_seeds(const ChainArgs &a, int frame, const FrameLds &fl)
@@ -1406,258 +1407,6 @@ __device__ __forceinline__ void frame_seeds(const ChainArgs &a, int frame, const
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// The clusters of ONE frame by connected-component labelling in LDS (k_sparse_frame) -- init_saddle_clusters
-// (detector.rs:171-187: the 4-connected components of the candidates, image_util.rs:208-236) and their centroid sums
-// (:421-429) without seeds and without floods.  With a workgroup per frame the frame's whole (sparse) mask fits LDS as
-// a sorted list of its non-zero words, so components are labelled directly:
-//   1  the sixteen waves scan the verified mask in address order (64 consecutive words per load, all of a wave's words
-//      in registers): count the non-zero words and their vertical runs; a second pass over the same registers writes
-//      the words, in order, into the list (word index | first run id, bits) and initialises one union-find node per run
-//      (ballot / bit-sliced prefix sums, no atomics);
-//   2  one thread per word: runs that touch a run of the word to the left (the previous list entry, if it is the
-//      neighbouring column) or the run that ends the word above (binary search in the list) are united -- lock-free
-//      union-find on LDS words, links from the larger id to the smaller;
-//   3  every run finds its root, roots take cluster slots, and every run adds its pixel count, coordinate sums and first
-//      pixel to its root's slot (LDS atomics): the cluster table (first pixel in raster order = the reference's emission
-//      rank, exact integer sums) that the flood path produces seed by seed.
-// Returns false (workgroup-uniform) when the frame does not fit the lists: the caller takes the flood path.
-// ------------------------------------------------------------------------------------------
-constexpr uint32_t CCL_NW = 6144;   // non-zero words
-constexpr uint32_t CCL_NR = 12288;  // runs (union-find nodes)
-constexpr uint32_t CCL_NC = 2048;   // clusters
-constexpr uint32_t CCL_NV = CCL_NC; // words whose first row continues a run of the word above, per pass of the vertical links
-constexpr int CCL_MAXG = 36;        // groups of 64 words per wave: frames of up to 36 864 mask words (1280 x 800: 35 200)
-constexpr int CCL_K = (int)(CCL_NW / 1024);  // list entries per thread in the prefix sum of the runs
-constexpr uint32_t CCL_IDX_BITS = 18, CCL_IDX_MASK = (1u << CCL_IDX_BITS) - 1u;  // list entry: word index | first run id << 18
-static_assert(CCL_NR <= (1u << (32 - CCL_IDX_BITS)), "run ids fit the entry");
-static_assert(CCL_NW % 1024 == 0, "whole entries per thread");
-struct CclLds {
-    uint32_t *ent, *bits;                 // [CCL_NW]
-    uint32_t *parent;                     // [CCL_NR]
-    uint32_t *s_n, *s_sx, *s_sy, *s_key;  // [CCL_NC]  (s_n doubles as the list of the vertical links before the slots are in use)
-    uint32_t *wave_tot;                   // [16]
-    uint32_t *n_clusters, *n_vert;
-};
-
-// inclusive prefix sum over the wave's lanes (DPP: four shifts within the rows of 16, two broadcasts across them)
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
-{
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);   // row_shr:1
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);   // row_shr:2
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);   // row_shr:4
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);   // row_shr:8
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
-    return v;
-}
-
-__device__ __forceinline__ uint32_t lds_find(uint32_t *parent, uint32_t x)
-{
-    for (;;) {
-        const uint32_t p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (p == x) return x;
-        x = p;
-    }
-}
-__device__ __forceinline__ void lds_unite(uint32_t *parent, uint32_t x, uint32_t y)
-{
-    for (;;) {
-        x = lds_find(parent, x);
-        y = lds_find(parent, y);
-        if (x == y) return;
-        if (x < y) {
-            const uint32_t tmp = x; x = y; y = tmp;
-        }
-        const uint32_t old = atomicCAS(&parent[x], x, y);
-        if (old == x) return;
-        x = old;
-    }
-}
-
-__device__ __forceinline__ bool frame_clusters(const ChainArgs &a, int frame, const CclLds &cl, uint32_t &n_clusters_out)
-{
-    const uint32_t t = threadIdx.x;
-    const int lane = (int)(t & 63u);
-    const int wv = __builtin_amdgcn_readfirstlane((int)(t >> 6));
-    const uint32_t *mask = a.mask + (size_t)frame * (size_t)a.mask_plane;
-    const uint32_t wpr = (uint32_t)a.mask_wpr, W = (uint32_t)a.W;
-    const uint32_t total = (uint32_t)((a.H + 31) >> 5) * wpr;  // the image's word rows, padding columns included (they are zero)
-    const uint32_t per_wave = (total + 1023u) >> 10;           // groups of 64 words per wave
-    if (per_wave > (uint32_t)CCL_MAXG || (uint64_t)a.mask_plane >= (1ull << CCL_IDX_BITS) || a.W >= 32768 || a.H >= 32768) return false;
-    const uint32_t base0 = (uint32_t)wv * per_wave * 64u;
-    FrameCounters &ctr = a.ctr[frame];
-    auto stamp = [&](int which) {  // debug_ablation & 131072 (see k_sparse_frame)
-        if ((a.dbg & 131072) && t == 0) ctr.stats[which] = (uint32_t)wall_clock64();
-    };
-    // 1a: the wave's words (address order), its number of non-zero ones
-    uint32_t w[CCL_MAXG];
-#pragma unroll
-    for (int g = 0; g < CCL_MAXG; ++g) {
-        const uint32_t idx = base0 + (uint32_t)g * 64u + (uint32_t)lane;
-        w[g] = ((uint32_t)g < per_wave && idx < total) ? mask[idx] : 0u;
-    }
-    uint32_t c_nz = 0;  // wave-uniform
-#pragma unroll
-    for (int g = 0; g < CCL_MAXG; ++g) c_nz += (uint32_t)__popcll(__ballot(w[g] != 0u));
-    if (lane == 0) cl.wave_tot[wv] = c_nz;
-    if (t == 0) {
-        *cl.n_clusters = 0u;
-        *cl.n_vert = 0u;
-    }
-    __syncthreads();
-    uint32_t off_nz = 0, n_words = 0;  // wave-uniform
-#pragma unroll
-    for (int v = 0; v < 16; ++v) {
-        const uint32_t a0 = cl.wave_tot[v];
-        if (v < wv) off_nz += a0;
-        n_words += a0;
-    }
-    off_nz = __builtin_amdgcn_readfirstlane(off_nz);
-    n_words = __builtin_amdgcn_readfirstlane(n_words);
-    if ((a.dbg & 131072) && t == 0) ctr.stats[12] = n_words;
-    stamp(6);
-    if (n_words > CCL_NW) return false;  // workgroup-uniform
-    // 1b: the non-zero words into the list, in address order
-#pragma unroll
-    for (int g = 0; g < CCL_MAXG; ++g) {
-        const unsigned long long bz = __ballot(w[g] != 0u);
-        if (w[g]) {
-            const uint32_t pos = off_nz + __builtin_amdgcn_mbcnt_hi((uint32_t)(bz >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bz, 0u));
-            cl.ent[pos] = base0 + (uint32_t)g * 64u + (uint32_t)lane;
-            cl.bits[pos] = w[g];
-        }
-        off_nz += (uint32_t)__popcll(bz);
-    }
-    __syncthreads();
-    // 1c: run ids = prefix sum of the words' run counts in list order (CCL_K consecutive entries per thread); one union-find
-    // node per run
-    uint32_t n_runs;
-    {
-        uint32_t nr[CCL_K], mine = 0;
-#pragma unroll
-        for (int j = 0; j < CCL_K; ++j) {
-            const uint32_t e = t * (uint32_t)CCL_K + (uint32_t)j;
-            const uint32_t b = e < n_words ? cl.bits[e] : 0u;
-            nr[j] = (uint32_t)__popc(b & ~(b << 1));
-            mine += nr[j];
-        }
-        const uint32_t incl = wave_incl_scan(mine);
-        if (lane == 63) cl.wave_tot[16 + wv] = incl;
-        __syncthreads();
-        uint32_t off = 0, all = 0;
-#pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            const uint32_t a0 = cl.wave_tot[16 + v];
-            if (v < wv) off += a0;
-            all += a0;
-        }
-        n_runs = __builtin_amdgcn_readfirstlane(all);
-        if ((a.dbg & 131072) && t == 0) ctr.stats[13] = n_runs;
-        if (n_runs > CCL_NR) return false;  // workgroup-uniform
-        uint32_t rb = off + incl - mine;
-#pragma unroll
-        for (int j = 0; j < CCL_K; ++j) {
-            const uint32_t e = t * (uint32_t)CCL_K + (uint32_t)j;
-            if (e < n_words) cl.ent[e] |= rb << CCL_IDX_BITS;
-            for (uint32_t k = 0; k < nr[j]; ++k) cl.parent[rb + k] = rb + k;
-            rb += nr[j];
-        }
-    }
-    __syncthreads();
-    stamp(7);
-    // 2a: links to the column on the left: the previous entry, if it is the neighbouring word (rows are separated by zero
-    // padding); the words whose first row may continue a run of the word above go into a list of their own
-    for (uint32_t e = t; e < n_words; e += 1024u) {
-        const uint32_t en = cl.ent[e], A = cl.bits[e];
-        const uint32_t wa = en & CCL_IDX_MASK, rb = en >> CCL_IDX_BITS;
-        if (e > 0) {
-            const uint32_t ep = cl.ent[e - 1];
-            if ((ep & CCL_IDX_MASK) == wa - 1u) {
-                const uint32_t B = cl.bits[e - 1], rbB = ep >> CCL_IDX_BITS;
-                const uint32_t sA = A & ~(A << 1), sB = B & ~(B << 1);
-                uint32_t c = A & B;  // every run of A & B joins one run of A and one run of B
-                while (c) {
-                    const uint32_t low = c & (0u - c), upto = low | (low - 1u);
-                    lds_unite(cl.parent, rb + (uint32_t)__popc(sA & upto) - 1u, rbB + (uint32_t)__popc(sB & upto) - 1u);
-                    c &= c + low;  // clears the lowest run
-                }
-            }
-        }
-        if ((A & 1u) && wa >= wpr) {
-            const uint32_t v = atomicAdd(cl.n_vert, 1u);
-            if (v < CCL_NV) cl.s_n[v] = e;
-        }
-    }
-    __syncthreads();
-    stamp(15);
-    // 2b: links to the word above (its last row is this word's row -1): binary search in the list, which is in address order
-    const uint32_t n_vert = *cl.n_vert;
-    if (n_vert > CCL_NV) return false;  // workgroup-uniform
-    for (uint32_t v = t; v < n_vert; v += 1024u) {
-        const uint32_t e = cl.s_n[v];
-        const uint32_t en = cl.ent[e];
-        const uint32_t target = (en & CCL_IDX_MASK) - wpr;
-        uint32_t lo = 0, hi = e;
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if ((cl.ent[mid] & CCL_IDX_MASK) < target) lo = mid + 1;
-            else hi = mid;
-        }
-        if (lo < e) {
-            const uint32_t ef = cl.ent[lo];
-            if ((ef & CCL_IDX_MASK) == target) {
-                const uint32_t B = cl.bits[lo];
-                if (B >> 31) lds_unite(cl.parent, en >> CCL_IDX_BITS, (ef >> CCL_IDX_BITS) + (uint32_t)__popc(B & ~(B << 1)) - 1u);
-            }
-        }
-    }
-    __syncthreads();
-    stamp(16);
-    // 3a: every run points at its root (safe while others still search: a link only ever moves towards the root); roots take
-    // cluster slots behind a barrier (tagged in place); the slots' sums are cleared
-    for (uint32_t r = t; r < n_runs; r += 1024u) {
-        const uint32_t root = lds_find(cl.parent, r);
-        __hip_atomic_store(&cl.parent[r], root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    for (uint32_t sl = t; sl < CCL_NC; sl += 1024u) {
-        cl.s_n[sl] = 0u;
-        cl.s_sx[sl] = 0u;
-        cl.s_sy[sl] = 0u;
-        cl.s_key[sl] = 0xffffffffu;
-    }
-    __syncthreads();
-    for (uint32_t r = t; r < n_runs; r += 1024u)
-        if (cl.parent[r] == r) cl.parent[r] = 0x80000000u | atomicAdd(cl.n_clusters, 1u);
-    __syncthreads();
-    stamp(17);
-    const uint32_t nc = *cl.n_clusters;
-    if (nc > CCL_NC) return false;  // workgroup-uniform
-    // 3b: pixel count, coordinate sums and first pixel of every run into its root's slot
-    for (uint32_t e = t; e < n_words; e += 1024u) {
-        const uint32_t en = cl.ent[e];
-        const uint32_t wa = en & CCL_IDX_MASK, rb = en >> CCL_IDX_BITS;
-        const uint32_t yb = wa / wpr, x = wa - yb * wpr - (uint32_t)MASK_PAD_X;
-        uint32_t m = cl.bits[e], k = 0;
-        while (m) {
-            const uint32_t low = m & (0u - m), next = m + low;
-            const uint32_t run = m & ~next;  // the lowest run
-            m &= next;
-            const uint32_t L = (uint32_t)__popc(run), row0 = yb * 32u + (uint32_t)(__ffs(low) - 1);
-            const uint32_t pr = cl.parent[rb + k];
-            const uint32_t sl = ((pr & 0x80000000u) ? pr : cl.parent[pr]) & 0x7fffffffu;
-            atomicAdd(&cl.s_n[sl], L);
-            atomicAdd(&cl.s_sx[sl], L * x);
-            atomicAdd(&cl.s_sy[sl], L * row0 + ((L * (L - 1u)) >> 1));
-            atomicMin(&cl.s_key[sl], row0 * W + x);
-            ++k;
-        }
-    }
-    __syncthreads();
-    stamp(18);
-    n_clusters_out = nc;
-    return true;
-}
 
 // ------------------------------------------------------------------------------------------
 // K3: bit-parallel flood fill, one seed per lane.  Window: 32 columns [sx-16, sx+15] x 32 rows
@@ -2674,17 +2423,16 @@ __global__ void __launch_bounds__(1024) k_rare(ChainArgs a, RefineConsts rc, uin
 // global-memory path (rare_frame), as under k_rare.  Used for batches that fill the chip with one workgroup per frame;
 // smaller batches keep the three launches (plan: launch_kernel / use_sparse_frame).
 // ------------------------------------------------------------------------------------------
-constexpr uint32_t SF_MISC = 64;                                   // LDS words: counters (below), per-wave totals of frame_clusters
+constexpr uint32_t SF_MISC = 16;                                   // LDS words: counters (below)
 constexpr uint32_t SF_REC = SF_MISC;                               // refined records [6][TAIL_CAP]
 constexpr uint32_t SF_R = SF_REC + 6 * TAIL_CAP;                   // one region, used in turn by: verify_frame (VFW_WORDS per wave),
-                                                                   // frame_clusters' lists -- or the flood path's seeds --, the emission's keys
-constexpr uint32_t SF_CCL_WORDS = 2 * CCL_NW + CCL_NR + 4 * CCL_NC;
-constexpr uint32_t SF_R_WORDS = 16 * VFW_WORDS > SF_CCL_WORDS ? 16 * VFW_WORDS : SF_CCL_WORDS;
+                                                                   // the flood seeds, the emission's keys
+constexpr uint32_t SF_R_WORDS = 16 * VFW_WORDS;
 constexpr uint32_t SF_WORDS = SF_R + SF_R_WORDS;
 static_assert(SF_R_WORDS >= TAIL_CAP + 8 && SF_R_WORDS >= SEED_LDS_CAP, "the emission's keys and the flood path's seeds fit the shared region");
 static_assert(SF_REC % 4 == 0 && SF_R % 4 == 0, "16-byte aligned parts");
 static_assert(SF_WORDS * 4 <= 160 * 1024 - 1024, "fits a CU's LDS");
-enum : int { SFM_SEEDS = 0, SFM_FLAGS = 1, SFM_CLUSTERS = 2, SFM_REFINED = 3, SFM_MAXK = 4, SFM_BIG = 5, SFM_CCL_N = 6, SFM_CCL_V = 7, SFM_EMIT = 8, SFM_RARE = 12, SFM_WAVE_TOT = 16 };
+enum : int { SFM_SEEDS = 0, SFM_FLAGS = 1, SFM_CLUSTERS = 2, SFM_REFINED = 3, SFM_MAXK = 4, SFM_BIG = 5, SFM_EMIT = 8, SFM_RARE = 12 };
 
 template <bool VEC, typename CLK>
 __global__ void __launch_bounds__(1024) k_sparse_frame(ChainArgs a, RefineConsts rc, uint32_t lds_entries)
@@ -2721,43 +2469,15 @@ __global__ void __launch_bounds__(1024) k_sparse_frame(ChainArgs a, RefineConsts
         verify_frame(a, frame, VerifyLds{wl, wl + VFW_SLOTS, wl + 2 * VFW_SLOTS, wl + 3 * VFW_SLOTS});  // (ends with a barrier: the mask is final)
     }
     stamp(1);
-    // ---- clusters: labelled in LDS ... ----
-    uint32_t n_ccl = 0;
-    bool ccl = false;
-    if (!a.force_generic && !a.sparse_after_verify && !(a.dbg & 524288)) {  // (524288: A/B, the flood path for every frame)
-        uint32_t *r = lds_u + SF_R;
-        const CclLds cl{r, r + CCL_NW, r + 2 * CCL_NW, r + 2 * CCL_NW + CCL_NR, r + 2 * CCL_NW + CCL_NR + CCL_NC,
-                        r + 2 * CCL_NW + CCL_NR + 2 * CCL_NC, r + 2 * CCL_NW + CCL_NR + 3 * CCL_NC, &misc[SFM_WAVE_TOT], &misc[SFM_CCL_N], &misc[SFM_CCL_V]};
-        ccl = frame_clusters(a, frame, cl, n_ccl);
-        stamp(5);
-        if (ccl && n_ccl <= a.cap_roots) {  // ... and refined, one cluster per lane
-            NoClock clk;
-            for (uint32_t base = (uint32_t)wv * 64u; base < n_ccl; base += 1024u) {  // wave-uniform trip count
-                const uint32_t sl = base + (uint32_t)lane;
-                if (sl < n_ccl) {
-                    const uint32_t key = cl.s_key[sl], cnt = cl.s_n[sl];
-                    float cx, cy;
-                    refine_values<VEC>(a, rc, frame, img, a.W, a.H, key, cnt, cl.s_sx[sl], cl.s_sy[sl], sink, cx, cy, clk);
-                    a.clu_key[cbase + sl] = key;  // the cluster table (agx_debug_fetch)
-                    a.clu_cnt[cbase + sl] = cnt;
-                    a.clu_sx[cbase + sl] = __float_as_uint(cx);
-                    a.clu_sy[cbase + sl] = __float_as_uint(cy);
-                }
-            }
-            if (t == 0) misc[SFM_CLUSTERS] = n_ccl;
-        } else if (ccl && t == 0) {
-            misc[SFM_CLUSTERS] = n_ccl;
-            misc[SFM_FLAGS] |= FLAG_ROOT_OVERFLOW;
-        }
-    }
-    // ---- ... or, for frames beyond its lists, flood seeds + one flood per lane ----
-    if (!ccl && !a.sparse_after_verify) {
-        __syncthreads();  // (frame_clusters' lists are dead: the seeds take their place)
+    // ---- flood seeds ----
+    if (!a.sparse_after_verify) {
         frame_seeds(a, frame, fl);
         __syncthreads();  // the seed list is complete
     }
-    const uint32_t n_seeds_raw = ccl ? 0u : misc[SFM_SEEDS];
-    if (!ccl && !a.force_generic && n_seeds_raw <= a.cap_roots && !(misc[SFM_FLAGS] & FLAG_CAND_OVERFLOW)) {
+    stamp(5);
+    // ---- flood + refine: one seed per lane ----
+    const uint32_t n_seeds_raw = misc[SFM_SEEDS];
+    if (!a.force_generic && n_seeds_raw <= a.cap_roots && !(misc[SFM_FLAGS] & FLAG_CAND_OVERFLOW)) {
         const uint32_t n = n_seeds_raw;
         const uint32_t *mask = a.mask + (size_t)frame * (size_t)a.mask_plane;
         const uint32_t W = (uint32_t)a.W;

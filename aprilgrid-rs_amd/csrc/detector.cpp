@@ -376,7 +376,11 @@ int enqueue_chunk(agx_detector *d, int f0, int nf, hipStream_t st)
     int path = d->sparse_path;
     if (const char *e = getenv("AGX_SPARSE_PATH")) path = atoi(e);
     const int sparse_dbg = 32 | 64 | 128 | 256 | 2048 | 4096 | 8192 | 16384;  // debug_ablation bits that instrument K2 / K3 / K4
-    const bool fused = (path == 2 || path == 3 || (path == 0 && nf >= 192)) && !(a.dbg & sparse_dbg);
+    // by batch size: one workgroup per frame pays when the frames fill the chip's 256 CUs in whole rounds (the last round at least
+    // three quarters full); then k_verify_seeds keeps its launch (8 waves per SIMD, balanced over the whole batch: 40 us against the
+    // 33 .. 75 us per frame of the verify stage inside k_sparse_frame) and flood + refine + emission share one (path 3)
+    if (path == 0) path = (nf >= 192 && (nf % 256 == 0 || nf % 256 >= 192)) ? 3 : 1;
+    const bool fused = (path == 2 || path == 3) && !(a.dbg & sparse_dbg);
     d->last_sparse_frame = fused;
     a.sparse_after_verify = fused && path == 3;
     const int plan_fused[] = {K_BLUR_HESSIAN, K_SPARSE}, plan_multi[] = {K_BLUR_HESSIAN, K_THRESHOLD, K_FLOOD_REFINE, K_RARE},

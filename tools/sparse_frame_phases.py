@@ -17,23 +17,15 @@ st = raw[:, :8] * 0.01  # us
 cnt = np.array([[det.debug_fetch(f, "counters")[k] for k in ("seeds", "clusters", "refined")] for f in range(F)])
 t0 = st[:, 0].min()
 print("frames %d: launch span %.1f us (first start -> last end); starts within %.1f us" % (F, st[:, 3].max() - t0, st[:, 0].max() - t0))
-for name, a, b in (("verify", 0, 1), ("flood+refine", 1, 2), ("emit", 2, 3), ("whole frame", 0, 3)):
+for name, a, b in (("verify", 0, 1), ("seeds+flood+refine", 1, 2), ("emit", 2, 3), ("whole frame", 0, 3)):
     d = st[:, b] - st[:, a]
     print("%-13s median %6.1f  p10 %6.1f  p90 %6.1f  max %6.1f (frame %d)" % (name, np.median(d), np.percentile(d, 10), np.percentile(d, 90), d.max(), d.argmax()))
-for name, a, b in (("verify 1+2 (re-tests)", 0, 4), ("verify 3 (seeds)", 4, 1)):
+for name, a, b in (("verify 1+2 (re-tests)", 0, 4), ("seed pass", 1, 5), ("floods + refine", 5, 2)):
     d = st[:, b] - st[:, a]
     print("  %-22s median %6.1f  p90 %6.1f  max %6.1f (frame %d)" % (name, np.median(d), np.percentile(d, 90), d.max(), d.argmax()))
 w0 = raw[:, 8:14] * 0.01
-print("  wave 0 of the frame, us (median over frames): words wait %.1f, slots + list %.1f, re-tests %.1f, write-back %.1f | seed words wait %.1f, seed extraction %.1f"
-      % tuple(np.median(w0, axis=0)))
-ccl = raw[:, 18] != 0
-print("frame_clusters: %d of %d frames fit its lists; non-zero words per frame median %d p90 %d max %d, runs median %d p90 %d max %d" % (ccl.sum(), F,
-      np.median(raw[:, 12]), np.percentile(raw[:, 12], 90), raw[:, 12].max(), np.median(raw[:, 13]), np.percentile(raw[:, 13], 90), raw[:, 13].max()))
-if ccl.any():
-    tt = raw[ccl] * 0.01
-    for name, a_, b_ in (("scan + counts", 1, 6), ("list + run ids", 6, 7), ("links left", 7, 15), ("links up", 15, 16), ("roots + slots", 16, 17), ("sums", 17, 18), ("refine", 18, 2)):
-        d = tt[:, b_] - tt[:, a_]
-        print("  clusters: %-14s median %6.1f  p90 %6.1f  max %6.1f" % (name, np.median(d), np.percentile(d, 90), d.max()))
+print("  wave 0 of the frame, us (median over frames): words wait %.1f, slots + list %.1f, re-tests %.1f, write-back %.1f"
+      % tuple(np.median(w0[:, :4], axis=0)))
 rt = raw[:, 14]
 v12 = st[:, 4] - st[:, 0]
 print("re-tested bits per frame: median %d p90 %d max %d; verify 1+2 against them: %s" % (np.median(rt), np.percentile(rt, 90), rt.max(),
