@@ -8,7 +8,7 @@ LIB_PATH = os.path.join(_PKG_DIR, "libaprilgrid_amd.so")
 
 AGX_OK = 0
 AGX_ERR_ARG, AGX_ERR_FORMAT, AGX_ERR_CAPACITY, AGX_ERR_HIP = -1, -2, -3, -4
-AGX_ERR_NO_DEVICE, AGX_ERR_FAMILY, AGX_ERR_STATE = -5, -6, -7
+AGX_ERR_NO_DEVICE, AGX_ERR_FAMILY, AGX_ERR_STATE, AGX_ERR_NOMEM = -5, -6, -7, -8
 AGX_L8, AGX_L16, AGX_RGB8, AGX_LF32 = 0, 1, 2, 3
 AGX_GATHER_RCCL, AGX_GATHER_PEER = 0, 1
 AGX_DBG_BLUR, AGX_DBG_RESP, AGX_DBG_MIN, AGX_DBG_CENTERS, AGX_DBG_REFINED = 0, 1, 2, 3, 4

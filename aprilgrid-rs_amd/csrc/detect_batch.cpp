@@ -11,6 +11,7 @@
 #include <condition_variable>
 #include <cstring>
 #include <deque>
+#include <exception>
 #include <functional>
 #include <mutex>
 #include <string>
@@ -28,17 +29,30 @@ class WorkerPool {
 public:
     explicit WorkerPool(int n)
     {
-        for (int i = 0; i < n; ++i) threads_.emplace_back([this] { run(); });
-    }
-    ~WorkerPool()
-    {
-        {
-            std::lock_guard<std::mutex> lk(m_);
-            stop_ = true;
+        threads_.reserve((size_t)std::max(n, 0));
+        try {
+            for (int i = 0; i < n; ++i) threads_.emplace_back([this] { run(); });
+        } catch (...) {  // no more threads (std::system_error): the ones already running are joined before the error leaves
+            stop_and_join();
+            throw;
         }
-        cv_.notify_all();
-        for (std::thread &t : threads_) t.join();
     }
+    ~WorkerPool() { stop_and_join(); }
+    void stop_and_join() noexcept
+    {
+        try {
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                stop_ = true;
+            }
+            cv_.notify_all();
+            for (std::thread &t : threads_)
+                if (t.joinable()) t.join();
+        } catch (...) {
+        }
+    }
+    WorkerPool(const WorkerPool &) = delete;
+    WorkerPool &operator=(const WorkerPool &) = delete;
     int size() const { return (int)threads_.size(); }
     void submit(std::function<void()> f)
     {
@@ -49,10 +63,15 @@ public:
         }
         cv_.notify_one();
     }
-    void wait()
+    // Blocks until every submitted task is done; false if one of them ended in an exception since the last wait (a task must
+    // not unwind out of its thread: run() catches, the caller of wait() learns of it)
+    bool wait()
     {
         std::unique_lock<std::mutex> lk(m_);
         done_.wait(lk, [this] { return pending_ == 0; });
+        const bool ok = !failed_;
+        failed_ = false;
+        return ok;
     }
 
 private:
@@ -67,9 +86,15 @@ private:
                 f = std::move(q_.front());
                 q_.pop_front();
             }
-            f();
+            bool threw = false;
+            try {
+                f();
+            } catch (...) {
+                threw = true;
+            }
             {
                 std::lock_guard<std::mutex> lk(m_);
+                if (threw) failed_ = true;
                 if (--pending_ == 0) done_.notify_all();
             }
         }
@@ -79,7 +104,7 @@ private:
     std::mutex m_;
     std::condition_variable cv_, done_;
     size_t pending_ = 0;
-    bool stop_ = false;
+    bool stop_ = false, failed_ = false;
 };
 
 void destroy_worker_pool(void *p) { delete static_cast<WorkerPool *>(p); }
@@ -92,9 +117,17 @@ public:
     int size() const override { return n_; }
     void run(int n, const std::function<void(int)> &f) override
     {
-        for (int t = 1; t < n; ++t) pool_.submit([&f, t] { f(t); });
-        if (n > 0) f(0);
-        pool_.wait();
+        int submitted = 1;
+        std::exception_ptr mine;
+        try {
+            for (int t = 1; t < n; ++t, ++submitted) pool_.submit([&f, t] { f(t); });
+            if (n > 0) f(0);
+        } catch (...) {  // (the tasks already queued hold a reference to f: they finish before the error leaves)
+            mine = std::current_exception();
+        }
+        const bool ok = pool_.wait();
+        if (mine) std::rethrow_exception(mine);
+        if (!ok) throw std::bad_alloc();  // a share of the search ran out of memory on its thread
     }
 
 private:
@@ -108,9 +141,35 @@ void destroy_tail_workers(TailWorkers *w) { delete w; }
 
 using namespace agx;
 
+static int detect_batch_impl(agx_detector *det, const void *frames, const void *d_frames, int n_frames, int width,
+                             int height, size_t row_stride_bytes, size_t frame_stride_bytes, int format, agx_tag *out,
+                             uint32_t cap_per_frame, uint32_t *counts, int *frame_status, int n_threads);
+
 extern "C" int agx_detect_batch(agx_detector *det, const void *frames, const void *d_frames, int n_frames, int width,
                                 int height, size_t row_stride_bytes, size_t frame_stride_bytes, int format, agx_tag *out,
                                 uint32_t cap_per_frame, uint32_t *counts, int *frame_status, int n_threads)
+{
+    int rc;
+    try {
+        rc = detect_batch_impl(det, frames, d_frames, n_frames, width, height, row_stride_bytes, frame_stride_bytes, format, out,
+                               cap_per_frame, counts, frame_status, n_threads);
+    } catch (...) {  // (the worker pool could not be created: nothing has run)
+        rc = AGX_ERR_NOMEM;
+    }
+    // A failure of the call as a whole (not a frame's own capacity status): no frame's result is valid -- say so in every
+    // frame's slot, so that a caller who looks at the per-frame arrays only cannot mistake an untouched slot for "no tags"
+    if (rc != AGX_OK && rc != AGX_ERR_CAPACITY && counts && n_frames > 0) {
+        for (int f = 0; f < n_frames; ++f) {
+            counts[f] = 0;
+            if (frame_status) frame_status[f] = rc;
+        }
+    }
+    return rc;
+}
+
+static int detect_batch_impl(agx_detector *det, const void *frames, const void *d_frames, int n_frames, int width,
+                             int height, size_t row_stride_bytes, size_t frame_stride_bytes, int format, agx_tag *out,
+                             uint32_t cap_per_frame, uint32_t *counts, int *frame_status, int n_threads)
 {
     if (!det || !frames || !counts || n_frames <= 0 || (!out && cap_per_frame)) return AGX_ERR_ARG;
     if (format != AGX_L8 && format != AGX_L16 && format != AGX_RGB8) return AGX_ERR_FORMAT;  // the tail derives to_luma8 itself
@@ -142,6 +201,7 @@ extern "C" int agx_detect_batch(agx_detector *det, const void *frames, const voi
     std::vector<std::vector<int>> fst(2);
     uint32_t cap_s = 16384;  // saddles per frame the staging holds; grown when a chunk has a longer list
     std::atomic<int> first_bad{AGX_OK};
+    std::atomic<bool> nomem{false};
     int rc = AGX_OK;
     bool pending_batch = false;  // a chunk is enqueued on the detector and not fetched yet
     // Nothing unwinds through the C boundary: an allocation failure on this thread (staging vectors, a task's
@@ -167,13 +227,13 @@ extern "C" int agx_detect_batch(agx_detector *det, const void *frames, const voi
         // the device behind the chain (the frames are there) and come back with the saddles
         const uint8_t *h_luma = nullptr;
         if (format != AGX_L8) {
-            if (ci >= 2) pool->wait();  // tails of the chunk two back read this half of the luma staging
+            if (ci >= 2) (void)pool->wait();  // tails of the chunk two back read this half of the luma staging
             rc = agx_internal_chunk_luma8(det, d_chunk, nf, width, height, row_stride_bytes, frame_stride_bytes, format, par,
                                           (size_t)chunk, &h_luma);
             if (rc) break;
         }
         // the tails of the chunk two back read saddles[par]: they must be done before it is refilled
-        if (ci >= 2) pool->wait();
+        if (ci >= 2) (void)pool->wait();
         saddles[par].resize((size_t)nf * cap_s);
         ns[par].assign(nf, 0);
         fst[par].assign(nf, 0);
@@ -205,7 +265,7 @@ extern "C" int agx_detect_batch(agx_detector *det, const void *frames, const voi
             const uint32_t n_s = ns[par][f];
             const uint8_t *img = h_chunk + (size_t)f * frame_stride_bytes;
             const uint8_t *dev_grey = h_luma ? h_luma + (size_t)f * (size_t)width * (size_t)height : nullptr;
-            pool->submit([=, &first_bad] {
+            pool->submit([=, &first_bad, &nomem] {
               try {  // nothing unwinds out of a worker thread: host memory exhaustion becomes the frame's status
                 const uint8_t *g = dev_grey ? dev_grey : img;  // L8: the frame itself, read at its own pitch
                 const size_t gstride = dev_grey ? (size_t)width : row_stride_bytes;
@@ -222,20 +282,20 @@ extern "C" int agx_detect_batch(agx_detector *det, const void *frames, const voi
                     if (!tags.empty()) std::memcpy(out + (size_t)gf * cap_per_frame, tags.data(), tags.size() * sizeof(agx_tag));
                 }
                 if (frame_status) frame_status[gf] = stf;
-              } catch (...) {
+              } catch (...) {  // host memory exhausted inside this frame's search: the call fails as a whole
                 counts[gf] = 0;
-                if (frame_status) frame_status[gf] = AGX_ERR_CAPACITY;
-                int exp = AGX_OK;
-                first_bad.compare_exchange_strong(exp, AGX_ERR_CAPACITY);
+                if (frame_status) frame_status[gf] = AGX_ERR_NOMEM;
+                nomem.store(true);
               }
             });
         }
     }
     } catch (...) {
-        rc = AGX_ERR_CAPACITY;  // host memory exhausted
+        rc = AGX_ERR_NOMEM;  // host memory exhausted on this thread
     }
-    pool->wait();
+    (void)pool->wait();
     if (pending_batch) agx_internal_abandon_batch(det);  // an error between enqueue and fetch: no stale batch is left to be fetched later
     if (rc) return rc;
+    if (nomem.load()) return AGX_ERR_NOMEM;
     return first_bad.load();
 }

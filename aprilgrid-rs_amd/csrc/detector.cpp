@@ -9,7 +9,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <new>
 #include <string>
+#include <system_error>
 #include <vector>
 
 #include "../../include/aprilgrid_amd.h"
@@ -116,6 +118,40 @@ int fail(agx_detector *d, int status, const std::string &msg)
 {
     if (d) d->last_error = msg;
     return status;
+}
+
+// Nothing unwinds across the C boundary (include/aprilgrid_amd.h, "Conventions"): every entry point runs its body through
+// agx_guard.  A failed host allocation or thread creation becomes AGX_ERR_NOMEM, anything else AGX_ERR_STATE; the message
+// goes to agx_last_error (best effort: storing it must not throw either).  Visible, like the reference's panic
+// (src/detector.rs:500) -- and recoverable, unlike an exception that reaches a Rust frame.
+void set_error_noexcept(agx_detector *d, const char *msg) noexcept
+{
+    try {
+        if (d) d->last_error = msg;
+        else g_create_error = msg;
+    } catch (...) {
+    }
+}
+
+template <typename F>
+int agx_guard(const agx_detector *det_c, F &&body) noexcept
+{
+    agx_detector *det = const_cast<agx_detector *>(det_c);
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        set_error_noexcept(det, "out of host memory");
+        return AGX_ERR_NOMEM;
+    } catch (const std::system_error &e) {  // std::thread: no more threads / resources
+        set_error_noexcept(det, e.what());
+        return AGX_ERR_NOMEM;
+    } catch (const std::exception &e) {
+        set_error_noexcept(det, e.what());
+        return AGX_ERR_STATE;
+    } catch (...) {
+        set_error_noexcept(det, "unknown exception");
+        return AGX_ERR_STATE;
+    }
 }
 
 #define HIP_TRY(det, expr)                                                                     \
@@ -470,7 +506,8 @@ __attribute__((visibility("hidden"))) void *agx_internal_pool(agx_detector *det,
         det->pool = nullptr;
     }
     if (!det->pool) {
-        det->pool = create_worker_pool(n_threads);
+        det->pool_threads = 0;
+        det->pool = create_worker_pool(n_threads);  // (throws where threads cannot be created: agx_detect_batch catches)
         det->pool_threads = n_threads;
     }
     return det->pool;
@@ -533,6 +570,7 @@ const char *agx_status_string(int status)
     case AGX_ERR_NO_DEVICE: return "no usable gfx950 device";
     case AGX_ERR_FAMILY: return "unknown tag family";
     case AGX_ERR_STATE: return "invalid call sequence";
+    case AGX_ERR_NOMEM: return "out of host memory or threads";
     default: return "unknown status";
     }
 }
@@ -541,6 +579,7 @@ const char *agx_last_error(const agx_detector *det) { return det ? det->last_err
 
 int agx_family_from_str(const char *name, int *family_out)
 {
+    return agx_guard(nullptr, [&]() -> int {
     if (!name || !family_out) return AGX_ERR_ARG;
     static const struct { const char *lo, *up; int fam; } kNames[] = {
         {"t16h5", "T16H5", AGX_T16H5},     {"t25h7", "T25H7", AGX_T25H7},
@@ -552,6 +591,7 @@ int agx_family_from_str(const char *name, int *family_out)
             return AGX_OK;
         }
     return AGX_ERR_FAMILY;
+    });
 }
 
 void agx_default_params(agx_params *out)
@@ -565,6 +605,7 @@ void agx_default_params(agx_params *out)
 
 int agx_detector_create(int family, const agx_params *params, int device, agx_detector **out)
 {
+    return agx_guard(nullptr, [&]() -> int {
     if (!out) return AGX_ERR_ARG;
     *out = nullptr;
     g_create_error.clear();
@@ -592,7 +633,14 @@ int agx_detector_create(int family, const agx_params *params, int device, agx_de
         g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e);
         return AGX_ERR_NO_DEVICE;
     }
-    std::unique_ptr<agx_detector> d(new agx_detector());
+    struct Unwind {  // (an exception or an early return behind the stream's creation)
+        void operator()(agx_detector *p) const
+        {
+            if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
+            delete p;
+        }
+    };
+    std::unique_ptr<agx_detector, Unwind> d(new agx_detector());
     d->family = family;
     d->fam = fam;
     if (params) d->params = *params;
@@ -611,18 +659,19 @@ int agx_detector_create(int family, const agx_params *params, int device, agx_de
     e = (hipError_t)init_device_kernels();  // function attributes are per device
     if (e != hipSuccess) {
         g_create_error = std::string("hipFuncSetAttribute: ") + hipGetErrorString(e);
-        (void)hipStreamDestroy(d->own_stream);
         return AGX_ERR_HIP;
     }
     make_blur_weights(1.5f, d->blur_w);
     make_refine_consts(d->rc);
     *out = d.release();
     return AGX_OK;
+    });
 }
 
 void agx_detector_destroy(agx_detector *det)
 {
     if (!det) return;
+    try {
     (void)hipSetDevice(det->device);
     (void)hipStreamSynchronize(det->stream);
     harvest_events(det);
@@ -637,12 +686,15 @@ void agx_detector_destroy(agx_detector *det)
     if (det->d_dbg_resp) (void)hipFree(det->d_dbg_resp);
     if (det->d_resp_store) (void)hipFree(det->d_resp_store);
     if (det->own_stream) (void)hipStreamDestroy(det->own_stream);
+    } catch (...) {  // (joining worker threads can throw std::system_error)
+    }
     delete det;
 }
 
 int agx_detector_family_info(const agx_detector *det, int *edge_bits, int *border_bits, int *hamming_distance,
                              const uint64_t **codes, int *n_codes)
 {
+    return agx_guard(det, [&]() -> int {
     if (!det) return AGX_ERR_ARG;
     if (edge_bits) *edge_bits = det->fam.edge;
     if (border_bits) *border_bits = det->fam.border;
@@ -650,30 +702,36 @@ int agx_detector_family_info(const agx_detector *det, int *edge_bits, int *borde
     if (codes) *codes = det->fam.codes;
     if (n_codes) *n_codes = det->fam.n_codes;
     return AGX_OK;
+    });
 }
 
 int agx_detector_set_limits(agx_detector *det, uint32_t max_candidates, uint32_t max_clusters, uint32_t max_saddles)
 {
+    return agx_guard(det, [&]() -> int {
     if (!det) return AGX_ERR_ARG;
     if (max_candidates >= (1u << 30) || max_saddles > (1u << 24)) return AGX_ERR_ARG;
     det->lim_cand = max_candidates;
     det->lim_roots = max_clusters;
     det->lim_out = max_saddles;
     return AGX_OK;
+    });
 }
 
 int agx_detector_set_stream(agx_detector *det, void *hip_stream, int external)
 {
+    return agx_guard(det, [&]() -> int {
     if (!det) return AGX_ERR_ARG;
     HIP_TRY(det, hipSetDevice(det->device));
     HIP_TRY(det, hipStreamSynchronize(det->stream));
     harvest_events(det);
     det->stream = external ? (hipStream_t)hip_stream : det->own_stream;
     return AGX_OK;
+    });
 }
 
 int agx_detector_set_option(agx_detector *det, const char *name, int value)
 {
+    return agx_guard(det, [&]() -> int {
     if (!det || !name) return AGX_ERR_ARG;
     if (!std::strcmp(name, "force_generic")) det->force_generic = value != 0;
     else if (!std::strcmp(name, "k1_rows_per_segment")) det->k1_rows = value > 0 ? value : 0;
@@ -686,15 +744,19 @@ int agx_detector_set_option(agx_detector *det, const char *name, int value)
         const int n = value < 1 ? 1 : (value > 64 ? 64 : value);
         if (n != det->tail_threads) {
             if (det->tail_workers) destroy_tail_workers(det->tail_workers);
+            det->tail_workers = nullptr;  // (creating the new ones can fail: AGX_ERR_NOMEM, the option back at one thread)
+            det->tail_threads = 1;
             det->tail_workers = create_tail_workers(n);
             det->tail_threads = n;
         }
     } else return fail(det, AGX_ERR_ARG, std::string("unknown option ") + name);
     return AGX_OK;
+    });
 }
 
 int agx_detector_get_option(const agx_detector *det, const char *name, int *value)
 {
+    return agx_guard(det, [&]() -> int {
     if (!det || !name || !value) return AGX_ERR_ARG;
     const ChainArgs &a = det->args;
     if (!std::strcmp(name, "force_generic")) *value = det->force_generic;
@@ -710,14 +772,17 @@ int agx_detector_get_option(const agx_detector *det, const char *name, int *valu
     else if (!std::strcmp(name, "k1_strip_columns")) *value = a.strip_cols;
     else return AGX_ERR_ARG;
     return AGX_OK;
+    });
 }
 
 int agx_detector_sync(agx_detector *det)
 {
+    return agx_guard(det, [&]() -> int {
     if (!det) return AGX_ERR_ARG;
     HIP_TRY(det, hipSetDevice(det->device));
     HIP_TRY(det, hipStreamSynchronize(det->stream));
     return AGX_OK;
+    });
 }
 
 static int batch_enqueue_impl(agx_detector *det, const void *d_frames, int n_frames, int width, int height,
@@ -798,23 +863,28 @@ static int batch_enqueue_impl(agx_detector *det, const void *d_frames, int n_fra
 int agx_saddles_batch_enqueue(agx_detector *det, const void *d_frames, int n_frames, int width, int height,
                               size_t row_stride_bytes, size_t frame_stride_bytes, int format)
 {
+    return agx_guard(det, [&]() -> int {
     return batch_enqueue_impl(det, d_frames, n_frames, width, height, row_stride_bytes, frame_stride_bytes, format,
                               nullptr, 0, nullptr);
+    });
 }
 
 int agx_saddles_batch_enqueue_to(agx_detector *det, const void *d_frames, int n_frames, int width, int height,
                                  size_t row_stride_bytes, size_t frame_stride_bytes, int format, void *d_saddles,
                                  uint32_t saddle_capacity, void *d_frame_table)
 {
+    return agx_guard(det, [&]() -> int {
     if (!d_saddles || !d_frame_table || ((uintptr_t)d_saddles & 3) || ((uintptr_t)d_frame_table & 3))
         return fail(det, AGX_ERR_ARG, "null or misaligned output buffers");
     return batch_enqueue_impl(det, d_frames, n_frames, width, height, row_stride_bytes, frame_stride_bytes, format,
                               d_saddles, saddle_capacity, d_frame_table);
+    });
 }
 
 int agx_saddles_batch_fetch(agx_detector *det, agx_saddle *out, uint32_t cap_per_frame, uint32_t *counts,
                             int *frame_status)
 {
+    return agx_guard(det, [&]() -> int {
     if (!det || !counts || (!out && cap_per_frame)) return fail(det, AGX_ERR_ARG, "null output");
     if (!det->enqueued) return fail(det, AGX_ERR_STATE, "no batch enqueued");
     if (det->external_out) return fail(det, AGX_ERR_STATE, "last batch wrote to caller-owned device buffers");
@@ -871,6 +941,7 @@ int agx_saddles_batch_fetch(agx_detector *det, agx_saddle *out, uint32_t cap_per
                         (size_t)c.n_out * sizeof(agx_saddle));
     }
     return first_bad;
+    });
 }
 
 }  // extern "C"
@@ -938,7 +1009,9 @@ extern "C" {
 int agx_refined_saddle_points(agx_detector *det, const void *pixels, int width, int height, size_t row_stride_bytes,
                               int format, agx_saddle *out, uint32_t cap, uint32_t *n_out)
 {
+    return agx_guard(det, [&]() -> int {
     return refined_saddle_points_impl(det, pixels, width, height, row_stride_bytes, format, out, cap, n_out, false);
+    });
 }
 
 // The single frame of the last agx_refined_saddle_points call again, into a larger buffer (its
@@ -955,21 +1028,26 @@ static int refetch_single(agx_detector *det, agx_saddle *out, uint32_t cap, uint
 
 int agx_debug_angle_pairs(const float *vectors, size_t n, float *exact, float *approx, uint8_t *has_approx)
 {
+    return agx_guard(nullptr, [&]() -> int {
     if (!vectors || !exact || !approx || !has_approx) return AGX_ERR_ARG;
     debug_angle_pairs(vectors, n, exact, approx, has_approx);
     return AGX_OK;
+    });
 }
 
 int agx_luma8(const void *pixels, int width, int height, size_t row_stride_bytes, int format, uint8_t *out)
 {
+    return agx_guard(nullptr, [&]() -> int {
     if (!pixels || !out || width <= 0 || height <= 0) return AGX_ERR_ARG;
     return luma8(pixels, width, height, row_stride_bytes, format, out);
+    });
 }
 
 int agx_detect_from_saddles(const agx_detector *det, const agx_saddle *saddles, uint32_t n_saddles,
                             const uint8_t *luma, int width, int height, size_t row_stride_bytes, agx_tag *out,
                             uint32_t cap, uint32_t *n_out)
 {
+    return agx_guard(det, [&]() -> int {
     if (!det || !luma || !n_out || (!saddles && n_saddles) || (!out && cap)) return AGX_ERR_ARG;
     std::vector<agx_saddle> refined(saddles, saddles + n_saddles);
     std::vector<agx_tag> tags;
@@ -979,20 +1057,24 @@ int agx_detect_from_saddles(const agx_detector *det, const agx_saddle *saddles, 
     if (tags.size() > cap) return AGX_ERR_CAPACITY;
     if (!tags.empty()) std::memcpy(out, tags.data(), tags.size() * sizeof(agx_tag));
     return AGX_OK;
+    });
 }
 
 int agx_detect_tail(int family, const agx_params *params, const agx_saddle *saddles, uint32_t n_saddles,
                     const uint8_t *luma, int width, int height, size_t row_stride_bytes, agx_tag *out, uint32_t cap,
                     uint32_t *n_out)
 {
+    return agx_guard(nullptr, [&]() -> int {
     return agx_detect_tail_threads(family, params, saddles, n_saddles, luma, width, height, row_stride_bytes, out, cap,
                                    n_out, 1);
+    });
 }
 
 int agx_detect_tail_threads(int family, const agx_params *params, const agx_saddle *saddles, uint32_t n_saddles,
                             const uint8_t *luma, int width, int height, size_t row_stride_bytes, agx_tag *out,
                             uint32_t cap, uint32_t *n_out, int n_threads)
 {
+    return agx_guard(nullptr, [&]() -> int {
     if (!luma || !n_out || (!saddles && n_saddles) || (!out && cap) || width < 1 || height < 1) return AGX_ERR_ARG;
     FamilyInfo fam;
     if (!family_info(family, fam)) return AGX_ERR_FAMILY;
@@ -1001,18 +1083,22 @@ int agx_detect_tail_threads(int family, const agx_params *params, const agx_sadd
     else agx_default_params(&prm);
     std::vector<agx_saddle> refined(saddles, saddles + n_saddles);
     std::vector<agx_tag> tags;
-    TailWorkers *workers = create_tail_workers(n_threads);  // threads of this call only (nullptr for <= 1)
-    detect_tail(fam, prm.max_num_of_boards, std::move(refined), luma, width, height, row_stride_bytes, tags, workers);
-    destroy_tail_workers(workers);
+    struct Del {
+        void operator()(TailWorkers *w) const { destroy_tail_workers(w); }
+    };
+    std::unique_ptr<TailWorkers, Del> workers(create_tail_workers(n_threads));  // threads of this call only (nullptr for <= 1)
+    detect_tail(fam, prm.max_num_of_boards, std::move(refined), luma, width, height, row_stride_bytes, tags, workers.get());
     *n_out = (uint32_t)tags.size();
     if (tags.size() > cap) return AGX_ERR_CAPACITY;
     if (!tags.empty()) std::memcpy(out, tags.data(), tags.size() * sizeof(agx_tag));
     return AGX_OK;
+    });
 }
 
 int agx_detect(agx_detector *det, const void *pixels, int width, int height, size_t row_stride_bytes, int format,
                agx_tag *out, uint32_t cap, uint32_t *n_out)
 {
+    return agx_guard(det, [&]() -> int {
     if (!det || !pixels || !n_out) return fail(det, AGX_ERR_ARG, "null argument");
     if (!valid_format(format)) return fail(det, AGX_ERR_FORMAT, kFormatMsg);
     if (width < 2 || height < 2) return fail(det, AGX_ERR_ARG, "width and height must be >= 2");
@@ -1034,11 +1120,13 @@ int agx_detect(agx_detector *det, const void *pixels, int width, int height, siz
     const uint8_t *grey = device_luma ? det->h_luma : (const uint8_t *)pixels;
     const size_t grey_stride = device_luma ? (size_t)width : row_stride_bytes;
     return agx_detect_from_saddles(det, saddles.data(), ns, grey, width, height, grey_stride, out, cap, n_out);
+    });
 }
 
 int agx_detect_planes(agx_detector *det, const float *luma32f, size_t stride32f_bytes, const uint8_t *luma8,
                       size_t stride8_bytes, int width, int height, agx_tag *out, uint32_t cap, uint32_t *n_out)
 {
+    return agx_guard(det, [&]() -> int {
     if (!det || !luma32f || !luma8 || !n_out) return fail(det, AGX_ERR_ARG, "null argument");
     if (width < 2 || height < 2) return fail(det, AGX_ERR_ARG, "width and height must be >= 2");
     if (stride8_bytes < (size_t)width) return fail(det, AGX_ERR_ARG, "row stride smaller than a row");
@@ -1053,6 +1141,7 @@ int agx_detect_planes(agx_detector *det, const float *luma32f, size_t stride32f_
     }
     if (rc) return rc;
     return agx_detect_from_saddles(det, saddles.data(), ns, luma8, width, height, stride8_bytes, out, cap, n_out);
+    });
 }
 
 int agx_profile_enable(agx_detector *det, int on)
@@ -1064,6 +1153,7 @@ int agx_profile_enable(agx_detector *det, int on)
 
 int agx_profile_reset(agx_detector *det)
 {
+    return agx_guard(det, [&]() -> int {
     if (!det) return AGX_ERR_ARG;
     HIP_TRY(det, hipSetDevice(det->device));
     HIP_TRY(det, hipStreamSynchronize(det->stream));
@@ -1074,10 +1164,12 @@ int agx_profile_reset(agx_detector *det)
     }
     det->prof_batches = 0;
     return AGX_OK;
+    });
 }
 
 int agx_profile_read(agx_detector *det, const char **names, double *ms_total, uint64_t *launches)
 {
+    return agx_guard(det, [&]() -> int {
     if (!det) return AGX_ERR_ARG;
     HIP_TRY(det, hipSetDevice(det->device));
     HIP_TRY(det, hipStreamSynchronize(det->stream));
@@ -1088,10 +1180,12 @@ int agx_profile_read(agx_detector *det, const char **names, double *ms_total, ui
         if (launches) launches[k] = k < K_COUNT ? det->prof_launches[k] : 0;
     }
     return AGX_OK;
+    });
 }
 
 int agx_detector_constants(const agx_detector *det, float *blur_w7, float *cone25, float *pmat150)
 {
+    return agx_guard(det, [&]() -> int {
     // det == NULL: compute them afresh (they do not depend on the family or the device)
     float w[7];
     RefineConsts rc;
@@ -1106,10 +1200,12 @@ int agx_detector_constants(const agx_detector *det, float *blur_w7, float *cone2
     if (cone25) std::memcpy(cone25, rc.cone, sizeof rc.cone);
     if (pmat150) std::memcpy(pmat150, rc.pmat, sizeof rc.pmat);
     return AGX_OK;
+    });
 }
 
 int agx_debug_fetch(agx_detector *det, int frame, int what, void *host_out, size_t cap_bytes, size_t *n_items)
 {
+    return agx_guard(det, [&]() -> int {
     if (!det || !host_out || !n_items) return fail(det, AGX_ERR_ARG, "null argument");
     if (!det->enqueued) return fail(det, AGX_ERR_STATE, "no batch enqueued");
     const ChainArgs &a = det->args;
@@ -1249,6 +1345,7 @@ int agx_debug_fetch(agx_detector *det, int frame, int what, void *host_out, size
     }
     default: return fail(det, AGX_ERR_ARG, "unknown debug item");
     }
+    });
 }
 
 }  // extern "C"

@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -123,11 +124,40 @@ int gfail(agx_group *g, int status, const std::string &msg)
     return status;
 }
 
+// nothing unwinds across the C boundary (see agx_guard in detector.cpp)
+void set_group_error_noexcept(agx_group *g, const char *msg) noexcept;
+
+template <typename F>
+int agx_group_guard(agx_group *g, F &&body) noexcept
+{
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        set_group_error_noexcept(g, "out of host memory");
+        return AGX_ERR_NOMEM;
+    } catch (const std::exception &e) {
+        set_group_error_noexcept(g, e.what());
+        return AGX_ERR_STATE;
+    } catch (...) {
+        set_group_error_noexcept(g, "unknown exception");
+        return AGX_ERR_STATE;
+    }
+}
+
 #define GHIP(g, expr)                                                                              \
     do {                                                                                           \
         hipError_t e_ = (expr);                                                                    \
         if (e_ != hipSuccess) return gfail((g), AGX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
+
+void set_group_error_noexcept(agx_group *g, const char *msg) noexcept
+{
+    try {
+        if (g) g->last_error = msg;
+        else g_group_error = msg;
+    } catch (...) {
+    }
+}
 
 void free_slabs(agx_group *g)
 {
@@ -180,6 +210,7 @@ const char *agx_group_last_error(const agx_group *g) { return g ? g->last_error.
 int agx_group_create(int family, const agx_params *params, const int *devices, int n_devices, int transport,
                      agx_group **out)
 {
+    return agx_group_guard(nullptr, [&]() -> int {
     if (!out) return AGX_ERR_ARG;
     *out = nullptr;
     if (n_devices < 1 || n_devices > 64) return gfail(nullptr, AGX_ERR_ARG, "n_devices must be 1..64");
@@ -188,11 +219,18 @@ int agx_group_create(int family, const agx_params *params, const int *devices, i
     g->n = n_devices;
     g->transport = transport;
     for (int r = 0; r < n_devices; ++r) g->devices.push_back(devices ? devices[r] : r);
-    if (transport == AGX_GATHER_RCCL && !rccl_override())
-        for (int r = 0; r < n_devices; ++r)
-            for (int q = 0; q < r; ++q)
-                if (g->devices[q] == g->devices[r])
-                    return gfail(nullptr, AGX_ERR_ARG, "the RCCL transport needs distinct devices (use AGX_GATHER_PEER to test on one GPU)");
+    if (transport == AGX_GATHER_RCCL) {
+        // the library first: only the test suite's stand-in (it exports stub_rccl_stats) may take several ranks on one
+        // device -- the real ncclCommInitAll would hang on them, whatever AGX_RCCL_LIBRARY says
+        std::string err;
+        if (!load_rccl(g->rccl, err)) return gfail(nullptr, AGX_ERR_HIP, err);
+        const bool stand_in = dlsym(g->rccl.lib, "stub_rccl_stats") != nullptr;
+        if (!stand_in)
+            for (int r = 0; r < n_devices; ++r)
+                for (int q = 0; q < r; ++q)
+                    if (g->devices[q] == g->devices[r])
+                        return gfail(nullptr, AGX_ERR_ARG, "the RCCL transport needs distinct devices (use AGX_GATHER_PEER to test on one GPU)");
+    }
     g->d_saddles.assign(n_devices, nullptr);
     g->d_table.assign(n_devices, nullptr);
     auto cleanup = [&]() {
@@ -225,12 +263,7 @@ int agx_group_create(int family, const agx_params *params, const int *devices, i
                 (void)hipDeviceEnablePeerAccess(g->devices[r], 0);
             }
         (void)hipGetLastError();
-    } else if (n_devices > 1) {
-        std::string err;
-        if (!load_rccl(g->rccl, err)) {
-            cleanup();
-            return gfail(nullptr, AGX_ERR_HIP, err);
-        }
+    } else {  // (one rank too: its slab then goes through the library as a send to itself, see agx_group_saddles_enqueue)
         g->comms.assign(n_devices, nullptr);
         const int rc = g->rccl.CommInitAll(g->comms.data(), n_devices, g->devices.data());
         if (rc != 0) {
@@ -240,17 +273,21 @@ int agx_group_create(int family, const agx_params *params, const int *devices, i
     }
     *out = g.release();
     return AGX_OK;
+    });
 }
 
 void agx_group_destroy(agx_group *g)
 {
     if (!g) return;
+    try {
     for (agx_detector *d : g->dets) (void)agx_detector_sync(d);
     free_slabs(g);
     for (size_t r = 0; r < g->comms.size(); ++r)
         if (g->comms[r]) (void)g->rccl.CommDestroy(g->comms[r]);
     for (hipEvent_t e : g->done) (void)hipEventDestroy(e);
     for (agx_detector *d : g->dets) agx_detector_destroy(d);
+    } catch (...) {
+    }
     delete g;
 }
 
@@ -261,6 +298,7 @@ agx_detector *agx_group_detector(agx_group *g, int rank) { return (g && rank >= 
 int agx_group_saddles_enqueue(agx_group *g, const void *const *d_frames, int frames_per_rank, int width, int height,
                               size_t row_stride_bytes, size_t frame_stride_bytes, int format, uint32_t records_per_frame)
 {
+    return agx_group_guard(g, [&]() -> int {
     if (!g || !d_frames || frames_per_rank <= 0) return gfail(g, AGX_ERR_ARG, "null frames or frames_per_rank <= 0");
     if (!records_per_frame) records_per_frame = 512;
     const unsigned long long slab64 = (unsigned long long)frames_per_rank * records_per_frame;
@@ -281,6 +319,21 @@ int agx_group_saddles_enqueue(agx_group *g, const void *const *d_frames, int fra
     // the one exchange step: gather the slabs on the root device, stream-ordered behind the chains
     hipStream_t root = (hipStream_t)agx_internal_stream(g->dets[0]);
     GHIP(g, hipSetDevice(g->devices[0]));
+    if (g->n == 1 && g->transport == AGX_GATHER_RCCL) {
+        // A group of one: the root's own slabs take the library's path too -- a send to itself and the matching receive in
+        // one ncclGroup on the root's stream.  (What a one-GPU box can exercise of the real librccl: the binding, the
+        // communicator, the datatype constant, the ordering behind the chain on a non-blocking stream.)
+        int e = g->rccl.GroupStart();
+        if (e == 0) e = g->rccl.Send(g->d_table[0], tab_bytes, kNcclUint8, 0, g->comms[0], root);
+        if (e == 0) e = g->rccl.Recv(g->d_all_table, tab_bytes, kNcclUint8, 0, g->comms[0], root);
+        if (e == 0) e = g->rccl.Send(g->d_saddles[0], sad_bytes, kNcclUint8, 0, g->comms[0], root);
+        if (e == 0) e = g->rccl.Recv(g->d_all_saddles, sad_bytes, kNcclUint8, 0, g->comms[0], root);
+        const int e2 = g->rccl.GroupEnd();
+        if (e != 0 || e2 != 0)
+            return gfail(g, AGX_ERR_HIP, std::string("RCCL self gather: ") + (g->rccl.GetErrorString ? g->rccl.GetErrorString(e ? e : e2) : "error"));
+        g->enqueued = true;
+        return AGX_OK;
+    }
     GHIP(g, hipMemcpyAsync(g->d_all_table, g->d_table[0], tab_bytes, hipMemcpyDeviceToDevice, root));
     GHIP(g, hipMemcpyAsync(g->d_all_saddles, g->d_saddles[0], sad_bytes, hipMemcpyDeviceToDevice, root));
     if (g->n > 1 && g->transport == AGX_GATHER_RCCL) {
@@ -308,10 +361,12 @@ int agx_group_saddles_enqueue(agx_group *g, const void *const *d_frames, int fra
     }
     g->enqueued = true;
     return AGX_OK;
+    });
 }
 
 int agx_group_saddles_fetch(agx_group *g, agx_saddle *out, uint32_t cap_per_frame, uint32_t *counts, int *frame_status)
 {
+    return agx_group_guard(g, [&]() -> int {
     if (!g || !counts || (!out && cap_per_frame)) return gfail(g, AGX_ERR_ARG, "null output");
     if (!g->enqueued) return gfail(g, AGX_ERR_STATE, "no batch enqueued");
     const size_t F = (size_t)g->frames_per_rank;
@@ -355,6 +410,7 @@ int agx_group_saddles_fetch(agx_group *g, agx_saddle *out, uint32_t cap_per_fram
         }
     }
     return first_bad;
+    });
 }
 
 }  // extern "C"

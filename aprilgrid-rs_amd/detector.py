@@ -184,7 +184,7 @@ class TagDetector:
         n, h, w = a.shape[:3]
         out = np.zeros((n, cap), np.dtype([("id", "u4"), ("xy", "f4", (8,))]))
         counts = np.zeros(n, np.uint32)
-        status = np.zeros(n, np.int32)
+        status = np.full(n, _ffi.AGX_ERR_STATE, np.int32)  # (every slot is written by the call; one that is not stays an error)
         dptr = None
         if device_frames is not None:
             # the chain reads device_frames, the decode reads `frames`: they must be the same pixels

@@ -363,7 +363,11 @@ def main():
     import torch
     import torch.distributed as dist
     from aprilgrid_rs_amd import sharding
-    if os.environ.get("AGX_BENCH_STUB") == "1":  # CPU test of the N > 1 control flow (tests/test_bench_cpu.py)
+    stub = os.environ.get("AGX_BENCH_STUB") == "1"  # CPU test of the N > 1 control flow (tests/test_bench_cpu.py)
+    if stub and torch.cuda.is_available():
+        raise SystemExit("AGX_BENCH_STUB=1 on a box with a GPU: the stub backend (CPU oracle behind the enqueue call) exists for the "
+                         "CPU test of the control flow only and must never produce a benchmark line here -- unset it")
+    if stub:
         from tests import bench_stub
         rt = bench_stub.StubRuntime(torch)
     else:
@@ -578,9 +582,11 @@ def main():
             roof["alone_avg_launch_ms"] = round(k1_alone_ms, 5)
             roof["alone_frac"] = round(roof["bytes_per_launch"] / (k1_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
         result = {
-            "metric": "Mpix/s through the saddle chain (blur->threshold->gradient->saddle), frames resident in HBM",
+            "metric": ("STUB -- NOT A MEASUREMENT (CPU oracle behind the enqueue call, control-flow test) -- " if stub else "")
+                      + "Mpix/s through the saddle chain (blur->threshold->gradient->saddle), frames resident in HBM",
+            "backend": "cpu-stub" if stub else "hip-gfx950",
             "value": round(mpix, 1),
-            "unit": "Mpix/s",
+            "unit": "Mpix/s (cpu stub)" if stub else "Mpix/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,

@@ -8,7 +8,8 @@
  *
  * Conventions
  *   - every function returns AGX_OK (0) or a negative agx_status; nothing unwinds across
- *     the boundary (the reference's panics -- detector.rs:500 "Only support u8c1 and u8c3",
+ *     the boundary: every entry point catches (std::bad_alloc, a failed std::thread ->
+ *     AGX_ERR_NOMEM; tests/test_abi_cpu.py forces both) (the reference's panics -- detector.rs:500 "Only support u8c1 and u8c3",
  *     the height()-1 underflow at detector.rs:174 -- become AGX_ERR_FORMAT / AGX_ERR_ARG);
  *   - the caller owns every buffer it passes; results are copied into caller memory;
  *   - "nothing found" is AGX_OK with a zero count (reference: empty Vec / HashMap);
@@ -40,7 +41,9 @@ typedef enum agx_status {
     AGX_ERR_HIP = -4,       /* a HIP runtime call failed; see agx_last_error              */
     AGX_ERR_NO_DEVICE = -5, /* no usable gfx950 device                                    */
     AGX_ERR_FAMILY = -6,    /* unknown tag family (TagFamily::from_str Err)               */
-    AGX_ERR_STATE = -7      /* call sequence error (e.g. fetch before enqueue)            */
+    AGX_ERR_STATE = -7,     /* call sequence error (e.g. fetch before enqueue); an unexpected internal error */
+    AGX_ERR_NOMEM = -8      /* a host allocation or the creation of a worker thread failed: the WHOLE call
+                               failed, no per-frame result of it is valid                  */
 } agx_status;
 
 /* tag_families::TagFamily -- src/tag_families.rs:5-13 */

@@ -327,6 +327,8 @@ def test_rccl_prototypes_group_cpp_binds_by_name():
 def test_stand_in_rccl_builds_and_exports_the_bound_symbols(tmp_path):
     """tests/stub_rccl compiles here (host code only) and exports every entry point group.cpp binds."""
     import subprocess
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc on this box")
     so = str(tmp_path / "librccl_stub.so")
     r = subprocess.run(["/opt/rocm/bin/hipcc", "-O2", "-fPIC", "-shared", "-o", so, os.path.join(ROOT, "tests", "stub_rccl", "stub_rccl.cpp")],
                        capture_output=True, text=True)
@@ -335,3 +337,58 @@ def test_stand_in_rccl_builds_and_exports_the_bound_symbols(tmp_path):
     for name in ("ncclCommInitAll", "ncclCommDestroy", "ncclGroupStart", "ncclGroupEnd", "ncclSend", "ncclRecv", "ncclGetErrorString",
                  "stub_rccl_stats"):
         assert re.search(r"\bT %s\b" % name, nm), name
+
+
+_NO_UNWIND_CHILD = r"""
+import ctypes as C, os, resource, sys
+import numpy as np
+sys.path.insert(0, %r)
+from aprilgrid_rs_amd import _ffi
+lib = _ffi.lib()
+mode = sys.argv[1]
+rng = np.random.default_rng(5)
+n = 30000 if mode == "threads" else 3000000
+sad = np.zeros((n, 5), np.float32)
+sad[:, 0] = rng.uniform(0, 1280, n); sad[:, 1] = rng.uniform(0, 800, n); sad[:, 2] = 1.0
+sad[:, 3] = rng.uniform(-90, 90, n); sad[:, 4] = 45.0
+luma = np.zeros((800, 1280), np.uint8)
+out = (C.c_uint8 * (36 * 64))()
+n_out = C.c_uint32(0)
+def vm_bytes():
+    for line in open("/proc/self/status"):
+        if line.startswith("VmSize:"):
+            return int(line.split()[1]) * 1024
+soft, hard = resource.getrlimit(resource.RLIMIT_AS)
+# threads: 64 worker threads need 64 x 8 MiB of stack address space; alloc: the saddle copy alone is 60 MB
+resource.setrlimit(resource.RLIMIT_AS, (vm_bytes() + (48 << 20 if mode == "threads" else 16 << 20), hard))
+rc = lib.agx_detect_tail_threads(3, None, sad.ctypes.data, n, luma.ctypes.data, 1280, 800, 1280, out, 64, C.byref(n_out),
+                                 64 if mode == "threads" else 1)
+resource.setrlimit(resource.RLIMIT_AS, (soft, hard))
+print("RC", rc, lib.agx_status_string(rc).decode())
+# the library is still usable afterwards
+small = sad[:100].copy()
+rc2 = lib.agx_detect_tail_threads(3, None, small.ctypes.data, 100, luma.ctypes.data, 1280, 800, 1280, out, 64, C.byref(n_out), 2)
+print("RC2", rc2)
+"""
+
+
+@pytest.mark.parametrize("mode", ["threads", "alloc"])
+def test_nothing_unwinds_across_the_boundary_when_the_host_runs_out_of_resources(mode, lib):
+    """include/aprilgrid_amd.h, Conventions: a failed worker-thread creation / host allocation inside an entry point is a
+    negative status (AGX_ERR_NOMEM), not an exception in the caller's frame -- the reference's failure model is a panic
+    the caller can see (src/detector.rs:500), a C++ exception through extern "C" into Rust is an abort.  In a subprocess,
+    with the address space capped right before the call."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-c", _NO_UNWIND_CHILD % ROOT, mode], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+    assert "RC -8 out of host memory or threads" in r.stdout, r.stdout
+    assert "RC2 0" in r.stdout, r.stdout
+
+
+def test_status_codes_of_the_header_and_the_ctypes_table_agree():
+    from aprilgrid_rs_amd import _ffi
+    hdr = open(os.path.join(ROOT, "include", "aprilgrid_amd.h")).read()
+    for name, val in re.findall(r"\b(AGX_(?:OK|ERR_[A-Z_]+))\s*=\s*(-?\d+)", hdr):
+        assert getattr(_ffi, name) == int(val), name
+    assert _ffi.AGX_ERR_NOMEM == -8

@@ -49,7 +49,8 @@ def test_bench_two_rank_control_flow_under_gloo():
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]  # ONE line, from rank 0
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak" and out["unit"] == "Mpix/s"
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak"
+    assert out["backend"] == "cpu-stub" and out["unit"] == "Mpix/s (cpu stub)" and out["metric"].startswith("STUB")  # a stub line cannot pass for a measurement
     gc = out["gather_check"]
     assert gc["ranks"] == 2 and gc["frames"] == 4 and gc["saddles"] > 0 and gc["oracle_checked_remote_frames"] == 1
     # whole-job value: both ranks' pixels over the slowest rank's time
