@@ -56,9 +56,12 @@ class GatherPipeline:
         gathered = pipe.finish()             # on dst: (list_of_saddles, list_of_tables) of the LAST step
     """
 
-    def __init__(self, n_frames, device, dst=0, group=None, depth=2, always_depth=False, slab_records=SLAB_RECORDS):
+    def __init__(self, n_frames, device, dst=0, group=None, depth=2, always_depth=False, slab_records=SLAB_RECORDS,
+                 force_collective=False):
+        # force_collective: a world of ONE rank still sends its slabs through the backend's gather (bench.py
+        # --collective-world-1: what a one-GPU box can exercise of the nccl = RCCL path)
         self.dst, self.group = dst, group
-        self.multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.multi = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force_collective)
         self.world = dist.get_world_size(group) if self.multi else 1
         self.rank = dist.get_rank(group) if self.multi else 0
         # one rank alone needs a single buffer pair unless several batches are in flight (ChainPipeline)
@@ -117,7 +120,7 @@ class ChainPipeline:
     """
 
     def __init__(self, tag_family, n_frames, device, depth=2, params=None, dst=0, group=None, slab_records=SLAB_RECORDS,
-                 detector_cls=None):
+                 detector_cls=None, force_collective=False):
         # detector_cls: a stand-in with TagDetector's enqueue interface (the CPU test of bench.py's N > 1 control flow)
         if detector_cls is None:
             from .detector import TagDetector
@@ -132,7 +135,7 @@ class ChainPipeline:
         # depth 1 stays on the caller's stream (no cross-stream events at all)
         self.streams = [torch.cuda.Stream(dev) for _ in range(self.depth)] if self.depth > 1 else [None]
         self.gather = GatherPipeline(n_frames, dev, dst=dst, group=group, depth=max(2, self.depth),
-                                     always_depth=self.depth > 1, slab_records=slab_records)
+                                     always_depth=self.depth > 1, slab_records=slab_records, force_collective=force_collective)
         self.i = -1
         self.last_table = None
 

@@ -85,6 +85,9 @@ def parse_args():
                     help="instead of the batch benchmark: the reference's own bench shape (benches/bench_detection.rs, "
                          "benches/bench_blur.rs) on its 7 / 3 fixture images, GPU path next to the CPU oracle "
                          "(tools/bench_images.py)")
+    ap.add_argument("--collective-world-1", action="store_true",
+                    help="N = 1 only: initialise the nccl (= RCCL) process group with a world of one rank anyway and send every "
+                         "step's result slabs through its gather -- what a one-GPU box can exercise of the multi-GPU path")
     ap.add_argument("--pmc-traffic", type=float, default=None,
                     help="HBM bytes per K1 launch from a separate rocprofv3 --pmc run (profiles/)")
     return ap.parse_args()
@@ -382,8 +385,13 @@ def main():
             raise SystemExit("--gpus %d needs the torch.distributed.run launcher (WORLD_SIZE=%d)" % (args.gpus, world))
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     dev = rt.device(local_rank)
-    if world > 1:
+    coll1 = world == 1 and args.collective_world_1
+    if world > 1 or coll1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if coll1:
+            os.environ.setdefault("MASTER_PORT", "29531")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         rt.init_process_group(dist, dev)
 
     W, H, F = args.width, args.height, args.frames
@@ -399,7 +407,7 @@ def main():
     # collective of the path -- so the gather of a step overlaps the chain of the next.
     slab = 8192 if args.noise else sharding.SLAB_RECORDS  # pure noise: ~7100 saddles per 1280x800 frame
     pipe = sharding.ChainPipeline(A.TagFamily.T36H11, F, dev, depth=args.pipeline, dst=0, slab_records=slab,
-                                  detector_cls=rt.detector_cls)
+                                  detector_cls=rt.detector_cls, force_collective=coll1)
 
     def step():
         pipe.submit(frames)
@@ -407,7 +415,7 @@ def main():
     def fence():
         res = pipe.finish()
         rt.synchronize(dev)
-        if world > 1:
+        if world > 1 or coll1:
             dist.barrier()
             rt.synchronize(dev)
         return res
@@ -483,7 +491,8 @@ def main():
             tot += int(t[:, 0].sum())
         mine = sharding.unpack_frames(gs[0], gt[0])
         assert all(a.tobytes() == b.tobytes() for a, b in zip(mine, own)), "rank 0's gathered slab differs from its own results"
-        gather_check = {"ranks": world, "frames": world * F, "saddles": tot}
+        gather_check = {"ranks": world, "frames": world * F, "saddles": tot,
+                        "through_collective": bool(pipe.gather.multi), "backend": rt.backend if pipe.gather.multi else None}
         if world > 1 and not args.no_verify:
             # first frame of every other rank, re-rendered here from its seed, against the oracle
             from aprilgrid_rs_amd import synth

@@ -84,6 +84,26 @@ def test_bench_batch_256_frames_every_frame(det, det_resp, oracle):
         assert a.tobytes() == b.tobytes()
 
 
+def test_config2_top_shard_frames(det, oracle):
+    """BASELINE configs[2] (2048 frames on 8 GPUs, 256 per rank): the frames of the LAST rank's shard -- indices 1792 .. 2047 of the
+    seeded generator, which no one-GPU run of bench.py ever renders -- exactly as bench.py builds that rank's batch: every
+    frame's saddle list against the oracle, and the batch takes the path a full rank takes (k_verify_seeds + k_sparse_frame)."""
+    import torch
+    import bench
+    from aprilgrid_rs_amd import sharding
+    first, last = sharding.shard_range(7, 8, 256)
+    assert (first, last) == (1792, 2048)
+    frames, uniq = bench.make_workload(first, 256, 1280, 800, "L8", 0, False, torch.device("cuda", 0))
+    assert uniq == 256
+    res = run_batch(det, frames)
+    assert det.get_option("last_sparse_path") == 2 and det.get_option("k1_rows_per_segment") == 96
+    host = host_frames(frames, "L8")
+    refs = oracle_saddles_parallel(oracle, host, threads=16)
+    for i in range(256):
+        check_saddles(res[i], refs[i], "frame %d of the generator" % (first + i))
+    check_frame(det, oracle, host[255], 255, "frame 2047")
+
+
 @pytest.mark.parametrize("height", [800, 810, 1080])
 @pytest.mark.parametrize("rows", [32, 64, 96, 128])
 def test_segment_height_sweep(det_resp, oracle, rows, height):

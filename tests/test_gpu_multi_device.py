@@ -113,17 +113,24 @@ def test_group_reports_overflow_per_frame(oracle):
 
 
 def test_group_rccl_transport(oracle):
-    """The RCCL gather (ncclSend / ncclRecv over xGMI) on every visible device; with one GPU the
-    group has a single rank and must not need librccl at all."""
+    """The RCCL gather (ncclSend / ncclRecv over xGMI) through the REAL librccl on every visible device.  With one GPU the
+    group has a single rank, and its slabs still take the library's path -- a send to itself and the matching receive in
+    one ncclGroup on the rank's non-blocking stream --: the dlopen / dlsym binding of group.cpp, ncclCommInitAll, the
+    datatype constant and the ordering behind the chain run against librccl.so itself, not the test suite's stand-in."""
     import torch
     import aprilgrid_rs_amd as A
+    assert "AGX_RCCL_LIBRARY" not in os.environ
     n_dev = torch.cuda.device_count()
     grp = A.DetectorGroup("t36h11", list(range(n_dev)), transport="rccl")
+    maps = open("/proc/self/maps").read()
+    assert "librccl" in maps, "the RCCL transport did not load librccl"
+    assert "librccl_stub" not in maps
     frames = [_frames(70 + 3 * r, 3, "cuda:%d" % r) for r in range(n_dev)]
     for d in range(n_dev):
         torch.cuda.synchronize(d)
-    grp.saddles_enqueue(frames)
-    res, status = grp.saddles_fetch()
+    for rep in range(3):  # slab reuse; one ncclGroup per batch
+        grp.saddles_enqueue(frames)
+        res, status = grp.saddles_fetch()
     assert (status == 0).all()
     host = np.concatenate([f.cpu().numpy() for f in frames])
     refs = oracle_saddles_parallel(oracle, host, threads=4)
@@ -227,3 +234,21 @@ def test_chain_can_be_captured_into_a_hip_graph():
     # ONE captured batch replayed three times (every captured batch clears its own counter set), and an
     # eager batch behind the graphs
     assert r.stdout.count("equals eager: True") == 6, r.stdout[-2000:]
+
+
+def test_bench_sends_its_slabs_through_nccl_with_a_world_of_one(tmp_path):
+    """bench.py --collective-world-1: the nccl (= RCCL) process group is initialised with one rank and every step's result
+    slabs go through its gather (sharding.GatherPipeline), the gathered slab is compared with the rank's own."""
+    import json
+    import subprocess
+    import sys
+    from tests.util import ROOT
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--collective-world-1", "--steps", "4", "--warmup", "1",
+                        "--frames", "64", "--settle-ms", "0", "--no-extra", "--no-cpu-baseline", "--extra-pipeline", "0"],
+                       capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    gc = out["gather_check"]
+    assert gc["through_collective"] is True and gc["backend"] == "nccl" and gc["ranks"] == 1 and gc["saddles"] > 0
+    assert out["verified_frames"] == 64 and out["backend"] == "hip-gfx950"
