@@ -147,6 +147,9 @@ constexpr int MASK_PAD_X = 64;  // zero columns on each side of the transposed m
 int init_device_kernels();
 
 int launch_debug_resp(const ChainArgs &a, int frame, float *dst, void *stream);
+// The batch's frame rows ([n_frames + 1][4]: count, offset, flags, clusters; the last row: total) and compact saddle array into
+// mapped pinned host memory (device addresses h_table_dev / h_out_dev) by a kernel on `stream`.
+int launch_publish(const ChainArgs &a, uint32_t h_out_records, uint32_t *h_table_dev, float *h_out_dev, void *stream);
 // Zero n_records counter records on `stream` (used instead of a memset while the stream is being captured).
 int launch_clear_counters(FrameCounters *ctr, size_t n_records, void *stream);
 // u8 luma (to_luma8) of n_frames L16 (format 1) / RGB8 (format 2) frames in device memory: rows `pitch`

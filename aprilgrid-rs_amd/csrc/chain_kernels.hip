@@ -2752,6 +2752,36 @@ int launch_luma8(const void *src, size_t pitch, size_t frame_stride, int n_frame
     return hipGetLastError();
 }
 
+// agx_saddles_batch_fetch: the batch's results from HBM into the detector's mapped pinned host memory by a KERNEL -- one row per
+// frame (count, offset, flags, clusters; row n_frames: the total) and the compact saddle array, 16 bytes per store --
+// instead of two device-to-host copies with a wait each: a copy shares the DMA queue with whatever else the process is
+// copying (the next batch's 262 MB upload: the results then arrive 2 ms late), a kernel does not.
+__global__ void __launch_bounds__(256) k_publish(const FrameCounters *ctr, int n_frames, const uint32_t *total_out, const float *out,
+                                                 uint32_t h_out_records, uint32_t *h_table, float *h_out)
+{
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (size_t)gridDim.x * blockDim.x;
+    const uint32_t total = *total_out;
+    for (size_t f = tid; f <= (size_t)n_frames; f += nthr) {
+        uint4 row;
+        if (f < (size_t)n_frames) {
+            const FrameCounters &c = ctr[f];
+            row = make_uint4(c.n_out, c.out_offset, c.flags, c.n_clusters + c.n_clusters2);
+        } else {
+            row = make_uint4(total, 0u, 0u, 0u);
+        }
+        reinterpret_cast<uint4 *>(h_table)[f] = row;
+    }
+    const size_t n4 = ((size_t)(total < h_out_records ? total : h_out_records) * 5 + 3) / 4;  // (both arrays are padded to 16 bytes)
+    for (size_t i = tid; i < n4; i += nthr) reinterpret_cast<float4 *>(h_out)[i] = reinterpret_cast<const float4 *>(out)[i];
+}
+
+int launch_publish(const ChainArgs &a, uint32_t h_out_records, uint32_t *h_table_dev, float *h_out_dev, void *stream)
+{
+    hipLaunchKernelGGL(k_publish, dim3(256), dim3(256), 0, (hipStream_t)stream, a.ctr, a.n_frames, a.total_out, a.out, h_out_records,
+                       h_table_dev, h_out_dev);
+    return hipGetLastError();
+}
+
 // Zero n counter records (the library's own kernel: a memset node inside a captured HIP graph faulted on the
 // graph's second replay on ROCm 7.2, a kernel node does not).
 __global__ void __launch_bounds__(256) k_clear_counters(uint32_t *p, size_t n_words)

@@ -192,10 +192,23 @@ static int detect_batch_impl(agx_detector *det, const void *frames, const void *
     const int chunk = std::max(1, std::min(n_frames, std::max(2 * pool->size(), 32)));
     const size_t chunk_bytes = (size_t)chunk * frame_stride_bytes;
     uint8_t *d_stage = nullptr;
+    hipStream_t up = nullptr;
+    hipEvent_t up_done[2] = {nullptr, nullptr}, stage_free[2] = {nullptr, nullptr};
     if (!d_frames) {
         d_stage = static_cast<uint8_t *>(agx_internal_stage(det, 2 * chunk_bytes));  // double-buffered upload
         if (!d_stage) return AGX_ERR_HIP;
+        if (agx_internal_upload_stream(det, (void **)&up, (void **)up_done, (void **)stage_free) != 0) return AGX_ERR_HIP;
     }
+    // chunk c + 1 goes up on the upload stream while chunk c's chain runs and its results are fetched (the two staging halves
+    // alternate: a half is written again when the chain that read it -- two chunks back -- is through)
+    auto upload = [&](int c0, int ci) -> bool {
+        const int nf = std::min(chunk, n_frames - c0), par = ci & 1;
+        if (ci >= 2 && hipStreamWaitEvent(up, stage_free[par], 0) != hipSuccess) return false;
+        if (hipMemcpyAsync(d_stage + (size_t)par * chunk_bytes, (const uint8_t *)frames + (size_t)c0 * frame_stride_bytes,
+                           (size_t)nf * frame_stride_bytes, hipMemcpyHostToDevice, up) != hipSuccess) return false;
+        return hipEventRecord(up_done[par], up) == hipSuccess;
+    };
+    if (!d_frames && !upload(0, 0)) return AGX_ERR_HIP;
     std::vector<std::vector<agx_saddle>> saddles(2);  // per chunk parity: [chunk frames][cap]
     std::vector<std::vector<uint32_t>> ns(2);
     std::vector<std::vector<int>> fst(2);
@@ -216,9 +229,9 @@ static int detect_batch_impl(agx_detector *det, const void *frames, const void *
         if (d_frames) {
             d_chunk = (const uint8_t *)d_frames + (size_t)c0 * frame_stride_bytes;
         } else {
-            uint8_t *dst = d_stage + (size_t)par * chunk_bytes;
-            if (hipMemcpyAsync(dst, h_chunk, (size_t)nf * frame_stride_bytes, hipMemcpyHostToDevice, st) != hipSuccess) { rc = AGX_ERR_HIP; break; }
-            d_chunk = dst;
+            if (c0 + chunk < n_frames && !upload(c0 + chunk, ci + 1)) { rc = AGX_ERR_HIP; break; }  // the next chunk, under this one's chain
+            if (hipStreamWaitEvent(st, up_done[par], 0) != hipSuccess) { rc = AGX_ERR_HIP; break; }
+            d_chunk = d_stage + (size_t)par * chunk_bytes;
         }
         rc = agx_saddles_batch_enqueue(det, d_chunk, nf, width, height, row_stride_bytes, frame_stride_bytes, format);
         if (rc) break;
@@ -232,6 +245,7 @@ static int detect_batch_impl(agx_detector *det, const void *frames, const void *
                                           (size_t)chunk, &h_luma);
             if (rc) break;
         }
+        if (!d_frames && hipEventRecord(stage_free[par], st) != hipSuccess) { rc = AGX_ERR_HIP; break; }  // chain + luma have read this half
         // the tails of the chunk two back read saddles[par]: they must be done before it is refilled
         if (ci >= 2) (void)pool->wait();
         saddles[par].resize((size_t)nf * cap_s);
@@ -294,6 +308,7 @@ static int detect_batch_impl(agx_detector *det, const void *frames, const void *
         rc = AGX_ERR_NOMEM;  // host memory exhausted on this thread
     }
     (void)pool->wait();
+    if (up) (void)hipStreamSynchronize(up);  // (after an error an upload may still be reading the caller's frames)
     if (pending_batch) agx_internal_abandon_batch(det);  // an error between enqueue and fetch: no stale batch is left to be fetched later
     if (rc) return rc;
     if (nomem.load()) return AGX_ERR_NOMEM;

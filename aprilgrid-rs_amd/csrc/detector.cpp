@@ -81,7 +81,8 @@ struct agx_detector {
     float *d_out_internal = nullptr;  // workspace copy of args.out
     float *h_out_dev = nullptr;       // device address of h_out (mapped pinned memory): a single frame's list is written there directly
     bool out_in_host = false;         // last batch's compact output went straight to h_out
-    uint32_t *h_table = nullptr, *h_table_dev = nullptr;  // mapped pinned [4]: the single frame's count, offset, status, clusters
+    uint32_t *h_table = nullptr, *h_table_dev = nullptr;  // mapped pinned [frames + 1][4]: per frame count, offset, status, clusters (k_publish / the single frame's k_rare)
+    size_t h_table_rows = 0;
     size_t mask_words = 0;
     bool external_out = false;       // last batch wrote into caller-owned device memory
 
@@ -101,6 +102,9 @@ struct agx_detector {
     double prof_ms[K_COUNT]{};
     uint64_t prof_launches[K_COUNT]{};
 
+    // agx_detect_batch: the next chunk's upload runs on a stream of its own under the current chunk's chain and fetch
+    hipStream_t upload_stream = nullptr;
+    hipEvent_t upload_done[2] = {nullptr, nullptr}, stage_free[2] = {nullptr, nullptr};
     TailWorkers *tail_workers = nullptr;  // option "tail_threads" > 1: one frame's board search on several threads
     int tail_threads = 1;
     void *pool = nullptr;  // agx_detect_batch: worker threads of the host tail
@@ -331,17 +335,21 @@ int ensure_workspace(agx_detector *d, int n_frames, int W, int H)
     if ((rc = dev_alloc(d, a.minidx, F * cap_cand))) return rc;
     if ((rc = dev_alloc(d, a.roots, F * cap_roots))) return rc;
     if ((rc = dev_alloc(d, a.refined, F * cap_roots))) return rc;
-    if ((rc = dev_alloc(d, d->d_out_internal, F * cap_out * 5))) return rc;
+    if ((rc = dev_alloc(d, d->d_out_internal, F * cap_out * 5 + 4))) return rc;  // (+4: k_publish copies 16 bytes at a time)
     d->ws_W = d->ws_H = 0;  // forces the mask to be zeroed below
     HIP_TRY(d, hipHostMalloc((void **)&d->h_ctr, (F + 1) * sizeof(FrameCounters), hipHostMallocDefault));
     d->h_total = (uint32_t *)(d->h_ctr + F);
     d->h_ctr_frames = F;
-    HIP_TRY(d, hipHostMalloc((void **)&d->h_out, F * cap_out * 5 * sizeof(float), hipHostMallocMapped));
+    HIP_TRY(d, hipHostMalloc((void **)&d->h_out, (F * cap_out * 5 + 4) * sizeof(float), hipHostMallocMapped));
     d->h_out_dev = nullptr;
     if (hipHostGetDevicePointer((void **)&d->h_out_dev, d->h_out, 0) != hipSuccess) d->h_out_dev = nullptr;
-    if (!d->h_table) {
-        HIP_TRY(d, hipHostMalloc((void **)&d->h_table, 4 * sizeof(uint32_t), hipHostMallocMapped));
+    if (d->h_table_rows < F + 1) {
+        if (d->h_table) (void)hipHostFree(d->h_table);
+        d->h_table = d->h_table_dev = nullptr;
+        d->h_table_rows = 0;
+        HIP_TRY(d, hipHostMalloc((void **)&d->h_table, (F + 1) * 4 * sizeof(uint32_t), hipHostMallocMapped));
         if (hipHostGetDevicePointer((void **)&d->h_table_dev, d->h_table, 0) != hipSuccess) d->h_table_dev = nullptr;
+        d->h_table_rows = F + 1;
     }
     d->h_out_records = F * cap_out;
     d->cap_frames = F;
@@ -537,6 +545,24 @@ __attribute__((visibility("hidden"))) int agx_internal_chunk_luma8(agx_detector 
     *h_out = h;
     return AGX_OK;
 }
+// agx_detect_batch: the upload stream and its four events (created on first use); hipError_t
+__attribute__((visibility("hidden"))) int agx_internal_upload_stream(agx_detector *det, void **stream, void **upload_done, void **stage_free)
+{
+    if (!det->upload_stream) {
+        hipError_t e = hipStreamCreateWithFlags(&det->upload_stream, hipStreamNonBlocking);
+        for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+            e = hipEventCreateWithFlags(&det->upload_done[i], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&det->stage_free[i], hipEventDisableTiming);
+        }
+        if (e != hipSuccess) return (int)e;
+    }
+    *stream = det->upload_stream;
+    for (int i = 0; i < 2; ++i) {
+        upload_done[i] = det->upload_done[i];
+        stage_free[i] = det->stage_free[i];
+    }
+    return 0;
+}
 __attribute__((visibility("hidden"))) void agx_internal_abandon_batch(agx_detector *det)
 {
     if (!det) return;
@@ -685,6 +711,11 @@ void agx_detector_destroy(agx_detector *det)
     if (det->h_table) (void)hipHostFree(det->h_table);
     if (det->d_dbg_resp) (void)hipFree(det->d_dbg_resp);
     if (det->d_resp_store) (void)hipFree(det->d_resp_store);
+    for (int i = 0; i < 2; ++i) {
+        if (det->upload_done[i]) (void)hipEventDestroy(det->upload_done[i]);
+        if (det->stage_free[i]) (void)hipEventDestroy(det->stage_free[i]);
+    }
+    if (det->upload_stream) (void)hipStreamDestroy(det->upload_stream);
     if (det->own_stream) (void)hipStreamDestroy(det->own_stream);
     } catch (...) {  // (joining worker threads can throw std::system_error)
     }
@@ -906,6 +937,27 @@ int agx_saddles_batch_fetch(agx_detector *det, agx_saddle *out, uint32_t cap_per
             have_counters = true;
         }  // else: the full record below (sizes of the overflowing lists for the error message)
     }
+    bool out_fetched = det->out_in_host;
+    if (!have_counters && !det->out_in_host && det->h_table_dev && det->h_out_dev && F + 1 <= det->h_table_rows) {
+        // a batch: frame rows and the compact array come over by a kernel (k_publish), one wait
+        hipError_t e = (hipError_t)launch_publish(a, (uint32_t)std::min<size_t>(det->h_out_records, 0xffffffffu), det->h_table_dev, det->h_out_dev, det->stream);
+        if (e != hipSuccess) return fail(det, AGX_ERR_HIP, std::string("k_publish: ") + hipGetErrorString(e));
+        HIP_TRY(det, hipStreamSynchronize(det->stream));
+        bool bad = false;
+        for (size_t f = 0; f < F; ++f) {
+            const uint32_t *row = det->h_table + 4 * f;
+            FrameCounters &c = det->h_ctr[f];
+            std::memset(&c, 0, sizeof c);
+            c.n_out = row[0];
+            c.out_offset = row[1];
+            c.flags = row[2];
+            c.n_clusters = row[3];
+            bad = bad || (row[2] & (FLAG_CAND_OVERFLOW | FLAG_ROOT_OVERFLOW | FLAG_OUT_OVERFLOW));
+        }
+        *det->h_total = det->h_table[4 * F];
+        have_counters = !bad;  // (an overflowing frame: the full records below, for the sizes in the error message)
+        out_fetched = true;
+    }
     if (!have_counters) {
         HIP_TRY(det, hipMemcpyAsync(det->h_ctr, a.ctr, F * sizeof(FrameCounters), hipMemcpyDeviceToHost, det->stream));
         HIP_TRY(det, hipMemcpyAsync(det->h_total, a.total_out, sizeof(uint32_t), hipMemcpyDeviceToHost, det->stream));
@@ -914,7 +966,7 @@ int agx_saddles_batch_fetch(agx_detector *det, agx_saddle *out, uint32_t cap_per
     harvest_events(det);
     const uint32_t total = *det->h_total;
     if (total > det->h_out_records) return fail(det, AGX_ERR_HIP, "compact output counter out of range");
-    if (total && !det->out_in_host) {
+    if (total && !out_fetched) {
         HIP_TRY(det, hipMemcpyAsync(det->h_out, a.out, (size_t)total * 5 * sizeof(float), hipMemcpyDeviceToHost,
                                     det->stream));
         HIP_TRY(det, hipStreamSynchronize(det->stream));

@@ -16,6 +16,7 @@ int agx_internal_max_boards(const agx_detector *det);
 void *agx_internal_stage(agx_detector *det, size_t bytes);
 // Wait for whatever is enqueued and forget it (an error path between enqueue and fetch).
 void agx_internal_abandon_batch(agx_detector *det);
+int agx_internal_upload_stream(agx_detector *det, void **stream, void **upload_done, void **stage_free);  // hipError_t
 // u8 luma of a chunk of L16 / RGB8 device frames, computed on the device and copied to pinned host
 // memory behind the detector's stream ([n_frames][H][W] at *h_out once the stream has been waited for)
 int agx_internal_chunk_luma8(agx_detector *det, const void *d_frames, int n_frames, int width, int height, size_t row_stride,

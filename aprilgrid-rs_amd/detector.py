@@ -345,6 +345,18 @@ class TagDetector:
         res = [out[i, : counts[i]].copy() if status[i] == 0 else out[i, :0].copy() for i in range(n)]
         return res, status
 
+    def saddles_batch_fetch_into(self, out, counts, status):
+        """agx_saddles_batch_fetch into caller-owned arrays (what a Rust / C caller does: no allocation per call): out
+        SADDLE_DTYPE [n, cap], counts uint32 [n], status int32 [n].  Returns the call's status (0 or AGX_ERR_CAPACITY)."""
+        if self._batch is None:
+            raise AgxError(_ffi.AGX_ERR_STATE, "no batch enqueued")
+        n = self._batch[0]
+        assert out.dtype == SADDLE_DTYPE and out.shape[0] == n and out.flags.c_contiguous and counts.shape == (n,) and status.shape == (n,)
+        st = self._lib.agx_saddles_batch_fetch(self._h, out.ctypes.data, out.shape[1], counts.ctypes.data, status.ctypes.data)
+        if st not in (_ffi.AGX_OK, _ffi.AGX_ERR_CAPACITY):
+            self._check(st)
+        return st
+
     # ---- measurement / parity hooks ------------------------------------------------------
     def profile_enable(self, level=2):
         """0/False off, 1 = time the blur kernel only, 2/True = time every kernel."""
