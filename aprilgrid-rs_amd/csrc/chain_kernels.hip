@@ -2332,16 +2332,26 @@ __device__ __forceinline__ void emit_wide_lds(const ChainArgs &a, int frame, uin
 //   - filters (detector.rs:436-445) and emits the frame's saddles in the reference's order (emit_wide; lists of
 //     more than TAIL_CAP refined records -- FLAG_LARGE_RESULT -- by the large LDS / global-memory sort).
 // lds_u: lds_entries * 2 words of LDS (16-byte aligned), s_misc3: three more.
+struct FrameHead {  // the frame's flags, the length of its refined list and the largest k
+    uint32_t flags, n_refined, max_k_bits;
+};
+__device__ __forceinline__ FrameHead load_frame_head(const FrameCounters &ctr)
+{
+    // ONE round trip (one 128-byte line)
+    FrameHead h;
+    h.flags = __hip_atomic_load(&ctr.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    h.n_refined = __hip_atomic_load(&ctr.n_refined, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    h.max_k_bits = __hip_atomic_load(&ctr.max_k_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" : "+v"(h.flags), "+v"(h.n_refined), "+v"(h.max_k_bits));  // (all three consumed here: no load is left behind a branch)
+    return h;
+}
+
 __device__ __forceinline__ void rare_frame(const ChainArgs &a, const RefineConsts &rc, int frame, uint32_t *lds_u, uint32_t lds_entries,
-                                           uint32_t *s_misc3)
+                                           uint32_t *s_misc3, const FrameHead &head)
 {
     uint32_t &s_count = s_misc3[0], &s_offset = s_misc3[1], &s_fits = s_misc3[2];
     FrameCounters &ctr = a.ctr[frame];
-    // the frame's flags, the length of its refined list and the largest k in ONE round trip (one 128-byte line)
-    uint32_t flags0 = __hip_atomic_load(&ctr.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    uint32_t n_ref0 = __hip_atomic_load(&ctr.n_refined, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    uint32_t maxk0 = __hip_atomic_load(&ctr.max_k_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("" : "+v"(flags0), "+v"(n_ref0), "+v"(maxk0));  // (all three consumed here: no load is left behind a branch)
+    uint32_t flags0 = head.flags, n_ref0 = head.n_refined, maxk0 = head.max_k_bits;
     const bool generic = a.force_generic || (flags0 & FLAG_BIG_CLUSTER);
     const size_t cbase = (size_t)frame * a.cap_roots;
     const float *img = a.blur + (size_t)frame * (size_t)a.plane;
@@ -2398,15 +2408,142 @@ __device__ __forceinline__ void clear_next_counters(const ChainArgs &a, int fram
     }
 }
 
-// K4, the last launch of the multi-launch chain: a 1024-thread workgroup per frame (rare_frame).
-__global__ void __launch_bounds__(1024) k_rare(ChainArgs a, RefineConsts rc, uint32_t lds_entries)
+// Large lists (more than TAIL_CAP refined records: pure-noise frames carry 8 000) by SEVERAL workgroups per frame: the keys --
+// the clusters' first pixels -- are order-preserving, so the frame is cut into `n_parts` bands of pixel indices; every part
+// reads all of the frame's records, filters them (detector.rs:436-445), counts the survivors of every band and keeps its own
+// band's (key, index) pairs in LDS; it sorts those (bitonic, a fraction of the list) and writes them behind the bands below
+// it.  The frame's place in the compact output is allocated by the part that gets there first (one atomic); the others wait
+// for the offset -- for a workgroup that is already running and waits for nobody.  Returns false (workgroup-uniform, the same
+// in every part) if a band does not fit LDS: part 0 then emits the frame alone (filter_sort_emit).
+__device__ __forceinline__ bool emit_large_split(const ChainArgs &a, int frame, uint32_t part, uint32_t n_parts, uint32_t n, uint32_t max_k_bits,
+                                                 uint32_t *keys, uint32_t *idxs, uint32_t lds_entries, uint32_t *s_cnt /*[n_parts + 2]*/)
+{
+    const uint32_t t = threadIdx.x, T = blockDim.x;
+    FrameCounters &ctr = a.ctr[frame];
+    uint32_t *rec = reinterpret_cast<uint32_t *>(a.refined + (size_t)frame * a.cap_roots);
+    auto rec_u = [&](uint32_t i, int field) { return __hip_atomic_load(rec + (size_t)i * 6 + field, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    if (t < n_parts + 2) s_cnt[t] = 0u;
+    __syncthreads();
+    const float s_max_k = __uint_as_float(max_k_bits) / 10.0f;
+    const unsigned long long plane = (unsigned long long)a.plane;
+    for (uint32_t i = t; i < n; i += T) {
+        const float k = __uint_as_float(rec_u(i, 3)), phi = __uint_as_float(rec_u(i, 5));
+        if (k >= s_max_k && phi >= a.min_angle && phi <= a.max_angle) {
+            const uint32_t key = rec_u(i, 0);
+            const uint32_t band = (uint32_t)(((unsigned long long)key * n_parts) / plane);  // key < plane
+            const uint32_t o = atomicAdd(&s_cnt[band], 1u);
+            if (band == part && o < lds_entries) {
+                keys[o] = key;
+                idxs[o] = i;
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t nf = 0, below = 0, biggest = 0;
+    for (uint32_t b = 0; b < n_parts; ++b) {
+        const uint32_t c = s_cnt[b];
+        if (b < part) below += c;
+        nf += c;
+        biggest = max(biggest, c);
+    }
+    uint32_t need = 1;
+    while (need < biggest) need <<= 1;  // the bitonic network pads to a power of two
+    if (need > lds_entries) return false;  // (every part computes the same counts: all of them return)
+    const uint32_t mine = s_cnt[part];
+    // the frame's place in the compact output: the part that arrives first allocates it
+    if (t == 0) {
+        uint32_t off = 0, fits = 1;
+        const uint32_t won = atomicCAS(&ctr.refine_done, 0u, 1u);
+        if (won == 0u) {
+            const bool ok = nf <= a.cap_out;
+            if (ok && nf) {
+                off = atomicAdd(a.total_out, nf);
+                if (off + nf > a.out_total_cap) fits = 0;  // caller's buffer is full
+            }
+            if (!ok || !fits) atomicOr(&ctr.flags, FLAG_OUT_OVERFLOW);
+            ctr.n_out = nf;
+            ctr.out_offset = off;
+            if (a.frame_table) {
+                uint32_t *row = a.frame_table + (size_t)frame * 4;
+                const uint32_t flags = __hip_atomic_load(&ctr.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool bad = (flags & (FLAG_CAND_OVERFLOW | FLAG_ROOT_OVERFLOW | FLAG_OUT_OVERFLOW)) != 0;
+                row[0] = bad ? 0u : nf;
+                row[1] = off;
+                row[2] = flags;
+                row[3] = __hip_atomic_load(&ctr.n_clusters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __hip_atomic_store(&ctr.out_offset, off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ctr.refine_done, (ok && fits) ? 2u : 3u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            s_cnt[n_parts] = off;
+            s_cnt[n_parts + 1] = (ok && fits) ? 1u : 0u;
+        } else {
+            uint32_t st;
+            while ((st = __hip_atomic_load(&ctr.refine_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < 2u) __builtin_amdgcn_s_sleep(2);
+            s_cnt[n_parts] = __hip_atomic_load(&ctr.out_offset, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_cnt[n_parts + 1] = st == 2u ? 1u : 0u;
+        }
+    }
+    __syncthreads();
+    if (!s_cnt[n_parts + 1] || !mine) return true;  // the frame does not fit the output (reported), or nothing in this band
+    uint32_t np2 = 1;
+    while (np2 < mine) np2 <<= 1;
+    for (uint32_t i = mine + t; i < np2; i += T) {
+        keys[i] = 0xffffffffu;
+        idxs[i] = 0;
+    }
+    __syncthreads();
+    for (uint32_t k2 = 2; k2 <= np2; k2 <<= 1) {
+        for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = t; i < np2; i += T) {
+                const uint32_t l = i ^ j;
+                if (l > i) {
+                    const bool asc = (i & k2) == 0;
+                    const uint32_t ki = keys[i], kl = keys[l];
+                    if ((ki > kl) == asc) {
+                        keys[i] = kl; keys[l] = ki;
+                        const uint32_t ti = idxs[i]; idxs[i] = idxs[l]; idxs[l] = ti;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    float *out = a.out + ((size_t)s_cnt[n_parts] + below) * 5;
+    for (uint32_t i = t; i < mine; i += T) {
+        const uint32_t src = idxs[i];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) out[(size_t)i * 5 + q] = __uint_as_float(rec_u(src, q + 1));
+    }
+    return true;
+}
+
+// K4, the last launch of the multi-launch chain: 1024-thread workgroups, `n_parts` of them per frame.  Part 0 does the frame's
+// rare work and its emission (rare_frame); the other parts only exist for frames with a large list, which the parts emit
+// together (emit_large_split).
+constexpr uint32_t RARE_MAX_PARTS = 8;
+__global__ void __launch_bounds__(1024) k_rare(ChainArgs a, RefineConsts rc, uint32_t lds_entries, uint32_t n_parts)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];  // (emit_wide reads its keys 16 bytes at a time)
     __shared__ uint32_t s_misc3[3];
+    __shared__ uint32_t s_cnt[RARE_MAX_PARTS + 2];
     const WaveTimer wt(a, K_RARE);
-    const int frame = blockIdx.x;
-    clear_next_counters(a, frame);
-    rare_frame(a, rc, frame, lds_u, lds_entries, s_misc3);
+    const int frame = (int)(blockIdx.x / n_parts);
+    const uint32_t part = blockIdx.x - (uint32_t)frame * n_parts;
+    if (part == 0) clear_next_counters(a, frame);
+    FrameCounters &ctr = a.ctr[frame];
+    const FrameHead head = load_frame_head(ctr);
+    if (n_parts > 1) {
+        const bool generic = a.force_generic || (head.flags & FLAG_BIG_CLUSTER);
+        const bool void_frame = (head.flags & (FLAG_CAND_OVERFLOW | FLAG_ROOT_OVERFLOW)) != 0;
+        const bool split = !generic && !void_frame && head.n_refined > TAIL_CAP;  // (the same decision in every part of the frame)
+        if (split) {
+            if (part == 0 && threadIdx.x == 0) atomicOr(&ctr.flags, FLAG_LARGE_RESULT);
+            if (emit_large_split(a, frame, part, n_parts, head.n_refined, head.max_k_bits, lds_u, lds_u + lds_entries, lds_entries, s_cnt)) return;
+            __syncthreads();
+        }
+        if (part != 0) return;
+    }
+    rare_frame(a, rc, frame, lds_u, lds_entries, s_misc3, head);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2548,7 +2685,7 @@ __global__ void __launch_bounds__(1024) k_sparse_frame(ChainArgs a, RefineConsts
         // the global-memory path: its counters and lists are in global memory (every record is mirrored there)
         if (t == 0) atomicOr(&ctr.flags, flags);
         phase_barrier();
-        rare_frame(a, rc, frame, lds_u + SF_MISC, lds_entries, &misc[SFM_RARE]);  // (everything behind the counters is free now)
+        rare_frame(a, rc, frame, lds_u + SF_MISC, lds_entries, &misc[SFM_RARE], load_frame_head(ctr));  // (everything behind the counters is free now)
         return;
     }
     emit_wide_lds(a, frame, void_frame ? 0u : n_ref, misc[SFM_MAXK], lds_u + SF_REC, lds_u + SF_R, &misc[SFM_EMIT], &misc[SFM_FLAGS], n_clu);
@@ -2685,8 +2822,13 @@ int launch_kernel(int which, const ChainArgs &a, const RefineConsts &rc, void *s
     }
     case K_RARE: {
         size_t lds = k5_lds_bytes(a);  // (the large-LDS attribute is set per device in init_device_kernels)
-        dim3 grid(a.n_frames), block(1024);
-        hipLaunchKernelGGL(k_rare, grid, block, lds, st, a, rc, (uint32_t)(lds / 8));
+        // several workgroups per frame when the frames alone do not fill the chip: a frame with a large list (pure noise) is then
+        // emitted by all of them together; frames with ordinary lists cost the extra workgroups one look at a counter
+        uint32_t parts = a.n_frames >= 128 ? 1u : (a.n_frames >= 64 ? 4u : RARE_MAX_PARTS);
+        const int forced = env_int("AGX_RARE_PARTS", 0);
+        if (forced >= 1 && forced <= (int)RARE_MAX_PARTS) parts = (uint32_t)forced;
+        dim3 grid((unsigned)a.n_frames * parts), block(1024);
+        hipLaunchKernelGGL(k_rare, grid, block, lds, st, a, rc, (uint32_t)(lds / 8), parts);
         return hipGetLastError();
     }
     case K_SPARSE: {
