@@ -30,4 +30,4 @@ for r, dbg in [(r, d) for r in rows for d in DBG]:
         det.saddles_batch_enqueue(frames)
     det.sync()
     p = det.profile_read(); det.profile_enable(False)
-    print(r, "dbg", dbg, {k: round(v[0] / v[1], 4) for k, v in p.items()}, "sum", round(sum(v[0] / v[1] for v in p.values()), 4), "WALL ms/step", round(wall, 4), flush=True)
+    print(r, "dbg", dbg, {k: round(v[0] / v[1], 4) for k, v in p.items() if v[1]}, "sum", round(sum(v[0] / v[1] for v in p.values() if v[1]), 4), "WALL ms/step", round(wall, 4), flush=True)
