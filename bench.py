@@ -559,6 +559,7 @@ def main():
             det.saddles_batch_enqueue_to(frames, out_s, out_t)
         fence()
         prof[name] = det.profile_read()[name]
+    prof = {k: v for k, v in prof.items() if v[1]}  # the launches this batch size takes (256 frames: K1, k_verify_seeds, k_sparse_frame)
     det.profile_enable(0)
     det.set_option("profile_kernel", 0)
     det.set_option("profile_stride", 1)
@@ -664,6 +665,8 @@ def main():
             "chain": {
                 "a_mat_bytes_per_px": a_mat,
                 "kernel_ms_per_step": {k: round(v[0] / max(v[1], 1), 5) for k, v in prof.items()},
+                "sparse_path": {1: "k_verify_seeds + k_flood_refine + k_rare (three launches)",
+                                2: "k_verify_seeds + k_sparse_frame (one workgroup per frame: floods, refinement, emission)"}.get(det.get_option("last_sparse_path")),
                 "sum_kernel_ms_per_step": round(chain_ms, 5),
                 "a_mat_equivalent_GBps": round(px_per_step_rank * a_mat / (chain_ms * 1e-3) / 1e9, 1),
                 "a_mat_equivalent_frac_of_peak": round(px_per_step_rank * a_mat / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
