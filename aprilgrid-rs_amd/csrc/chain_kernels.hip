@@ -1663,6 +1663,8 @@ __device__ __forceinline__ int flood_lane(const ChainArgs &a, const uint32_t *ma
                 cnt += nc;
                 sumy += bitpos_sum(w);
                 sumx += nc * (uint32_t)c;
+                // (column by column: left to itself the scheduler starts all 32 columns' popcounts at once and spills at 128 registers)
+                if ((c & 3) == 3) asm volatile("" : "+v"(cnt), "+v"(sumx), "+v"(sumy));
             }
             sumx += cnt * (uint32_t)x0;  // window column 0 is image column x0 (mod 2^32 arithmetic)
             sumy += cnt * (sy - 1u);     // window row 0 is image row sy-1
