@@ -117,6 +117,10 @@ int agx_detector_set_limits(agx_detector *det, uint32_t max_candidates, uint32_t
  *   "force_generic"        1 = cluster every frame with the generic union-find kernels instead
  *                          of the windowed flood fill (results are identical; test hook)
  *   "k1_rows_per_segment"  rows one wave of the blur kernel walks (0 = automatic)
+ *   "sparse_path"          how a batch's sparse stages (verify, clusters, refinement, emission) are launched: 0 = by batch size
+ *                          (default), 1 = three batch-wide launches, 2 = one 1024-thread workgroup per frame for all of it,
+ *                          3 = the verify launch, then one workgroup per frame for the rest (what batches that fill the chip
+ *                          take by themselves).  Results are identical on every path (tests/test_gpu_sparse_paths.py)
  *   "store_response"       1 = the blur kernel also stores the Hessian response it evaluates in
  *                          registers (parity tests: agx_debug_fetch AGX_DBG_RESP); slower
  *   "profile_stride"       with agx_profile_enable(det, 1): time the blur kernel of every n-th batch
@@ -134,10 +138,13 @@ int agx_detector_set_limits(agx_detector *det, uint32_t max_candidates, uint32_t
  *                          work -- timing experiments, results are INVALID; bits 128 / 2048 / 8192 / 16384 collect
  *                          statistics and phase times (AGX_DBG_VERIFY_STATS), 4096 the start and end of every wave of
  *                          the sparse kernels (AGX_DBG_WAVE_TIMES), 32768 selects the blur kernel's former ascending
- *                          segment order, 65536 its former refresh interval: results unchanged (tests/test_gpu_parity.py) */
+ *                          segment order, 65536 its former refresh interval, 131072 / 262144 stage and phase times of the
+ *                          workgroup-per-frame kernel (tools/sparse_frame_phases.py, tools/flood_phases.py): results unchanged
+ *                          (tests/test_gpu_parity.py) */
 int agx_detector_set_option(agx_detector *det, const char *name, int value);
 /* Read an option back; additionally the tiling the blur kernel used for the last enqueued batch:
- * "k1_rows_per_segment" (effective value), "k1_segments", "k1_strips", "k1_strip_columns". */
+ * "k1_rows_per_segment" (effective value), "k1_segments", "k1_strips", "k1_strip_columns", and
+ * "last_sparse_path": 1 = the last batch took the three launches, 2 = a workgroup per frame. */
 int agx_detector_get_option(const agx_detector *det, const char *name, int *value);
 
 /* Stream selection.  external != 0: launch on the caller's stream `hip_stream` (hipStream_t as
