@@ -938,6 +938,7 @@ __device__ __forceinline__ uint32_t seed_bits(uint32_t kw, uint32_t upw)
     uint32_t alive = sd, mk = kw, uk = upw;  // rows whose run still continues and has not met a pixel with one above
 #pragma unroll
     for (int k = 1; k < 8; ++k) {
+        if (!__any(alive != 0u)) break;  // wave-uniform: no run of the wave reaches this far (clusters are a few pixels wide)
         mk = from_right_u(mk);
         uk = from_right_u(uk);
         alive &= mk;
@@ -1137,6 +1138,7 @@ __device__ __forceinline__ void verify_tiles(const ChainArgs &a, int frame, int 
             const uint32_t kw = keep[r];  // rows past the tile's end hold no bits
             const uint32_t upw = (kw << 1) | carry;  // bit q: the pixel above (column, row q) is a candidate
             carry = kw >> 31;
+            if (!__any(kw != 0u)) continue;  // wave-uniform: a word row of the tile without a candidate
             uint32_t sd = seed_bits(kw, upw);
             if (!owner) sd = 0u;
             while (sd) {
