@@ -65,5 +65,10 @@ int main()
     run<224, 32, true, false>("224 columns x 32 rows, nt", a, (double)bytes, e0, e1);
     run<224, 800, true, false>("224 columns x 800 rows, nt", a, (double)bytes, e0, e1);
     run<128, 96, true, false>("128 columns, nt", a, (double)bytes, e0, e1);
+    run<240, 96, true, false>("240 columns, nt", a, (double)bytes, e0, e1);
+    run<240, 96, false, false>("240 columns, cached", a, (double)bytes, e0, e1);
+    run<232, 96, true, false>("232 columns, nt", a, (double)bytes, e0, e1);
+    run<248, 96, true, false>("248 columns, nt", a, (double)bytes, e0, e1);
+    run<224, 96, true, false>("224 columns, nt (again)", a, (double)bytes, e0, e1);
     return 0;
 }
