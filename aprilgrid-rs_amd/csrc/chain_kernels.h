@@ -79,6 +79,7 @@ struct ChainArgs {
     int rows_per_seg;   // output rows per workgroup
     int n_segs;
     int k1_group;       // frames per dispatch group of K1 (0 or >= n_frames: the whole batch segment-major)
+    int k1_async_poll;  // K1 polls the frame's running minimum by asynchronous vector loads (few waves) / awaited scalar loads
     float publish_factor;  // a wave publishes its running minimum m only if m < factor * the frame's known minimum
     float w[7];  // blur taps
     // dense planes [n_frames][H][W]

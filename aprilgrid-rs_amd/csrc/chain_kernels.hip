@@ -407,9 +407,20 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((A4 &&
     // starts when other waves of its frame have already published (the later segments under the
     // segment-major dispatch order) thresholds against the frame's running minimum from its first row
     // on instead of against the minimum of that one row.
-    uint32_t polled;
-    asm volatile("s_load_dword %0, %1, 0x0 glc" : "=s"(polled) : "s"(&ctr.min_key_inv) : "memory");
-    bool polled_pending = true;
+    // The poll is a vector load (every lane the same word, one request) whose register is read at the NEXT sync point:
+    // the compiler's own counted wait sits in front of that read, rows later, and the wave computes in between.  (As a
+    // scalar load it had to be awaited where it was issued -- an in-flight SGPR cannot be kept from the compiler -- and
+    // with one frame on the chip every wave of the frame polls and publishes to the same L2 line at the same moment:
+    // ~2.5 us per poll, six polls per 32-row segment, 15 of K1's 45 us at 1280x800.)
+    // Batches that fill the chip keep the scalar load (a.k1_async_poll == 0, plan_k1): four other waves per SIMD cover the
+    // wait, and the vector load's counted wait would drain the blur stores at every sync point (K1 +4 % at 256 frames).
+    auto poll_min = [&]() { return __hip_atomic_load(&ctr.min_key_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    const bool async_poll = a.k1_async_poll != 0;  // wave-uniform
+    uint32_t polled_v = 0u;
+    uint32_t polled = 0u;  // the last value polled (wave-uniform)
+    if (async_poll) polled_v = poll_min();
+    else asm volatile("s_load_dword %0, %1, 0x0 glc" : "=s"(polled) : "s"(&ctr.min_key_inv) : "memory");
+    bool first_sync = true;
     float cmax = -__builtin_inff();  // weakest candidate response of this lane in the current 32-row block
     uint32_t mw[4] = {0u, 0u, 0u, 0u};  // this lane's 4 mask words (4 columns x 32 rows) in progress
     int y_pushed = 0;                    // last row whose bits were shifted into mw
@@ -679,9 +690,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((A4 &&
                         const int wmin_bits = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wmin));
                         wmin = __builtin_bit_cast(float, wmin_bits);
                         const float published = __builtin_bit_cast(float, published_bits);
-                        if (polled_pending) {  // the fetch issued at the start of the wave
-                            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(polled) : : "memory");
-                            polled_pending = false;
+                        if (async_poll) polled = __builtin_amdgcn_readfirstlane(polled_v);
+                        if (first_sync) {  // the fetch issued at the start of the wave
+                            if (!async_poll) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(polled) : : "memory");
+                            first_sync = false;
                             // a wave that starts when the frame has already published a minimum (the later dispatch rounds)
                             // refreshes less often: what it would learn it mostly knows
                             if (polled && !(a.dbg & 65536)) gap_cap = AGX_K1_SYNC_GAP_LATE;
@@ -701,9 +713,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((A4 &&
                         // assembler inserts no wait states inside asm: on gfx950 a readlane needs one
                         // after the VALU write of its source, a VALU read of the SGPR two after this)
                         asm("s_nop 0\n\tv_readfirstlane_b32 %0, %1\n\ts_nop 1" : "=s"(thr_run_bits) : "v"(fminf(wmin, gmin) * 0.05f));
-                        // scalar load past the scalar cache: its own counter (lgkmcnt), so the wave does
-                        // not have to drain its blur stores (vmcnt) to read one word
-                        asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(polled) : "s"(&ctr.min_key_inv) : "memory");
+                        if (async_poll) polled_v = poll_min();  // read at the next sync point
+                        else  // scalar load past the scalar cache, awaited here
+                            asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(polled) : "s"(&ctr.min_key_inv) : "memory");
                         rows_to_sync = sync_gap;
                         sync_gap = min(sync_gap * 2, gap_cap);
                     }
@@ -827,10 +839,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((A4 &&
     // The wave's exact minimum goes to the frame's word unless the word is known to hold something at
     // least as small already (the last value polled from it; it only ever decreases).  A word never
     // polled non-zero may still be unset: then the wave publishes in any case, so the word ends up valid.
-    if (polled_pending) {
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(polled) : : "memory");
-        polled_pending = false;
-    }
+    if (async_poll) polled = __builtin_amdgcn_readfirstlane(polled_v);
+    else if (first_sync) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(polled) : : "memory");  // (a wave without a sync point)
     const bool known_smaller = polled != 0u && !(run_min < f32_from_order_key(~polled));
     if (lane == 0 && !known_smaller) atomicMax(&ctr.min_key_inv, ~f32_order_key(run_min));
 }
@@ -2469,7 +2479,8 @@ __device__ __forceinline__ bool emit_large_split(const ChainArgs &a, int frame, 
             ctr.out_offset = off;
             if (a.frame_table) {
                 uint32_t *row = a.frame_table + (size_t)frame * 4;
-                const uint32_t flags = __hip_atomic_load(&ctr.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // (part 0 sets FLAG_LARGE_RESULT in the frame's record; the part that writes the row may be here before that lands)
+                const uint32_t flags = __hip_atomic_load(&ctr.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | FLAG_LARGE_RESULT;
                 const bool bad = (flags & (FLAG_CAND_OVERFLOW | FLAG_ROOT_OVERFLOW | FLAG_OUT_OVERFLOW)) != 0;
                 row[0] = bad ? 0u : nf;
                 row[1] = off;
@@ -2706,6 +2717,7 @@ static int env_int(const char *name, int dflt)
     return (s && *s) ? atoi(s) : dflt;
 }
 
+constexpr long long K1_ASYNC_POLL_MAX_WAVES = 4608;  // measured crossover: 1280x800 x 16 (2 400 waves) and 1920x1080 x 16 (4 352) gain, 1280x800 x 32 (4 800) loses (profiles/r4_k1_async_poll.txt)
 bool plan_k1(ChainArgs &a, int override_rows_per_seg)
 {
     const int W = a.W, H = a.H;
@@ -2744,6 +2756,9 @@ bool plan_k1(ChainArgs &a, int override_rows_per_seg)
     a.n_segs = (H + rps - 1) / rps;
     a.publish_factor = a.n_strips * a.n_segs > 128 ? 1.5f : 1.0f;  // see the publish step of K1
     a.k1_group = env_int("AGX_K1_GROUP", 0);
+    // threshold polls as asynchronous vector loads while the waves are (nearly) alone on their SIMDs; see K1
+    const int ap = env_int("AGX_K1_ASYNC_POLL", -1);  // tuning override: 0 / 1
+    a.k1_async_poll = ap >= 0 ? (ap != 0) : ((long long)a.n_strips * a.n_segs * a.n_frames <= K1_ASYNC_POLL_MAX_WAVES);
     return true;
 }
 

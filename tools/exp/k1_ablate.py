@@ -5,7 +5,8 @@ sys.path.insert(0, ".")
 import torch
 import aprilgrid_rs_amd as A
 from aprilgrid_rs_amd import synth
-frames, _ = synth.render_batch(0, 256, 1280, 800, device="cuda")
+F_ = int(os.environ.get("FRAMES", "256"))
+frames, _ = synth.render_batch(0, F_, 1280, 800, device="cuda")
 det = A.TagDetector("t36h11")
 def run(dbg):
     det.set_option("debug_ablation", dbg)
