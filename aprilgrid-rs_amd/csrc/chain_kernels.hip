@@ -262,6 +262,9 @@ __device__ __forceinline__ int H_full_segs(const ChainArgs &a) { return a.H / a.
 
 // RESP: debug instantiation (agx_detector_set_option "store_response") that also stores the
 // determinant this kernel evaluates in registers, for the parity tests (AGX_DBG_RESP).
+#ifndef AGX_K1_VALU_MASK
+#define AGX_K1_VALU_MASK 1  // the row's compare / mask / weakest-candidate block on the vector ALU alone (0: through the scalar unit)
+#endif
 #ifndef AGX_BLUR_STORE_AUX
 #define AGX_BLUR_STORE_AUX 2  // cache policy bits of the blur plane's buffer stores: 2 = nt (the plane is written once and read
 // sparsely two launches later; kept out of the caches' way, the sparse kernels' misses do not have to evict it first)
@@ -401,6 +404,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((A4 &&
     uint32_t *mask_f = a.mask + (size_t)frame * (size_t)a.mask_plane;
     // wave-uniform; kept as bit patterns so that they live in scalar registers
     int thr_run_bits = 0, published_bits = 0;  // 0.0f
+    // VALU_MASK: the row's candidate bits without the scalar unit in the chain (see the row's compare block): the running
+    // threshold per column of the lane, -inf for columns that are not its own (halo lanes, the image's border ring)
+    constexpr bool VALU_MASK = AGX_K1_VALU_MASK != 0 && !(FMT != 3 && AGX_K1_DEFER_ROWS > 0);
+    float thr_v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     int rows_to_sync = 0, sync_gap = 1, gap_cap = AGX_K1_SYNC_GAP_MAX;
     // ctr.min_key_inv as fetched at the previous sync point.  The first fetch is issued right here, at
     // the start of the wave, and awaited at the first sync point seven warm-up rows later: a wave that
@@ -432,6 +439,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((A4 &&
     for (int j = 0; j < 4; ++j) {
         min_ok[j] = lane_valid && (c0 + j > 0) && (c0 + j < W - 1);
         ok_mask[j] = __ballot(min_ok[j]);
+    }
+    if (VALU_MASK) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) thr_v[j] = min_ok[j] ? 0.0f : -__builtin_inff();
     }
     auto lane_min = [&]() {
         float v = 0.0f;
@@ -713,6 +724,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((A4 &&
                         // assembler inserts no wait states inside asm: on gfx950 a readlane needs one
                         // after the VALU write of its source, a VALU read of the SGPR two after this)
                         asm("s_nop 0\n\tv_readfirstlane_b32 %0, %1\n\ts_nop 1" : "=s"(thr_run_bits) : "v"(fminf(wmin, gmin) * 0.05f));
+                        if (VALU_MASK) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) thr_v[j] = min_ok[j] ? __builtin_bit_cast(float, thr_run_bits) : -__builtin_inff();
+                        }
                         if (async_poll) polled_v = poll_min();  // read at the next sync point
                         else  // scalar load past the scalar cache, awaited here
                             asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(polled) : "s"(&ctr.min_key_inv) : "memory");
@@ -725,41 +740,71 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((A4 &&
                     // rows enter at bit 0, the word is bit-reversed when it is stored).  One block with
                     // the four columns interleaved: a VALU-written SGPR needs two wait states before
                     // a VALU reads it on gfx950, which the assembler does not insert inside asm.
-                    uint64_t cj[4], cj_any;  // cj_any: some lane has a candidate in this row
-                    asm("v_cmp_lt_f32_e64 %[c0], %[d0], %[thr]\n\t"
-                        "v_cmp_lt_f32_e64 %[c1], %[d1], %[thr]\n\t"
-                        "v_cmp_lt_f32_e64 %[c2], %[d2], %[thr]\n\t"
-                        "v_cmp_lt_f32_e64 %[c3], %[d3], %[thr]\n\t"
-                        "s_and_b64 %[c0], %[c0], %[k0]\n\t"
-                        "s_and_b64 %[c1], %[c1], %[k1]\n\t"
-                        "s_and_b64 %[c2], %[c2], %[k2]\n\t"
-                        "s_and_b64 %[c3], %[c3], %[k3]\n\t"
-                        "v_addc_co_u32_e64 %[m0], vcc, %[m0], %[m0], %[c0]\n\t"
-                        "v_addc_co_u32_e64 %[m1], vcc, %[m1], %[m1], %[c1]\n\t"
-                        "v_addc_co_u32_e64 %[m2], vcc, %[m2], %[m2], %[c2]\n\t"
-                        "v_addc_co_u32_e64 %[m3], vcc, %[m3], %[m3], %[c3]\n\t"
-                        "s_or_b64 %[any], %[c0], %[c1]\n\t"
-                        "s_or_b64 %[any], %[any], %[c2]\n\t"
-                        "s_or_b64 %[any], %[any], %[c3]"
-                        : [m0] "+v"(mw[0]), [m1] "+v"(mw[1]), [m2] "+v"(mw[2]), [m3] "+v"(mw[3]),
-                          [c0] "=&s"(cj[0]), [c1] "=&s"(cj[1]), [c2] "=&s"(cj[2]), [c3] "=&s"(cj[3]), [any] "=&s"(cj_any)
-                        : [d0] "v"(dv[0]), [d1] "v"(dv[1]), [d2] "v"(dv[2]), [d3] "v"(dv[3]), [thr] "s"(thr_run_bits),
-                          [k0] "s"(ok_mask[0]), [k1] "s"(ok_mask[1]), [k2] "s"(ok_mask[2]), [k3] "s"(ok_mask[3])
-                        : "vcc", "scc");  // s_and_b64 writes SCC
-                    const bool defer_row = DEFER && __builtin_expect((y - ys) < K1_DEFER_ROWS, 0);  // wave-uniform, 10 rows of a segment
-                    if (defer_row) {  // the row's bits are decided again later: keep its responses (bf16, truncated)
-                        uint2 pk;
-                        pk.x = __builtin_amdgcn_perm(__float_as_uint(dv[1]), __float_as_uint(dv[0]), 0x07060302u);
-                        pk.y = __builtin_amdgcn_perm(__float_as_uint(dv[3]), __float_as_uint(dv[2]), 0x07060302u);
-                        s_def[wv][y - ys][lane_id_here()] = pk;
-                    }
-                    if (cj_any != 0ull && !defer_row) {  // wave-uniform; most rows have no candidate
-                        float sel[4];  // the candidate's response, or the current maximum itself
+                    if constexpr (VALU_MASK) {
+                        // All on the vector ALU: compare against the column's own threshold (lane mask in an SGPR pair),
+                        // add-with-carry into the word, and the block's weakest candidate kept unconditionally (the candidate's
+                        // response, or the current maximum itself).  The former block went VALU -> SALU (s_and with the
+                        // column masks, s_or for "any candidate in this row") -> VALU and branched on the s_or: with one
+                        // wave per SIMD the round trips through the scalar unit were the longest stretch of the row.
+                        uint64_t cj[4];
+                        float sel[4];
+                        asm("v_cmp_lt_f32_e64 %[c0], %[d0], %[t0]\n\t"
+                            "v_cmp_lt_f32_e64 %[c1], %[d1], %[t1]\n\t"
+                            "v_cmp_lt_f32_e64 %[c2], %[d2], %[t2]\n\t"
+                            "v_cmp_lt_f32_e64 %[c3], %[d3], %[t3]\n\t"
+                            "v_addc_co_u32_e64 %[m0], vcc, %[m0], %[m0], %[c0]\n\t"
+                            "v_addc_co_u32_e64 %[m1], vcc, %[m1], %[m1], %[c1]\n\t"
+                            "v_addc_co_u32_e64 %[m2], vcc, %[m2], %[m2], %[c2]\n\t"
+                            "v_addc_co_u32_e64 %[m3], vcc, %[m3], %[m3], %[c3]\n\t"
+                            "v_cndmask_b32_e64 %[s0], %[cm], %[d0], %[c0]\n\t"
+                            "v_cndmask_b32_e64 %[s1], %[cm], %[d1], %[c1]\n\t"
+                            "v_cndmask_b32_e64 %[s2], %[cm], %[d2], %[c2]\n\t"
+                            "v_cndmask_b32_e64 %[s3], %[cm], %[d3], %[c3]\n\t"
+                            "v_max3_f32 %[cm], %[cm], %[s0], %[s1]\n\t"
+                            "v_max3_f32 %[cm], %[cm], %[s2], %[s3]"
+                            : [m0] "+v"(mw[0]), [m1] "+v"(mw[1]), [m2] "+v"(mw[2]), [m3] "+v"(mw[3]), [cm] "+v"(cmax),
+                              [c0] "=&s"(cj[0]), [c1] "=&s"(cj[1]), [c2] "=&s"(cj[2]), [c3] "=&s"(cj[3]),
+                              [s0] "=&v"(sel[0]), [s1] "=&v"(sel[1]), [s2] "=&v"(sel[2]), [s3] "=&v"(sel[3])
+                            : [d0] "v"(dv[0]), [d1] "v"(dv[1]), [d2] "v"(dv[2]), [d3] "v"(dv[3]),
+                              [t0] "v"(thr_v[0]), [t1] "v"(thr_v[1]), [t2] "v"(thr_v[2]), [t3] "v"(thr_v[3])
+                            : "vcc");
+                    } else {
+                        uint64_t cj[4], cj_any;  // cj_any: some lane has a candidate in this row
+                        asm("v_cmp_lt_f32_e64 %[c0], %[d0], %[thr]\n\t"
+                            "v_cmp_lt_f32_e64 %[c1], %[d1], %[thr]\n\t"
+                            "v_cmp_lt_f32_e64 %[c2], %[d2], %[thr]\n\t"
+                            "v_cmp_lt_f32_e64 %[c3], %[d3], %[thr]\n\t"
+                            "s_and_b64 %[c0], %[c0], %[k0]\n\t"
+                            "s_and_b64 %[c1], %[c1], %[k1]\n\t"
+                            "s_and_b64 %[c2], %[c2], %[k2]\n\t"
+                            "s_and_b64 %[c3], %[c3], %[k3]\n\t"
+                            "v_addc_co_u32_e64 %[m0], vcc, %[m0], %[m0], %[c0]\n\t"
+                            "v_addc_co_u32_e64 %[m1], vcc, %[m1], %[m1], %[c1]\n\t"
+                            "v_addc_co_u32_e64 %[m2], vcc, %[m2], %[m2], %[c2]\n\t"
+                            "v_addc_co_u32_e64 %[m3], vcc, %[m3], %[m3], %[c3]\n\t"
+                            "s_or_b64 %[any], %[c0], %[c1]\n\t"
+                            "s_or_b64 %[any], %[any], %[c2]\n\t"
+                            "s_or_b64 %[any], %[any], %[c3]"
+                            : [m0] "+v"(mw[0]), [m1] "+v"(mw[1]), [m2] "+v"(mw[2]), [m3] "+v"(mw[3]),
+                              [c0] "=&s"(cj[0]), [c1] "=&s"(cj[1]), [c2] "=&s"(cj[2]), [c3] "=&s"(cj[3]), [any] "=&s"(cj_any)
+                            : [d0] "v"(dv[0]), [d1] "v"(dv[1]), [d2] "v"(dv[2]), [d3] "v"(dv[3]), [thr] "s"(thr_run_bits),
+                              [k0] "s"(ok_mask[0]), [k1] "s"(ok_mask[1]), [k2] "s"(ok_mask[2]), [k3] "s"(ok_mask[3])
+                            : "vcc", "scc");  // s_and_b64 writes SCC
+                        const bool defer_row = DEFER && __builtin_expect((y - ys) < K1_DEFER_ROWS, 0);  // wave-uniform, 10 rows of a segment
+                        if (defer_row) {  // the row's bits are decided again later: keep its responses (bf16, truncated)
+                            uint2 pk;
+                            pk.x = __builtin_amdgcn_perm(__float_as_uint(dv[1]), __float_as_uint(dv[0]), 0x07060302u);
+                            pk.y = __builtin_amdgcn_perm(__float_as_uint(dv[3]), __float_as_uint(dv[2]), 0x07060302u);
+                            s_def[wv][y - ys][lane_id_here()] = pk;
+                        }
+                        if (cj_any != 0ull && !defer_row) {  // wave-uniform; most rows have no candidate
+                            float sel[4];  // the candidate's response, or the current maximum itself
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(sel[j]) : "v"(cmax), "v"(dv[j]), "s"(cj[j]));
-                        cmax = fmaxf(fmaxf(cmax, sel[0]), sel[1]);
-                        cmax = fmaxf(fmaxf(cmax, sel[2]), sel[3]);
+                            for (int j = 0; j < 4; ++j)
+                                asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(sel[j]) : "v"(cmax), "v"(dv[j]), "s"(cj[j]));
+                            cmax = fmaxf(fmaxf(cmax, sel[0]), sel[1]);
+                            cmax = fmaxf(fmaxf(cmax, sel[2]), sel[3]);
+                        }
                     }
                     y_pushed = y;
                 }
