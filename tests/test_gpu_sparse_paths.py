@@ -87,3 +87,27 @@ def test_batch_size_selects_the_path():
         d.sync()
         assert d.get_option("last_sparse_path") == expect, n
     d.close()
+
+
+@pytest.mark.parametrize("fmt", ["L8", "L16", "RGB8"])
+def test_k1_poll_forms_agree_bit_for_bit(monkeypatch, fmt):
+    """K1 polls the frame's running minimum by an awaited scalar load (batches that fill the chip) or by an asynchronous vector
+    load (few waves: plan_k1).  Both forms forced on a batch either would take: the blur plane, the frame minimum and the lists are
+    identical, and a batch of each size takes the form the planner documents."""
+    import torch
+    import aprilgrid_rs_amd as A
+    synth = synth_module()
+    frames, _ = synth.render_batch(21, 6, 640, 416, device="cuda", fmt=fmt)
+    got = {}
+    for form in ("0", "1"):
+        monkeypatch.setenv("AGX_K1_ASYNC_POLL", form)
+        d = A.TagDetector("t36h11", None, device=0)
+        d.saddles_batch_enqueue(frames)
+        res, status = d.saddles_batch_fetch()
+        assert (status == 0).all()
+        got[form] = ([r.tobytes() for r in res], [float(d.debug_fetch(i, "min")) for i in range(len(res))],
+                     d.debug_fetch(2, "blur", (416, 640)).tobytes())
+        d.close()
+    assert got["0"] == got["1"]
+    monkeypatch.delenv("AGX_K1_ASYNC_POLL")
+    torch.cuda.synchronize()
