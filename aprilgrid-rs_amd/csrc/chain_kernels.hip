@@ -107,6 +107,36 @@ __device__ __forceinline__ uint32_t from_right_u(uint32_t v)
 // The lane id recomputed where it is used (2 VALU): values that are needed once every few rows are derived
 // from it on the spot instead of living in registers across K1's row loop (the kernel sits exactly at
 // the 5-waves-per-SIMD register limit, and the compiler hoists anything loop-invariant).
+// OR (minimum) of a value over the wave, wave-uniform result: four row shifts, two row broadcasts and a readlane on the
+// vector ALU.  (The __shfl_xor butterfly is six ds_bpermute round trips through LDS, ~100 cycles each for a wave that has
+// nothing else to do meanwhile: k_verify_seeds reduces up to five words per tile.)
+__device__ __forceinline__ uint32_t wave_or_u32(uint32_t v)
+{
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);  // row_shr:1 (lanes without a source: 0)
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);  // row_shr:2
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);  // row_shr:4
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);  // row_shr:8  -> lane 15 of a row: the row
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);  // row_bcast:15 into rows 1, 3
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);  // row_bcast:31 into rows 2, 3 -> lane 63: the wave
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_min_step(float f)
+{
+    const float inf = __builtin_inff();  // lanes without a source, rows outside the mask: their own value stands
+    return fminf(f, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, inf), __builtin_bit_cast(int, f), CTRL, ROW_MASK, 0xf, false)));
+}
+__device__ __forceinline__ float wave_min_f32(float f)
+{
+    f = dpp_min_step<0x111, 0xf>(f);
+    f = dpp_min_step<0x112, 0xf>(f);
+    f = dpp_min_step<0x114, 0xf>(f);
+    f = dpp_min_step<0x118, 0xf>(f);
+    f = dpp_min_step<0x142, 0xa>(f);
+    f = dpp_min_step<0x143, 0xc>(f);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, f), 63));
+}
+
 __device__ __forceinline__ int lane_id_here()
 {
     int l;
@@ -146,8 +176,8 @@ constexpr int K1_DEFER_ROWS = AGX_K1_DEFER_ROWS > 0 ? AGX_K1_DEFER_ROWS : 1;
 struct WaveTimer {
     unsigned long long *rec;
     unsigned long long t0;
-    __device__ __forceinline__ WaveTimer(const ChainArgs &a, int kernel)
-        : rec(a.wave_times ? a.wave_times + 2 * ((size_t)(kernel - 1) * WAVE_TIMES_STRIDE + (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) : nullptr), t0(0)
+    __device__ __forceinline__ WaveTimer(const ChainArgs &a, int kernel, bool on = true)
+        : rec(on && a.wave_times ? a.wave_times + 2 * ((size_t)(kernel - 1) * WAVE_TIMES_STRIDE + (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) : nullptr), t0(0)
     {
         if (rec) t0 = wall_clock64();
     }
@@ -695,11 +725,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((A4 &&
                     // the value fetched at the previous one and issues the next fetch without
                     // waiting for it (a staler threshold is only a slightly larger superset).
                     if (rows_to_sync <= 0 && !(a.dbg & 16)) {
-                        float wmin = lane_min();
-#pragma unroll
-                        for (int off = 32; off > 0; off >>= 1) wmin = fminf(wmin, __shfl_xor(wmin, off, 64));
-                        const int wmin_bits = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wmin));
-                        wmin = __builtin_bit_cast(float, wmin_bits);
+                        float wmin = wave_min_f32(lane_min());
+                        const int wmin_bits = __builtin_bit_cast(int, wmin);
                         const float published = __builtin_bit_cast(float, published_bits);
                         if (async_poll) polled = __builtin_amdgcn_readfirstlane(polled_v);
                         if (first_sync) {  // the fetch issued at the start of the wave
@@ -878,9 +905,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((A4 &&
         }
     }
     // per-frame min: wave reduction, one atomic per wave
-    float run_min = lane_min();
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) run_min = fminf(run_min, __shfl_xor(run_min, off, 64));
+    const float run_min = wave_min_f32(lane_min());
     // The wave's exact minimum goes to the frame's word unless the word is known to hold something at
     // least as small already (the last value polled from it; it only ever decreases).  A word never
     // polled non-zero may still be unset: then the wave publishes in any case, so the word ends up valid.
@@ -1006,9 +1031,16 @@ __device__ __forceinline__ uint32_t seed_bits(uint32_t kw, uint32_t upw)
 
 // Tiles first_tile, first_tile + tile_stride, ... of `frame` by one wave of k_verify_seeds (the tile's seeds are collected
 // in the wave's LDS and appended to the frame's global list with one atomic per tile; s_nseeds / s_base: the wave's own words).
+// DBG: the instantiation that looks at the debug_ablation bits (statistics, phase clocks, ablations); the product's has none of
+// their tests in its loops (k_verify_seeds -2 us per batch: the kernel is a chain of short scalar-controlled steps).
+constexpr uint32_t K2_DBG_BITS = 32u | 64u | 128u | 256u | 2048u | 8192u;
+// GRID3: the launch is (frames, column groups, row chunks) -- one tile per wave, its coordinates are the workgroup's own (no
+// integer divisions per wave: three of them were a tenth of the wave's instructions).
+template <bool DBG, bool GRID3 = false>
 __device__ __forceinline__ void verify_tiles(const ChainArgs &a, int frame, int first_tile, int tile_stride, uint32_t *s_keep,
                                              uint32_t *s_list, uint32_t *s_nseeds_p, uint32_t *s_base_p)
 {
+    const uint32_t dbg = DBG ? a.dbg : 0u;
     uint32_t *s_seeds = s_list;
     uint32_t &s_nseeds = *s_nseeds_p, &s_base = *s_base_p;
     FrameCounters &ctr = a.ctr[frame];
@@ -1018,13 +1050,13 @@ __device__ __forceinline__ void verify_tiles(const ChainArgs &a, int frame, int 
     const int W = a.W, wpr = a.mask_wpr;
     const int lane = threadIdx.x & 63;
     const int n_yb = (a.H + 31) >> 5;
-    const int groups = (W + VS_OWN - 1) / VS_OWN;
-    const int tiles = ((n_yb + VS_ROWS - 1) / VS_ROWS) * groups;
+    const int groups = GRID3 ? (int)gridDim.y : (W + VS_OWN - 1) / VS_OWN;
+    const int tiles = GRID3 ? first_tile + 1 : ((n_yb + VS_ROWS - 1) / VS_ROWS) * groups;
     if (lane == 0) s_nseeds = 0u;
     wave_lds_sync();
     // debug_ablation & 8192: where a wave's time goes -- 10 ns ticks per phase summed into the frame's stats[0..5]
     // (first loads, block maxima + threshold, work list + re-tests, seeds, list append, rest), tiles in stats[7]
-    const bool phase_on = (a.dbg & 8192) != 0;
+    const bool phase_on = (dbg & 8192) != 0;
     unsigned long long t_prev = phase_on ? wall_clock64() : 0ull;
     auto phase = [&](int which) {
         if (phase_on) {
@@ -1034,7 +1066,7 @@ __device__ __forceinline__ void verify_tiles(const ChainArgs &a, int frame, int 
         }
     };
     for (int t = first_tile; t < tiles; t += tile_stride) {  // wave-uniform
-        const int ch = t / groups, g = t - ch * groups;
+        const int ch = GRID3 ? (int)blockIdx.z : t / groups, g = GRID3 ? (int)blockIdx.y : t - ch * groups;
         const int yb0 = ch * VS_ROWS;
         const int x = g * VS_OWN - 1 + lane;  // -1 .. W + 62: inside the mask's zero padding
         uint32_t *wp0 = mask + (size_t)yb0 * wpr + MASK_PAD_X + x;
@@ -1081,7 +1113,7 @@ __device__ __forceinline__ void verify_tiles(const ChainArgs &a, int frame, int 
             if (m[r] && !(cm[r] < thr)) needmask |= 1u << r;
         const bool up_retest = up_need && !(cmu < thr);
         if (phase_on) { (void)__any(needmask != 0u || up_retest); phase(1); }
-        if (a.dbg & 128) {  // statistics by word row within the K1 segment (4 word rows of 128 rows)
+        if (dbg & 128) {  // statistics by word row within the K1 segment (4 word rows of 128 rows)
             const bool own = lane >= 1 && lane <= VS_OWN && x < W;
 #pragma unroll
             for (int r = 0; r < VS_ROWS; ++r)
@@ -1095,7 +1127,7 @@ __device__ __forceinline__ void verify_tiles(const ChainArgs &a, int frame, int 
                     }
                 }
         }
-        if (a.dbg & 2048) {  // where the re-tested bits sit: by image row inside a segment's first word row, by segment
+        if (dbg & 2048) {  // where the re-tested bits sit: by image row inside a segment's first word row, by segment
             const bool own = lane >= 1 && lane <= VS_OWN && x < W;
 #pragma unroll
             for (int r = 0; r < VS_ROWS; ++r)
@@ -1117,11 +1149,8 @@ __device__ __forceinline__ void verify_tiles(const ChainArgs &a, int frame, int 
         for (int r = 0; r < VS_ROWS; ++r) keep[r] = m[r];
         uint32_t upbit = up_need ? 1u : 0u;
         const unsigned long long need_any = __ballot(needmask != 0u || up_retest);
-        if (need_any && !(a.dbg & 32)) {  // wave-uniform
-            uint32_t rows_any = needmask;  // wave OR of the word rows that need the blur plane
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) rows_any |= __shfl_xor(rows_any, off, 64);
-            rows_any = __builtin_amdgcn_readfirstlane(rows_any);
+        if (need_any && !(dbg & 32)) {  // wave-uniform
+            const uint32_t rows_any = wave_or_u32(needmask);  // the word rows that need the blur plane
             uint32_t n_list = 0;  // wave-uniform fill of s_list
             auto run_list = [&]() {
                 wave_lds_sync();
@@ -1136,7 +1165,7 @@ __device__ __forceinline__ void verify_tiles(const ChainArgs &a, int frame, int 
                         ent[q] = s_list[on[q] ? e : 0u];  // (word row * 64 + lane) << 5 | bit
                         const int ln = (int)((ent[q] >> 5) & 63u), r = (int)(ent[q] >> 11), b = (int)(ent[q] & 31u);
                         const int row = r == VS_ROWS ? yb0 * 32 - 1 : (yb0 + r) * 32 + b;
-                        d[q] = (a.dbg & 256) ? 0.0f : det_at(blur + (size_t)row * W + (g * VS_OWN - 1 + ln), W);
+                        d[q] = (dbg & 256) ? 0.0f : det_at(blur + (size_t)row * W + (g * VS_OWN - 1 + ln), W);
                     }
 #pragma unroll
                     for (int q = 0; q < 2; ++q)
@@ -1159,10 +1188,7 @@ __device__ __forceinline__ void verify_tiles(const ChainArgs &a, int frame, int 
                 if (!(rows_any & (1u << r))) continue;  // wave-uniform
                 s_keep[r * 64 + lane] = m[r];
                 const uint32_t mr = (needmask & (1u << r)) ? m[r] : 0u;
-                uint32_t bits_any = mr;
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) bits_any |= __shfl_xor(bits_any, off, 64);
-                bits_any = __builtin_amdgcn_readfirstlane(bits_any);
+                uint32_t bits_any = wave_or_u32(mr);
                 while (bits_any) {  // scalar loop over the image rows of this word row that any lane needs
                     const int b = __builtin_ctz(bits_any);
                     bits_any &= bits_any - 1;
@@ -1180,14 +1206,14 @@ __device__ __forceinline__ void verify_tiles(const ChainArgs &a, int frame, int 
 #pragma unroll
         for (int r = 0; r < VS_ROWS; ++r)
             if (owner && keep[r] != m[r]) wp0[(size_t)r * wpr] = keep[r];
-        if (a.dbg & 128) {
+        if (dbg & 128) {
 #pragma unroll
             for (int r = 0; r < VS_ROWS; ++r)
                 if (owner && m[r]) atomicAdd(&ctr.stats[16 + ((yb0 + r) & 3)], (uint32_t)__popc(keep[r]));  // bits that stay
         }
         // seeds, word row by word row; the bit above a word's row 0 is bit 31 of the word before
         uint32_t carry = upbit;
-        if (a.dbg & 64) continue;
+        if (dbg & 64) continue;
 #pragma unroll
         for (int r = 0; r < VS_ROWS; ++r) {
             const uint32_t kw = keep[r];  // rows past the tile's end hold no bits
@@ -1231,17 +1257,23 @@ __device__ __forceinline__ void verify_tiles(const ChainArgs &a, int frame, int 
     }
 }
 
+template <bool DBG, bool GRID3 = false>
 __global__ void __launch_bounds__(64 * VS_WAVES) AGX_VS_ATTR k_verify_seeds(ChainArgs a)
 {
+    static_assert(!GRID3 || VS_WAVES == 1, "one tile per workgroup");
     __shared__ uint32_t s_keep_all[VS_WAVES][(VS_ROWS + 1) * 64];  // row VS_ROWS: bit 0 = the pixel above the tile's first row
     __shared__ uint32_t s_list_all[VS_WAVES][VS_LIST];  // re-test work list, then the tile's seeds (VS_SEEDS <= VS_LIST)
     __shared__ uint32_t s_nseeds_all[VS_WAVES], s_base_all[VS_WAVES];
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const WaveTimer wt(a, K_THRESHOLD);
+    const WaveTimer wt(a, K_THRESHOLD, DBG);
+    if (GRID3) {  // x = frame (fastest: tile t of every frame before tile t + 1 of any, as the slot-major linear grid), y, z = the tile
+        verify_tiles<DBG, true>(a, a.n_frames - 1 - (int)blockIdx.x, 0, 1, s_keep_all[0], s_list_all[0], &s_nseeds_all[0], &s_base_all[0]);
+        return;
+    }
     FrameSlot fs = frame_slot(a.n_frames, true);  // latest-written blur planes first (cache)
     fs.slot = fs.slot * VS_WAVES + (uint32_t)wv;  // this wave's slot of the frame
     fs.n_slots *= VS_WAVES;
-    verify_tiles(a, fs.frame, (int)fs.slot, (int)fs.n_slots, s_keep_all[wv], s_list_all[wv], &s_nseeds_all[wv], &s_base_all[wv]);
+    verify_tiles<DBG>(a, fs.frame, (int)fs.slot, (int)fs.n_slots, s_keep_all[wv], s_list_all[wv], &s_nseeds_all[wv], &s_base_all[wv]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1386,10 +1418,7 @@ __device__ __forceinline__ void verify_frame(const ChainArgs &a, int frame, cons
                         vl.pix[slot] = (uint32_t)((yb0 + r) * 32) * (uint32_t)W + (uint32_t)x;
                         vl.keep[slot] = mr;
                     }
-                    uint32_t bits_any = mr;
-#pragma unroll
-                    for (int off = 32; off > 0; off >>= 1) bits_any |= __shfl_xor(bits_any, off, 64);
-                    bits_any = __builtin_amdgcn_readfirstlane(bits_any);
+                    uint32_t bits_any = wave_or_u32(mr);
                     while (bits_any) {  // scalar loop over the image rows of this word row that any lane needs
                         const int b = __builtin_ctz(bits_any);
                         bits_any &= bits_any - 1;
@@ -2866,7 +2895,11 @@ int launch_kernel(int which, const ChainArgs &a, const RefineConsts &rc, void *s
         if (tiles > 512) tiles = 512;
         const int per_frame = (env_int("AGX_G_VERIFY", tiles) + VS_WAVES - 1) / VS_WAVES;  // workgroups of VS_WAVES waves
         dim3 grid((unsigned)per_frame * (unsigned)a.n_frames), block(64 * VS_WAVES);  // slot-major, see frame_slot
-        hipLaunchKernelGGL(k_verify_seeds, grid, block, 0, st, a);
+        if ((a.dbg & K2_DBG_BITS) || a.wave_times) hipLaunchKernelGGL(k_verify_seeds<true>, grid, block, 0, st, a);
+        else if (VS_WAVES == 1 && env_int("AGX_G_VERIFY", 0) <= 0 && (n_yb + VS_ROWS - 1) / VS_ROWS <= 65535 && (a.W + VS_OWN - 1) / VS_OWN <= 65535)
+            hipLaunchKernelGGL((k_verify_seeds<false, VS_WAVES == 1>), dim3((unsigned)a.n_frames, (unsigned)((a.W + VS_OWN - 1) / VS_OWN), (unsigned)((n_yb + VS_ROWS - 1) / VS_ROWS)),
+                               block, 0, st, a);
+        else hipLaunchKernelGGL(k_verify_seeds<false>, grid, block, 0, st, a);
         return hipGetLastError();
     }
     case K_FLOOD_REFINE: {
