@@ -992,6 +992,10 @@ constexpr uint32_t VS_SEEDS = 256; // seeds buffered per tile
 #define AGX_VS_WAVES 1
 #endif
 constexpr int VS_WAVES = AGX_VS_WAVES;
+#ifndef AGX_VS_RT
+#define AGX_VS_RT 2
+#endif
+constexpr int VS_RT = AGX_VS_RT;  // re-tested bits per lane and round trip of k_verify_seeds
 // orders the LDS traffic of ONE wave (its lanes exchange data through LDS; the LDS queue of a wave is in order)
 __device__ __forceinline__ void wave_lds_sync()
 {
@@ -1154,12 +1158,12 @@ __device__ __forceinline__ void verify_tiles(const ChainArgs &a, int frame, int 
             uint32_t n_list = 0;  // wave-uniform fill of s_list
             auto run_list = [&]() {
                 wave_lds_sync();
-                for (uint32_t e0 = 0; e0 < n_list; e0 += 128) {  // two bits per lane and round: 18 loads in flight
-                    float d[2];
-                    uint32_t ent[2];
-                    bool on[2];
+                for (uint32_t e0 = 0; e0 < n_list; e0 += 64 * VS_RT) {  // VS_RT bits per lane and round: 9 VS_RT loads in flight
+                    float d[VS_RT];
+                    uint32_t ent[VS_RT];
+                    bool on[VS_RT];
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) {
+                    for (int q = 0; q < VS_RT; ++q) {
                         const uint32_t e = e0 + q * 64 + (uint32_t)lane;
                         on[q] = e < n_list;
                         ent[q] = s_list[on[q] ? e : 0u];  // (word row * 64 + lane) << 5 | bit
@@ -1168,7 +1172,7 @@ __device__ __forceinline__ void verify_tiles(const ChainArgs &a, int frame, int 
                         d[q] = (dbg & 256) ? 0.0f : det_at(blur + (size_t)row * W + (g * VS_OWN - 1 + ln), W);
                     }
 #pragma unroll
-                    for (int q = 0; q < 2; ++q)
+                    for (int q = 0; q < VS_RT; ++q)
                         if (on[q] && !(d[q] < thr)) atomicAnd(&s_keep[ent[q] >> 5], ~(1u << (ent[q] & 31u)));
                 }
                 wave_lds_sync();

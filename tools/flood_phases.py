@@ -6,7 +6,7 @@ import numpy as np
 import aprilgrid_rs_amd as A
 from aprilgrid_rs_amd import synth
 F = int(os.environ.get("FRAMES", "256"))
-frames, _ = synth.render_batch(0, F, 1280, 800, device="cuda")
+frames, _ = synth.render_batch(0, F, 1280, 800, device="cuda", pure_noise=os.environ.get("NOISE", "0") == "1")
 det = A.TagDetector("t36h11")
 FUSED = os.environ.get("FUSED", "0") == "1"  # the flood + refine stage of k_sparse_frame instead of k_flood_refine
 det.set_option("sparse_path", 2 if FUSED else 1)
