@@ -2327,13 +2327,21 @@ __device__ __forceinline__ void emit_wide(const ChainArgs &a, int frame, uint32_
     keys[t] = pass ? f[0] : 0xffffffffu;
     if (t < 4) keys[TAIL_CAP + t] = 0xffffffffu;  // (padding for the 16-byte reads of the rank loop)
     const uint32_t nf = (uint32_t)__syncthreads_count(pass ? 1 : 0);
-    if (t == 0) {
-        uint32_t off = 0, fits = 1;
-        const bool ok = nf <= a.cap_out;
-        if (ok && nf) {
-            off = atomicAdd(a.total_out, nf);
-            if (off + nf > a.out_total_cap) fits = 0;  // caller's buffer is full
+    // the frame's place in the compact output: one atomic, issued now; its round trip runs under the rank loop
+    const bool ok = nf <= a.cap_out;
+    uint32_t off = 0;
+    if (t == 0 && ok && nf) off = atomicAdd(a.total_out, nf);
+    const uint32_t n4 = (n + 3u) >> 2;
+    uint32_t rank = 0;
+    if (pass) {
+        for (uint32_t j = 0; j < n4; ++j) {  // every lane reads the same 16 bytes: LDS broadcast
+            const uint4 q = reinterpret_cast<const uint4 *>(keys)[j];
+            rank += (q.x < f[0] ? 1u : 0u) + (q.y < f[0] ? 1u : 0u) + (q.z < f[0] ? 1u : 0u) + (q.w < f[0] ? 1u : 0u);
         }
+    }
+    if (t == 0) {
+        uint32_t fits = 1;
+        if (ok && nf && off + nf > a.out_total_cap) fits = 0;  // caller's buffer is full
         if (!ok || !fits) atomicOr(&ctr.flags, FLAG_OUT_OVERFLOW);
         s_misc[0] = off;
         s_misc[1] = (ok && fits) ? 1u : 0u;
@@ -2353,12 +2361,6 @@ __device__ __forceinline__ void emit_wide(const ChainArgs &a, int frame, uint32_
     __syncthreads();
     if (!pass || !s_misc[1]) return;
     float *out = a.out + (size_t)s_misc[0] * 5;
-    const uint32_t n4 = (n + 3u) >> 2;
-    uint32_t rank = 0;
-    for (uint32_t j = 0; j < n4; ++j) {  // every lane reads the same 16 bytes: LDS broadcast
-        const uint4 q = reinterpret_cast<const uint4 *>(keys)[j];
-        rank += (q.x < f[0] ? 1u : 0u) + (q.y < f[0] ? 1u : 0u) + (q.z < f[0] ? 1u : 0u) + (q.w < f[0] ? 1u : 0u);
-    }
 #pragma unroll
     for (int q = 0; q < 5; ++q) out[(size_t)rank * 5 + q] = __uint_as_float(f[q + 1]);
 }
@@ -2383,13 +2385,21 @@ __device__ __forceinline__ void emit_wide_lds(const ChainArgs &a, int frame, uin
     keys[t] = pass ? f[0] : 0xffffffffu;
     if (t < 4) keys[TAIL_CAP + t] = 0xffffffffu;  // (padding for the 16-byte reads of the rank loop)
     const uint32_t nf = (uint32_t)__syncthreads_count(pass ? 1 : 0);
-    if (t == 0) {
-        uint32_t off = 0, fits = 1;
-        const bool ok = nf <= a.cap_out;
-        if (ok && nf) {
-            off = atomicAdd(a.total_out, nf);
-            if (off + nf > a.out_total_cap) fits = 0;  // caller's buffer is full
+    // the frame's place in the compact output: one atomic, issued now; its round trip runs under the rank loop
+    const bool ok = nf <= a.cap_out;
+    uint32_t off = 0;
+    if (t == 0 && ok && nf) off = atomicAdd(a.total_out, nf);
+    const uint32_t n4 = (n + 3u) >> 2;
+    uint32_t rank = 0;
+    if (pass) {
+        for (uint32_t j = 0; j < n4; ++j) {  // every lane reads the same 16 bytes: LDS broadcast
+            const uint4 q = reinterpret_cast<const uint4 *>(keys)[j];
+            rank += (q.x < f[0] ? 1u : 0u) + (q.y < f[0] ? 1u : 0u) + (q.z < f[0] ? 1u : 0u) + (q.w < f[0] ? 1u : 0u);
         }
+    }
+    if (t == 0) {
+        uint32_t fits = 1;
+        if (ok && nf && off + nf > a.out_total_cap) fits = 0;  // caller's buffer is full
         if (!ok || !fits) *flags_lds |= FLAG_OUT_OVERFLOW;
         s_misc[0] = off;
         s_misc[1] = (ok && fits) ? 1u : 0u;
@@ -2408,12 +2418,6 @@ __device__ __forceinline__ void emit_wide_lds(const ChainArgs &a, int frame, uin
     __syncthreads();
     if (!pass || !s_misc[1]) return;
     float *out = a.out + (size_t)s_misc[0] * 5;
-    const uint32_t n4 = (n + 3u) >> 2;
-    uint32_t rank = 0;
-    for (uint32_t j = 0; j < n4; ++j) {  // every lane reads the same 16 bytes: LDS broadcast
-        const uint4 q = reinterpret_cast<const uint4 *>(keys)[j];
-        rank += (q.x < f[0] ? 1u : 0u) + (q.y < f[0] ? 1u : 0u) + (q.z < f[0] ? 1u : 0u) + (q.w < f[0] ? 1u : 0u);
-    }
 #pragma unroll
     for (int q = 0; q < 5; ++q) out[(size_t)rank * 5 + q] = __uint_as_float(f[q + 1]);
 }
