@@ -120,6 +120,17 @@ __device__ __forceinline__ uint32_t wave_or_u32(uint32_t v)
     v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);  // row_bcast:31 into rows 2, 3 -> lane 63: the wave
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
+// Inclusive prefix sum over the wave's lanes (same six DPP steps).
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);  // inclusive within each row of 16
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);  // rows 1, 3 += the row before
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);  // rows 2, 3 += rows 0 + 1
+    return v;
+}
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_min_step(float f)
 {
@@ -978,7 +989,6 @@ __device__ __forceinline__ uint32_t retest_word(const float *blur, int W, int yb
 constexpr int VS_OWN = 56;         // owner lanes of a wave (1 left halo + 56 + 7 look-ahead = 64)
 constexpr int VS_ROWS = 4;         // word rows per tile
 constexpr uint32_t VS_LIST = 512;  // re-test work list entries per pass
-constexpr uint32_t VS_SEEDS = 256; // seeds buffered per tile
 
 // Workgroups of VS_WAVES independent waves (each with its own part of the LDS arrays, no workgroup barrier): the
 // launch used to be 41 000 single-wave workgroups for 256 frames and was bound by the rate at which workgroups
@@ -1034,7 +1044,7 @@ __device__ __forceinline__ uint32_t seed_bits(uint32_t kw, uint32_t upw)
 }
 
 // Tiles first_tile, first_tile + tile_stride, ... of `frame` by one wave of k_verify_seeds (the tile's seeds are collected
-// in the wave's LDS and appended to the frame's global list with one atomic per tile; s_nseeds / s_base: the wave's own words).
+// by a prefix sum over the lanes and appended to the frame's global list with one atomic per tile).
 // DBG: the instantiation that looks at the debug_ablation bits (statistics, phase clocks, ablations); the product's has none of
 // their tests in its loops (k_verify_seeds -2 us per batch: the kernel is a chain of short scalar-controlled steps).
 constexpr uint32_t K2_DBG_BITS = 32u | 64u | 128u | 256u | 2048u | 8192u;
@@ -1042,11 +1052,9 @@ constexpr uint32_t K2_DBG_BITS = 32u | 64u | 128u | 256u | 2048u | 8192u;
 // integer divisions per wave: three of them were a tenth of the wave's instructions).
 template <bool DBG, bool GRID3 = false>
 __device__ __forceinline__ void verify_tiles(const ChainArgs &a, int frame, int first_tile, int tile_stride, uint32_t *s_keep,
-                                             uint32_t *s_list, uint32_t *s_nseeds_p, uint32_t *s_base_p)
+                                             uint32_t *s_list)
 {
     const uint32_t dbg = DBG ? a.dbg : 0u;
-    uint32_t *s_seeds = s_list;
-    uint32_t &s_nseeds = *s_nseeds_p, &s_base = *s_base_p;
     FrameCounters &ctr = a.ctr[frame];
     uint32_t *mask = a.mask + (size_t)frame * (size_t)a.mask_plane;
     const float *blur = a.blur + (size_t)frame * (size_t)a.plane;
@@ -1056,8 +1064,6 @@ __device__ __forceinline__ void verify_tiles(const ChainArgs &a, int frame, int 
     const int n_yb = (a.H + 31) >> 5;
     const int groups = GRID3 ? (int)gridDim.y : (W + VS_OWN - 1) / VS_OWN;
     const int tiles = GRID3 ? first_tile + 1 : ((n_yb + VS_ROWS - 1) / VS_ROWS) * groups;
-    if (lane == 0) s_nseeds = 0u;
-    wave_lds_sync();
     // debug_ablation & 8192: where a wave's time goes -- 10 ns ticks per phase summed into the frame's stats[0..5]
     // (first loads, block maxima + threshold, work list + re-tests, seeds, list append, rest), tiles in stats[7]
     const bool phase_on = (dbg & 8192) != 0;
@@ -1218,44 +1224,48 @@ __device__ __forceinline__ void verify_tiles(const ChainArgs &a, int frame, int 
         // seeds, word row by word row; the bit above a word's row 0 is bit 31 of the word before
         uint32_t carry = upbit;
         if (dbg & 64) continue;
+        uint32_t sdr[VS_ROWS], c = 0u;  // the lane's seed bits by word row, and how many they are
 #pragma unroll
         for (int r = 0; r < VS_ROWS; ++r) {
             const uint32_t kw = keep[r];  // rows past the tile's end hold no bits
             const uint32_t upw = (kw << 1) | carry;  // bit q: the pixel above (column, row q) is a candidate
             carry = kw >> 31;
-            if (!__any(kw != 0u)) continue;  // wave-uniform: a word row of the tile without a candidate
-            uint32_t sd = seed_bits(kw, upw);
-            if (!owner) sd = 0u;
-            while (sd) {
-                const int b = __ffs(sd) - 1;
-                sd &= sd - 1;
-                const uint32_t pix = (uint32_t)((yb0 + r) * 32 + b) * (uint32_t)W + (uint32_t)x;
-                const uint32_t i = atomicAdd(&s_nseeds, 1u);
-                if (i < VS_SEEDS) {
-                    s_seeds[i] = pix;
-                } else {  // buffer full (dense noise): straight to the frame's list
-                    const uint32_t o = atomicAdd(&ctr.n_seeds, 1u);
+            sdr[r] = 0u;
+            if (__any(kw != 0u)) {  // wave-uniform: a word row of the tile with a candidate
+                const uint32_t sd = seed_bits(kw, upw);
+                sdr[r] = owner ? sd : 0u;
+            }
+            c += (uint32_t)__popc(sdr[r]);
+        }
+        phase(3);
+        // The tile's seeds go straight to the frame's list: a prefix sum over the lanes' counts gives every lane its place behind
+        // ONE atomic of the wave (no staging in LDS, no atomic per seed; the list's order is the emission's business: it sorts).
+        if (__any(c != 0u)) {  // wave-uniform
+            // word row by word row (raster order within the tile, as the flood stage likes its neighbouring lanes): two scans of
+            // two 16-bit counts each (a row's count over the wave is at most 56 x 32)
+            static_assert(VS_ROWS == 4, "two packed scans");
+            const uint32_t c01 = (uint32_t)__popc(sdr[0]) | ((uint32_t)__popc(sdr[1]) << 16), c23 = (uint32_t)__popc(sdr[2]) | ((uint32_t)__popc(sdr[3]) << 16);
+            const uint32_t i01 = wave_incl_scan_u32(c01), i23 = wave_incl_scan_u32(c23);
+            const uint32_t t01 = (uint32_t)__builtin_amdgcn_readlane((int)i01, 63), t23 = (uint32_t)__builtin_amdgcn_readlane((int)i23, 63);
+            const uint32_t tot[VS_ROWS] = {t01 & 0xffffu, t01 >> 16, t23 & 0xffffu, t23 >> 16};
+            const uint32_t exc[VS_ROWS] = {(i01 - c01) & 0xffffu, (i01 - c01) >> 16, (i23 - c23) & 0xffffu, (i23 - c23) >> 16};
+            uint32_t base = 0u;
+            if (lane == 0) base = atomicAdd(&ctr.n_seeds, tot[0] + tot[1] + tot[2] + tot[3]);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (phase_on) phase(4);
+#pragma unroll
+            for (int r = 0; r < VS_ROWS; ++r) {
+                uint32_t sd = sdr[r], o = base + exc[r];
+                base += tot[r];
+                while (sd) {
+                    const int b = __ffs(sd) - 1;
+                    sd &= sd - 1;
+                    const uint32_t pix = (uint32_t)((yb0 + r) * 32 + b) * (uint32_t)W + (uint32_t)x;
                     if (o < a.cap_roots) a.seeds[(size_t)frame * a.cap_roots + o] = pix;
                     else atomicOr(&ctr.flags, FLAG_CAND_OVERFLOW);
+                    ++o;
                 }
             }
-        }
-        // append the tile's seeds to the frame's list: one atomic, coalesced stores
-        wave_lds_sync();
-        const uint32_t ns = min(s_nseeds, VS_SEEDS);
-        phase(3);
-        if (ns) {  // wave-uniform
-            if (lane == 0) s_base = atomicAdd(&ctr.n_seeds, ns);
-            wave_lds_sync();
-            if (phase_on) { (void)__any(s_base == 0xffffffffu); phase(4); }
-            for (uint32_t i = (uint32_t)lane; i < ns; i += 64u) {
-                const uint32_t o = s_base + i;
-                if (o < a.cap_roots) a.seeds[(size_t)frame * a.cap_roots + o] = s_seeds[i];
-                else atomicOr(&ctr.flags, FLAG_CAND_OVERFLOW);
-            }
-            wave_lds_sync();
-            if (lane == 0) s_nseeds = 0u;
-            wave_lds_sync();
         }
         phase(5);
     }
@@ -1266,18 +1276,17 @@ __global__ void __launch_bounds__(64 * VS_WAVES) AGX_VS_ATTR k_verify_seeds(Chai
 {
     static_assert(!GRID3 || VS_WAVES == 1, "one tile per workgroup");
     __shared__ uint32_t s_keep_all[VS_WAVES][(VS_ROWS + 1) * 64];  // row VS_ROWS: bit 0 = the pixel above the tile's first row
-    __shared__ uint32_t s_list_all[VS_WAVES][VS_LIST];  // re-test work list, then the tile's seeds (VS_SEEDS <= VS_LIST)
-    __shared__ uint32_t s_nseeds_all[VS_WAVES], s_base_all[VS_WAVES];
+    __shared__ uint32_t s_list_all[VS_WAVES][VS_LIST];  // re-test work list
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const WaveTimer wt(a, K_THRESHOLD, DBG);
     if (GRID3) {  // x = frame (fastest: tile t of every frame before tile t + 1 of any, as the slot-major linear grid), y, z = the tile
-        verify_tiles<DBG, true>(a, a.n_frames - 1 - (int)blockIdx.x, 0, 1, s_keep_all[0], s_list_all[0], &s_nseeds_all[0], &s_base_all[0]);
+        verify_tiles<DBG, true>(a, a.n_frames - 1 - (int)blockIdx.x, 0, 1, s_keep_all[0], s_list_all[0]);
         return;
     }
     FrameSlot fs = frame_slot(a.n_frames, true);  // latest-written blur planes first (cache)
     fs.slot = fs.slot * VS_WAVES + (uint32_t)wv;  // this wave's slot of the frame
     fs.n_slots *= VS_WAVES;
-    verify_tiles<DBG>(a, fs.frame, (int)fs.slot, (int)fs.n_slots, s_keep_all[wv], s_list_all[wv], &s_nseeds_all[wv], &s_base_all[wv]);
+    verify_tiles<DBG>(a, fs.frame, (int)fs.slot, (int)fs.n_slots, s_keep_all[wv], s_list_all[wv]);
 }
 
 // ------------------------------------------------------------------------------------------
