@@ -984,7 +984,7 @@ __device__ __forceinline__ uint32_t retest_word(const float *blur, int W, int yb
 // lane's words, then all their block maxima, are fetched together; the bits that need the blur
 // plane go into a work list in LDS (wave prefix sum) and are re-tested one bit per lane with all
 // loads in flight, whatever lane they came from; failures clear their bit with an LDS atomic.  The
-// seeds of the tile are collected in LDS and appended to the frame's list with one atomic.
+// seeds of the tile get their places by a prefix sum over the lanes and go to the frame's list behind one atomic.
 // ------------------------------------------------------------------------------------------
 constexpr int VS_OWN = 56;         // owner lanes of a wave (1 left halo + 56 + 7 look-ahead = 64)
 constexpr int VS_ROWS = 4;         // word rows per tile
