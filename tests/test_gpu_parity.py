@@ -226,10 +226,11 @@ def test_batch_matches_oracle_and_is_deterministic(det, oracle):
             assert np.min(np.hypot(*(g - p).T)) < 0.5
 
 
-@pytest.mark.parametrize("bits", [16384, 32768, 65536, 4096, 8192])
+@pytest.mark.parametrize("bits", [16384, 32768, 65536, 4096, 8192, 128, 2048])
 def test_diagnostic_instantiations_do_not_change_results(det, bits):
     """debug_ablation 16384 runs the flood + refine kernel's second instantiation (phase clock), 32768 K1's ascending
-    segment order (the A/B of the middle-outwards dispatch), 65536 the uniform refresh interval of its threshold, 4096 / 8192 the wave and phase timers: the superset K1
+    segment order (the A/B of the middle-outwards dispatch), 65536 the uniform refresh interval of its threshold, 4096 / 8192 the wave and phase timers,
+    128 / 2048 k_verify_seeds' statistics (8192, 128, 2048: its instantiation with the debug tests, on the linear grid): the superset K1
     leaves depends on the order in which its waves learn the frame's minimum, the results must not."""
     import aprilgrid_rs_amd as A
     synth = synth_module()
@@ -248,6 +249,27 @@ def test_diagnostic_instantiations_do_not_change_results(det, bits):
         if bits == 16384:  # the clock has run: chunks counted, time recorded in every phase of a working wave
             st = d2.debug_fetch(0, "verify_stats").astype(np.int64)
             assert st[19] > 0 and st[18] > 0 and all(st[k] > 0 for k in (8, 9, 10, 11, 13, 16, 7))
+    finally:
+        d2.close()
+
+
+def test_verify_kernel_linear_grid_equals_tile_grid(det, monkeypatch):
+    """k_verify_seeds is launched as a (frame, column group, row chunk) grid, one tile per wave; the tuning override AGX_G_VERIFY keeps the
+    linear slot-major grid with several tiles per wave.  Same lists either way."""
+    import aprilgrid_rs_amd as A
+    synth = synth_module()
+    frames, _ = synth.render_batch(7, 3, 1000, 600, device="cuda")
+    det.saddles_batch_enqueue(frames)
+    res, status = det.saddles_batch_fetch()
+    assert (status == 0).all()
+    monkeypatch.setenv("AGX_G_VERIFY", "37")
+    d2 = A.TagDetector(A.TagFamily.T36H11, None, device=0)
+    try:
+        d2.saddles_batch_enqueue(frames)
+        res2, status2 = d2.saddles_batch_fetch()
+        assert (status2 == 0).all()
+        for a, b in zip(res, res2):
+            assert a.tobytes() == b.tobytes()
     finally:
         d2.close()
 
