@@ -724,9 +724,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((A4 &&
                             if (min_ok[j]) rrow[j] = dv[j];
                     }
                     if (A4) {
-                        rmin[0] = fminf(rmin[0], dv[0]);
-                        rmin[1] = fminf(fminf(rmin[1], dv[1]), dv[2]);
-                        rmin[3] = fminf(rmin[3], dv[3]);
+                        // (as instructions: fminf() makes the compiler canonicalise the loop-carried operand first -- a v_max_f32 per
+                        // minimum; the operands are results of arithmetic or of these minima, v_min_f32 returns the other operand for a NaN)
+                        asm("v_min_f32 %0, %0, %1" : "+v"(rmin[0]) : "v"(dv[0]));
+                        asm("v_min3_f32 %0, %0, %1, %2" : "+v"(rmin[1]) : "v"(dv[1]), "v"(dv[2]));
+                        asm("v_min_f32 %0, %0, %1" : "+v"(rmin[3]) : "v"(dv[3]));
                     } else {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) rmin[j] = fminf(rmin[j], dv[j]);
