@@ -6,9 +6,12 @@
 // work disappears behind them.
 #include <hip/hip_runtime_api.h>
 
+#include <sched.h>
+
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
+#include <cstdio>
 #include <cstring>
 #include <deque>
 #include <exception>
@@ -25,6 +28,8 @@
 namespace agx {
 
 // A fixed set of worker threads with a task queue; wait() blocks until every submitted task is done.
+// submit_front() puts a task ahead of everything queued (agx_detect_batch's uploads: a chunk of frames must not
+// wait behind the hundreds of board searches already queued).
 class WorkerPool {
 public:
     explicit WorkerPool(int n)
@@ -54,15 +59,8 @@ public:
     WorkerPool(const WorkerPool &) = delete;
     WorkerPool &operator=(const WorkerPool &) = delete;
     int size() const { return (int)threads_.size(); }
-    void submit(std::function<void()> f)
-    {
-        {
-            std::lock_guard<std::mutex> lk(m_);
-            q_.push_back(std::move(f));
-            ++pending_;
-        }
-        cv_.notify_one();
-    }
+    void submit(std::function<void()> f) { push(std::move(f), false); }
+    void submit_front(std::function<void()> f) { push(std::move(f), true); }
     // Blocks until every submitted task is done; false if one of them ended in an exception since the last wait (a task must
     // not unwind out of its thread: run() catches, the caller of wait() learns of it)
     bool wait()
@@ -75,6 +73,16 @@ public:
     }
 
 private:
+    void push(std::function<void()> f, bool front)
+    {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            if (front) q_.push_front(std::move(f));
+            else q_.push_back(std::move(f));
+            ++pending_;
+        }
+        cv_.notify_one();
+    }
     void run()
     {
         for (;;) {
@@ -141,6 +149,79 @@ void destroy_tail_workers(TailWorkers *w) { delete w; }
 
 using namespace agx;
 
+// CPUs of this process: affinity mask, narrowed by the CPU quota of its cgroup and of the cgroups above it
+// (v2: cpu.max "quota period" | "max period"; v1: cpu.cfs_quota_us / cpu.cfs_period_us)
+static int cgroup_cpu_quota()
+{
+    auto read_pair = [](const std::string &path, long long &a, long long &b) -> bool {
+        FILE *f = std::fopen(path.c_str(), "r");
+        if (!f) return false;
+        char buf[64] = {0};
+        const bool got = std::fgets(buf, sizeof buf, f) != nullptr;
+        std::fclose(f);
+        if (!got) return false;
+        if (!std::strncmp(buf, "max", 3)) { a = -1; b = 100000; return true; }
+        return std::sscanf(buf, "%lld %lld", &a, &b) >= 1;
+    };
+    long long best = -1;  // CPUs, rounded up; -1 = no quota found
+    auto take = [&](long long quota, long long period) {
+        if (quota <= 0 || period <= 0) return;
+        const long long cpus = std::max(1ll, (quota + period - 1) / period);
+        best = best < 0 ? cpus : std::min(best, cpus);
+    };
+    // this process's cgroup path (v2: "0::/path"; v1: "N:cpu,cpuacct:/path")
+    std::string v2_path, v1_path;
+    if (FILE *f = std::fopen("/proc/self/cgroup", "r")) {
+        char line[512];
+        while (std::fgets(line, sizeof line, f)) {
+            std::string l(line);
+            while (!l.empty() && (l.back() == '\n' || l.back() == '\r')) l.pop_back();
+            const size_t c1 = l.find(':'), c2 = c1 == std::string::npos ? c1 : l.find(':', c1 + 1);
+            if (c2 == std::string::npos) continue;
+            const std::string ctrl = l.substr(c1 + 1, c2 - c1 - 1), path = l.substr(c2 + 1);
+            if (ctrl.empty()) v2_path = path;
+            else if (ctrl.find("cpu") != std::string::npos && ctrl.find("cpuset") == std::string::npos) v1_path = path;
+        }
+        std::fclose(f);
+    }
+    for (std::string p = v2_path;;) {  // the cgroup and every ancestor (inside a container the namespace root is "/")
+        long long q = -1, per = 100000;
+        if (read_pair("/sys/fs/cgroup" + p + (p.empty() || p.back() != '/' ? "/" : "") + "cpu.max", q, per)) take(q, per);
+        if (p.empty() || p == "/") break;
+        const size_t cut = p.find_last_of('/');
+        p = cut == std::string::npos || cut == 0 ? "/" : p.substr(0, cut);
+    }
+    for (const char *root : {"/sys/fs/cgroup/cpu", "/sys/fs/cgroup/cpu,cpuacct"}) {
+        for (std::string p = v1_path.empty() ? "/" : v1_path;;) {
+            long long q = -1, per = -1, dummy = 0;
+            const std::string dir = std::string(root) + p + (p.back() != '/' ? "/" : "");
+            if (read_pair(dir + "cpu.cfs_quota_us", q, dummy) && read_pair(dir + "cpu.cfs_period_us", per, dummy)) take(q, per);
+            if (p == "/") break;
+            const size_t cut = p.find_last_of('/');
+            p = cut == std::string::npos || cut == 0 ? "/" : p.substr(0, cut);
+        }
+    }
+    return best < 0 ? 0 : (int)std::min<long long>(best, 1 << 20);
+}
+
+extern "C" int agx_host_parallelism(void)
+{
+    try {
+        static const int cached = [] {
+            int n = (int)std::max(1u, std::thread::hardware_concurrency());
+            cpu_set_t set;
+            CPU_ZERO(&set);
+            if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0) n = std::min(n, CPU_COUNT(&set));
+            const int quota = cgroup_cpu_quota();
+            if (quota > 0) n = std::min(n, quota);
+            return std::max(n, 1);
+        }();
+        return cached;
+    } catch (...) {
+        return 1;
+    }
+}
+
 static int detect_batch_impl(agx_detector *det, const void *frames, const void *d_frames, int n_frames, int width,
                              int height, size_t row_stride_bytes, size_t frame_stride_bytes, int format, agx_tag *out,
                              uint32_t cap_per_frame, uint32_t *counts, int *frame_status, int n_threads);
@@ -179,60 +260,81 @@ static int detect_batch_impl(agx_detector *det, const void *frames, const void *
     // one frame: the stride between frames means nothing to the caller (0 is a natural value), but the staging
     // and the upload below are sized by it -- use the frame's own extent
     if (n_frames == 1 && frame_stride_bytes < row_stride_bytes * (size_t)height) frame_stride_bytes = row_stride_bytes * (size_t)height;
-    if (n_threads <= 0) n_threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 64u);
+    // 0 = every CPU this process may keep busy: its affinity mask or its cgroup quota, whichever is smaller (threads beyond a
+    // quota are not merely idle: the quota is spent sooner and EVERY thread of the process, the one driving the device
+    // included, is frozen for the rest of the scheduler period -- profiles/r5_host_cpu_quota_and_tail_scaling.txt)
+    if (n_threads <= 0) n_threads = agx_host_parallelism();
     WorkerPool *pool = static_cast<WorkerPool *>(agx_internal_pool(det, n_threads));
     if (!pool) return AGX_ERR_ARG;
     const FamilyInfo *fam = static_cast<const FamilyInfo *>(agx_internal_family(det));
     const int max_boards = agx_internal_max_boards(det);
-    hipStream_t st = (hipStream_t)agx_internal_stream(det);
     if (hipSetDevice(agx_internal_device(det)) != hipSuccess) return AGX_ERR_HIP;
+    const int device = agx_internal_device(det);
 
-    // chunks: large enough that the chain runs at batch efficiency, small enough that the pool has
-    // work while the next chunk is uploaded and processed
-    const int chunk = std::max(1, std::min(n_frames, std::max(2 * pool->size(), 32)));
+    // Chunks of about one frame per worker (8 .. 64): the chain of a chunk takes 0.1 ms on the device, a frame's board
+    // search 1.5 ms on a host thread, so small chunks cost nothing and the workers start after the first 8 .. 64 frames
+    // instead of after a quarter of the batch.  Three kinds of work, none of which waits for another chunk's:
+    //   uploads   (host frames only) pool tasks that jump the queue: pageable memory goes to the device through the
+    //             runtime's staging copies on the calling thread, i.e. it is host work -- it runs on the workers, up to
+    //             AGX_UPLOAD_STREAMS chunks ahead, not on the thread that drives the device;
+    //   chain     this thread: enqueue, luma (L16 / RGB8), one wait per chunk, the compact list into the chunk's slot;
+    //   tails     pool tasks, one per frame, reading the slot; a slot is refilled when ITS tails are done (a counter per
+    //             slot) -- no barrier over the pool between chunks.
+    constexpr int S = AGX_UPLOAD_STREAMS, R = 4;
+    const int chunk = std::max(1, std::min(n_frames, std::min(std::max(pool->size(), 8), 64)));
+    const int n_chunks = (n_frames + chunk - 1) / chunk;
     const size_t chunk_bytes = (size_t)chunk * frame_stride_bytes;
     uint8_t *d_stage = nullptr;
-    hipStream_t up = nullptr;
-    hipEvent_t up_done[2] = {nullptr, nullptr}, stage_free[2] = {nullptr, nullptr};
+    hipStream_t up[S] = {nullptr, nullptr, nullptr};
     if (!d_frames) {
-        d_stage = static_cast<uint8_t *>(agx_internal_stage(det, 2 * chunk_bytes));  // double-buffered upload
+        d_stage = static_cast<uint8_t *>(agx_internal_stage(det, (size_t)std::min(S, n_chunks) * chunk_bytes));
         if (!d_stage) return AGX_ERR_HIP;
-        if (agx_internal_upload_stream(det, (void **)&up, (void **)up_done, (void **)stage_free) != 0) return AGX_ERR_HIP;
+        if (agx_internal_upload_streams(det, (void **)up) != 0) return AGX_ERR_HIP;
     }
-    // chunk c + 1 goes up on the upload stream while chunk c's chain runs and its results are fetched (the two staging halves
-    // alternate: a half is written again when the chain that read it -- two chunks back -- is through)
-    auto upload = [&](int c0, int ci) -> bool {
-        const int nf = std::min(chunk, n_frames - c0), par = ci & 1;
-        if (ci >= 2 && hipStreamWaitEvent(up, stage_free[par], 0) != hipSuccess) return false;
-        if (hipMemcpyAsync(d_stage + (size_t)par * chunk_bytes, (const uint8_t *)frames + (size_t)c0 * frame_stride_bytes,
-                           (size_t)nf * frame_stride_bytes, hipMemcpyHostToDevice, up) != hipSuccess) return false;
-        return hipEventRecord(up_done[par], up) == hipSuccess;
+    struct Slot {  // one chunk's results while its tails run
+        std::vector<agx_saddle> saddles;  // compact
+        std::vector<uint32_t> ns, offs;
+        std::vector<int> fst;
     };
-    if (!d_frames && !upload(0, 0)) return AGX_ERR_HIP;
-    std::vector<std::vector<agx_saddle>> saddles(2);  // per chunk parity: [chunk frames][cap]
-    std::vector<std::vector<uint32_t>> ns(2);
-    std::vector<std::vector<int>> fst(2);
-    uint32_t cap_s = 16384;  // saddles per frame the staging holds; grown when a chunk has a longer list
+    std::vector<Slot> slots((size_t)R);
+    std::mutex m;
+    std::condition_variable cv;
+    std::vector<int> uploaded;   // per chunk: 0 pending, 1 on the device, -1 failed        (guarded by m)
+    int outstanding[R] = {0, 0, 0, 0};  // tails of the slot's chunk not finished yet        (guarded by m)
     std::atomic<int> first_bad{AGX_OK};
     std::atomic<bool> nomem{false};
     int rc = AGX_OK;
     bool pending_batch = false;  // a chunk is enqueued on the detector and not fetched yet
-    // Nothing unwinds through the C boundary: an allocation failure on this thread (staging vectors, a task's
+    auto upload_task = [&, device](int ci) {
+        const int c0 = ci * chunk, nf = std::min(chunk, n_frames - c0), slot = ci % S;
+        const bool ok = hipSetDevice(device) == hipSuccess &&
+                        hipMemcpyAsync(d_stage + (size_t)slot * chunk_bytes, (const uint8_t *)frames + (size_t)c0 * frame_stride_bytes,
+                                       (size_t)nf * frame_stride_bytes, hipMemcpyHostToDevice, up[slot]) == hipSuccess &&
+                        hipStreamSynchronize(up[slot]) == hipSuccess;
+        {
+            std::lock_guard<std::mutex> lk(m);
+            uploaded[(size_t)ci] = ok ? 1 : -1;
+        }
+        cv.notify_all();
+    };
+    // Nothing unwinds through the C boundary: an allocation failure on this thread (slot vectors, a task's
     // std::function) ends the loop like any other error, after the worker tasks -- which hold pointers into
-    // saddles[] and a reference to first_bad -- have finished.
+    // the slots and references to the locals above -- have finished.
     try {
-    for (int c0 = 0, ci = 0; c0 < n_frames; c0 += chunk, ++ci) {
-        const int nf = std::min(chunk, n_frames - c0);
-        const int par = ci & 1;
+    uploaded.assign((size_t)n_chunks, 0);
+    if (!d_frames)
+        for (int ci = 0; ci < std::min(S, n_chunks); ++ci) pool->submit([&upload_task, ci] { upload_task(ci); });  // (empty queue: in order)
+    for (int ci = 0; ci < n_chunks; ++ci) {
+        const int c0 = ci * chunk, nf = std::min(chunk, n_frames - c0), r = ci % R;
         const uint8_t *h_chunk = (const uint8_t *)frames + (size_t)c0 * frame_stride_bytes;
         const void *d_chunk;
-        if (d_frames) {
-            d_chunk = (const uint8_t *)d_frames + (size_t)c0 * frame_stride_bytes;
-        } else {
-            if (c0 + chunk < n_frames && !upload(c0 + chunk, ci + 1)) { rc = AGX_ERR_HIP; break; }  // the next chunk, under this one's chain
-            if (hipStreamWaitEvent(st, up_done[par], 0) != hipSuccess) { rc = AGX_ERR_HIP; break; }
-            d_chunk = d_stage + (size_t)par * chunk_bytes;
+        {
+            std::unique_lock<std::mutex> lk(m);
+            cv.wait(lk, [&] { return outstanding[r] == 0 && (d_frames || uploaded[(size_t)ci] != 0); });
+            if (!d_frames && uploaded[(size_t)ci] < 0) { rc = AGX_ERR_HIP; break; }
         }
+        if (d_frames) d_chunk = (const uint8_t *)d_frames + (size_t)c0 * frame_stride_bytes;
+        else d_chunk = d_stage + (size_t)(ci % S) * chunk_bytes;
         rc = agx_saddles_batch_enqueue(det, d_chunk, nf, width, height, row_stride_bytes, frame_stride_bytes, format);
         if (rc) break;
         pending_batch = true;
@@ -240,60 +342,58 @@ static int detect_batch_impl(agx_detector *det, const void *frames, const void *
         // the device behind the chain (the frames are there) and come back with the saddles
         const uint8_t *h_luma = nullptr;
         if (format != AGX_L8) {
-            if (ci >= 2) (void)pool->wait();  // tails of the chunk two back read this half of the luma staging
-            rc = agx_internal_chunk_luma8(det, d_chunk, nf, width, height, row_stride_bytes, frame_stride_bytes, format, par,
+            rc = agx_internal_chunk_luma8(det, d_chunk, nf, width, height, row_stride_bytes, frame_stride_bytes, format, r, R,
                                           (size_t)chunk, &h_luma);
             if (rc) break;
         }
-        if (!d_frames && hipEventRecord(stage_free[par], st) != hipSuccess) { rc = AGX_ERR_HIP; break; }  // chain + luma have read this half
-        // the tails of the chunk two back read saddles[par]: they must be done before it is refilled
-        if (ci >= 2) (void)pool->wait();
-        saddles[par].resize((size_t)nf * cap_s);
-        ns[par].assign(nf, 0);
-        fst[par].assign(nf, 0);
-        rc = agx_saddles_batch_fetch(det, saddles[par].data(), cap_s, ns[par].data(), fst[par].data());  // waits for the device
+        Slot &sl = slots[(size_t)r];
+        sl.ns.resize((size_t)nf);
+        sl.offs.resize((size_t)nf);
+        sl.fst.resize((size_t)nf);
+        const agx_saddle *records = nullptr;
+        rc = agx_internal_fetch_compact(det, &records, sl.ns.data(), sl.offs.data(), sl.fst.data());  // waits for the device
         pending_batch = false;
-        if (rc == AGX_ERR_CAPACITY) {
-            // a list longer than the staging (pure-noise frames of several megapixels; the reference's
-            // Vec has no limit): the batch is still fetchable -- make room and fetch again
-            uint32_t longest = 0;
-            for (int f = 0; f < nf; ++f) longest = std::max(longest, ns[par][f]);
-            if (longest > cap_s) {
-                cap_s = longest;
-                saddles[par].resize((size_t)nf * cap_s);
-                rc = agx_saddles_batch_fetch(det, saddles[par].data(), cap_s, ns[par].data(), fst[par].data());
-            }
+        if (rc) break;
+        // chain and luma have read the staging slot: the chunk S ahead may go up (ahead of every queued tail)
+        if (!d_frames && ci + S < n_chunks) pool->submit_front([&upload_task, ci] { upload_task(ci + S); });
+        size_t total = 0;
+        for (int f = 0; f < nf; ++f)
+            if (sl.fst[(size_t)f] == AGX_OK) total = std::max(total, (size_t)sl.offs[(size_t)f] + sl.ns[(size_t)f]);
+        sl.saddles.assign(records, records + total);  // (the detector's mirror is overwritten by the next chunk)
+        int n_tasks = 0;
+        for (int f = 0; f < nf; ++f) n_tasks += sl.fst[(size_t)f] == AGX_OK;
+        {
+            std::lock_guard<std::mutex> lk(m);
+            outstanding[r] = n_tasks;
         }
-        if (rc && rc != AGX_ERR_CAPACITY) break;
-        rc = AGX_OK;
+        int submitted = 0;
+        try {
         for (int f = 0; f < nf; ++f) {
             const int gf = c0 + f;
-            if (fst[par][f] != AGX_OK) {  // reported, never truncated
+            if (sl.fst[(size_t)f] != AGX_OK) {  // reported, never truncated
                 counts[gf] = 0;
-                if (frame_status) frame_status[gf] = fst[par][f];
+                if (frame_status) frame_status[gf] = sl.fst[(size_t)f];
                 int exp = AGX_OK;
-                first_bad.compare_exchange_strong(exp, fst[par][f]);
+                first_bad.compare_exchange_strong(exp, sl.fst[(size_t)f]);
                 continue;
             }
-            const agx_saddle *sp = saddles[par].data() + (size_t)f * cap_s;
-            const uint32_t n_s = ns[par][f];
+            const agx_saddle *sp = sl.saddles.data() + sl.offs[(size_t)f];
+            const uint32_t n_s = sl.ns[(size_t)f];
             const uint8_t *img = h_chunk + (size_t)f * frame_stride_bytes;
             const uint8_t *dev_grey = h_luma ? h_luma + (size_t)f * (size_t)width * (size_t)height : nullptr;
-            pool->submit([=, &first_bad, &nomem] {
+            pool->submit([=, &first_bad, &nomem, &m, &cv, &outstanding] {
               try {  // nothing unwinds out of a worker thread: host memory exhaustion becomes the frame's status
                 const uint8_t *g = dev_grey ? dev_grey : img;  // L8: the frame itself, read at its own pitch
                 const size_t gstride = dev_grey ? (size_t)width : row_stride_bytes;
-                std::vector<agx_tag> tags;
-                detect_tail(*fam, max_boards, std::vector<agx_saddle>(sp, sp + n_s), g, width, height, gstride, tags);
+                const std::vector<agx_tag> &tags = detect_tail_scratch(*fam, max_boards, sp, n_s, g, width, height, gstride);
                 int stf = AGX_OK;
+                counts[gf] = (uint32_t)tags.size();
                 if (tags.size() > cap_per_frame) {
                     stf = AGX_ERR_CAPACITY;
                     int exp = AGX_OK;
                     first_bad.compare_exchange_strong(exp, stf);
-                    counts[gf] = (uint32_t)tags.size();
-                } else {
-                    counts[gf] = (uint32_t)tags.size();
-                    if (!tags.empty()) std::memcpy(out + (size_t)gf * cap_per_frame, tags.data(), tags.size() * sizeof(agx_tag));
+                } else if (!tags.empty()) {
+                    std::memcpy(out + (size_t)gf * cap_per_frame, tags.data(), tags.size() * sizeof(agx_tag));
                 }
                 if (frame_status) frame_status[gf] = stf;
               } catch (...) {  // host memory exhausted inside this frame's search: the call fails as a whole
@@ -301,14 +401,25 @@ static int detect_batch_impl(agx_detector *det, const void *frames, const void *
                 if (frame_status) frame_status[gf] = AGX_ERR_NOMEM;
                 nomem.store(true);
               }
+              bool last;
+              {
+                  std::lock_guard<std::mutex> lk(m);
+                  last = --outstanding[r] == 0;
+              }
+              if (last) cv.notify_all();
             });
+            ++submitted;
+        }
+        } catch (...) {  // a task could not be queued: the slot's counter must not wait for tails that will never run
+            std::lock_guard<std::mutex> lk(m);
+            outstanding[r] -= n_tasks - submitted;
+            throw;
         }
     }
     } catch (...) {
         rc = AGX_ERR_NOMEM;  // host memory exhausted on this thread
     }
-    (void)pool->wait();
-    if (up) (void)hipStreamSynchronize(up);  // (after an error an upload may still be reading the caller's frames)
+    (void)pool->wait();  // every tail and every upload still queued (an upload may be reading the caller's frames)
     if (pending_batch) agx_internal_abandon_batch(det);  // an error between enqueue and fetch: no stale batch is left to be fetched later
     if (rc) return rc;
     if (nomem.load()) return AGX_ERR_NOMEM;

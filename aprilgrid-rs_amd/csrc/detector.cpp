@@ -103,8 +103,8 @@ struct agx_detector {
     uint64_t prof_launches[K_COUNT]{};
 
     // agx_detect_batch: the next chunk's upload runs on a stream of its own under the current chunk's chain and fetch
-    hipStream_t upload_stream = nullptr;
-    hipEvent_t upload_done[2] = {nullptr, nullptr}, stage_free[2] = {nullptr, nullptr};
+    hipStream_t upload_streams[AGX_UPLOAD_STREAMS] = {nullptr, nullptr, nullptr};  // agx_detect_batch: one per staging slot, all or none
+    bool upload_streams_ready = false;
     TailWorkers *tail_workers = nullptr;  // option "tail_threads" > 1: one frame's board search on several threads
     int tail_threads = 1;
     void *pool = nullptr;  // agx_detect_batch: worker threads of the host tail
@@ -522,46 +522,72 @@ __attribute__((visibility("hidden"))) void *agx_internal_pool(agx_detector *det,
 }
 // agx_detect_batch: u8 luma of a chunk of L16 / RGB8 frames (device pointers), computed on the device
 // behind whatever is on the detector's stream and copied into pinned host memory: [n_frames][H][W] at
-// *h_out (valid after the stream has been waited for -- the chunk's fetch does).  parity: two staging halves.
+// *h_out (valid after the stream has been waited for -- the chunk's fetch does).  The staging is a ring of
+// n_slots chunks; the caller reuses a slot when the host tails that read it are done.
 __attribute__((visibility("hidden"))) int agx_internal_chunk_luma8(agx_detector *det, const void *d_frames, int n_frames,
                                                                    int width, int height, size_t row_stride,
-                                                                   size_t frame_stride, int format, int parity,
+                                                                   size_t frame_stride, int format, int slot, int n_slots,
                                                                    size_t chunk_capacity_frames, const uint8_t **h_out)
 {
-    const size_t plane = (size_t)width * (size_t)height, half = plane * chunk_capacity_frames;
-    if (2 * half > det->luma_bytes) {
+    const size_t plane = (size_t)width * (size_t)height, one = plane * chunk_capacity_frames;
+    if (slot < 0 || slot >= n_slots) return AGX_ERR_ARG;
+    if ((size_t)n_slots * one > det->luma_bytes) {
         if (hipStreamSynchronize(det->stream) != hipSuccess) return AGX_ERR_HIP;
         if (det->d_luma) (void)hipFree(det->d_luma);
         if (det->h_luma) (void)hipHostFree(det->h_luma);
         det->d_luma = det->h_luma = nullptr;
         det->luma_bytes = 0;
-        if (hipMalloc((void **)&det->d_luma, 2 * half) != hipSuccess) return AGX_ERR_HIP;
-        if (hipHostMalloc((void **)&det->h_luma, 2 * half, hipHostMallocDefault) != hipSuccess) return AGX_ERR_HIP;
-        det->luma_bytes = 2 * half;
+        if (hipMalloc((void **)&det->d_luma, (size_t)n_slots * one) != hipSuccess) return AGX_ERR_HIP;
+        if (hipHostMalloc((void **)&det->h_luma, (size_t)n_slots * one, hipHostMallocDefault) != hipSuccess) return AGX_ERR_HIP;
+        det->luma_bytes = (size_t)n_slots * one;
     }
-    uint8_t *d = det->d_luma + (size_t)parity * half, *h = det->h_luma + (size_t)parity * half;
+    uint8_t *d = det->d_luma + (size_t)slot * one, *h = det->h_luma + (size_t)slot * one;
     if (launch_luma8(d_frames, row_stride, frame_stride, n_frames, format, d, width, height, det->stream) != 0) return AGX_ERR_HIP;
     if (hipMemcpyAsync(h, d, plane * (size_t)n_frames, hipMemcpyDeviceToHost, det->stream) != hipSuccess) return AGX_ERR_HIP;
     *h_out = h;
     return AGX_OK;
 }
-// agx_detect_batch: the upload stream and its four events (created on first use); hipError_t
-__attribute__((visibility("hidden"))) int agx_internal_upload_stream(agx_detector *det, void **stream, void **upload_done, void **stage_free)
+// agx_detect_batch: the upload streams, one per staging slot (created on first use, all of them or none: a failure
+// half way destroys what exists, so that a later call starts over instead of finding a half-initialised set); hipError_t
+__attribute__((visibility("hidden"))) int agx_internal_upload_streams(agx_detector *det, void **streams)
 {
-    if (!det->upload_stream) {
-        hipError_t e = hipStreamCreateWithFlags(&det->upload_stream, hipStreamNonBlocking);
-        for (int i = 0; i < 2 && e == hipSuccess; ++i) {
-            e = hipEventCreateWithFlags(&det->upload_done[i], hipEventDisableTiming);
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&det->stage_free[i], hipEventDisableTiming);
+    if (!det->upload_streams_ready) {
+        hipError_t e = hipSuccess;
+        for (int i = 0; i < AGX_UPLOAD_STREAMS && e == hipSuccess; ++i)
+            e = hipStreamCreateWithFlags(&det->upload_streams[i], hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            for (int i = 0; i < AGX_UPLOAD_STREAMS; ++i) {
+                if (det->upload_streams[i]) (void)hipStreamDestroy(det->upload_streams[i]);
+                det->upload_streams[i] = nullptr;
+            }
+            return (int)e;
         }
-        if (e != hipSuccess) return (int)e;
+        det->upload_streams_ready = true;
     }
-    *stream = det->upload_stream;
-    for (int i = 0; i < 2; ++i) {
-        upload_done[i] = det->upload_done[i];
-        stage_free[i] = det->stage_free[i];
-    }
+    for (int i = 0; i < AGX_UPLOAD_STREAMS; ++i) streams[i] = det->upload_streams[i];
     return 0;
+}
+// agx_detect_batch: the last batch's results without the [frame][cap] layout of agx_saddles_batch_fetch: waits for the
+// device, then *records = the batch's compact list in the detector's pinned host mirror (valid until the next enqueue;
+// frame f's list = counts[f] records from offsets[f]) and status[f] = AGX_OK / AGX_ERR_CAPACITY (a device-side list of
+// the frame overflowed: its count is 0).  Returns AGX_OK, or the HIP / state error of the fetch.
+__attribute__((visibility("hidden"))) int agx_internal_fetch_compact(agx_detector *det, const agx_saddle **records, uint32_t *counts,
+                                                                     uint32_t *offsets, int *status)
+{
+    const int n = det->enqueued ? det->args.n_frames : 0;
+    // cap 0: counts and status only (a frame with any saddles reads "capacity" against cap 0: the real status is
+    // derived from the counters below, with no limit on the list's length)
+    int rc = agx_saddles_batch_fetch(det, nullptr, 0, counts, status);
+    if (rc != AGX_OK && rc != AGX_ERR_CAPACITY) return rc;
+    for (int f = 0; f < n; ++f) {
+        const FrameCounters &c = det->h_ctr[f];
+        status[f] = frame_status_of(c, 0xffffffffu);
+        counts[f] = status[f] == AGX_OK ? c.n_out : 0;
+        offsets[f] = c.out_offset;
+    }
+    *records = reinterpret_cast<const agx_saddle *>(det->h_out);
+    det->last_error.clear();
+    return AGX_OK;
 }
 __attribute__((visibility("hidden"))) void agx_internal_abandon_batch(agx_detector *det)
 {
@@ -711,11 +737,8 @@ void agx_detector_destroy(agx_detector *det)
     if (det->h_table) (void)hipHostFree(det->h_table);
     if (det->d_dbg_resp) (void)hipFree(det->d_dbg_resp);
     if (det->d_resp_store) (void)hipFree(det->d_resp_store);
-    for (int i = 0; i < 2; ++i) {
-        if (det->upload_done[i]) (void)hipEventDestroy(det->upload_done[i]);
-        if (det->stage_free[i]) (void)hipEventDestroy(det->stage_free[i]);
-    }
-    if (det->upload_stream) (void)hipStreamDestroy(det->upload_stream);
+    for (int i = 0; i < AGX_UPLOAD_STREAMS; ++i)
+        if (det->upload_streams[i]) (void)hipStreamDestroy(det->upload_streams[i]);
     if (det->own_stream) (void)hipStreamDestroy(det->own_stream);
     } catch (...) {  // (joining worker threads can throw std::system_error)
     }

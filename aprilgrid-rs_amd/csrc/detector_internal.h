@@ -16,11 +16,17 @@ int agx_internal_max_boards(const agx_detector *det);
 void *agx_internal_stage(agx_detector *det, size_t bytes);
 // Wait for whatever is enqueued and forget it (an error path between enqueue and fetch).
 void agx_internal_abandon_batch(agx_detector *det);
-int agx_internal_upload_stream(agx_detector *det, void **stream, void **upload_done, void **stage_free);  // hipError_t
+#define AGX_UPLOAD_STREAMS 3
+int agx_internal_upload_streams(agx_detector *det, void **streams /* [AGX_UPLOAD_STREAMS] */);  // hipError_t
 // u8 luma of a chunk of L16 / RGB8 device frames, computed on the device and copied to pinned host
-// memory behind the detector's stream ([n_frames][H][W] at *h_out once the stream has been waited for)
+// memory behind the detector's stream ([n_frames][H][W] at *h_out once the stream has been waited for);
+// the staging is a ring of n_slots chunks of chunk_capacity_frames
 int agx_internal_chunk_luma8(agx_detector *det, const void *d_frames, int n_frames, int width, int height, size_t row_stride,
-                             size_t frame_stride, int format, int parity, size_t chunk_capacity_frames, const uint8_t **h_out);
+                             size_t frame_stride, int format, int slot, int n_slots, size_t chunk_capacity_frames,
+                             const uint8_t **h_out);
+// the last batch's compact list in the detector's pinned host mirror (valid until the next enqueue) + per-frame
+// counts / offsets / status; waits for the device
+int agx_internal_fetch_compact(agx_detector *det, const agx_saddle **records, uint32_t *counts, uint32_t *offsets, int *status);
 }
 namespace agx {
 void destroy_worker_pool(void *pool);

@@ -7,8 +7,12 @@
 //
 // Transports of the gather:
 //   AGX_GATHER_RCCL   ncclSend / ncclRecv in one ncclGroup over xGMI, enqueued on the detectors'
-//                     streams behind their chains.  librccl is opened with dlopen on first use, so a
-//                     single-GPU host (or a process that never builds a group) does not need it.
+//                     streams behind their chains.  librccl is opened with dlopen when a group of MORE
+//                     THAN ONE rank is created, so a single-GPU host (a group of one, or a process that
+//                     never builds a group) does not need it: a group of one moves its slabs with two
+//                     device-to-device copies whatever the transport.  AGX_GROUP_RCCL_SELF=1 (environment,
+//                     read at agx_group_create; a test switch) makes a group of one bind the library and
+//                     send its slabs to itself through it -- what a one-GPU box can exercise of librccl.
 //   AGX_GATHER_PEER   hipMemcpyPeerAsync on the producer's stream + an event the root stream waits
 //                     on.  Same data path over xGMI, no communicator; also the only transport that
 //                     accepts the same device twice (a test configuration for one-GPU boxes).
@@ -67,7 +71,8 @@ bool load_rccl(Rccl &r, std::string &err)
         }
     }
     if (!r.lib) {
-        err = std::string("dlopen librccl: ") + (dlerror() ? dlerror() : "not found");
+        const char *why = dlerror();  // (a second call would return NULL: the message is consumed by the first)
+        err = std::string("dlopen librccl: ") + (why ? why : "not found");
         return false;
     }
     auto sym = [&](const char *n) { return dlsym(r.lib, n); };
@@ -96,6 +101,7 @@ struct agx_group {
     std::vector<agx_detector *> dets;
     Rccl rccl;
     std::vector<void *> comms;
+    bool rccl_bound = false;  // the library is loaded and a communicator exists (n > 1, or n == 1 with AGX_GROUP_RCCL_SELF=1)
     // per rank, on its own device: result slabs of the last batch
     std::vector<float *> d_saddles;
     std::vector<uint32_t *> d_table;
@@ -219,7 +225,9 @@ int agx_group_create(int family, const agx_params *params, const int *devices, i
     g->n = n_devices;
     g->transport = transport;
     for (int r = 0; r < n_devices; ++r) g->devices.push_back(devices ? devices[r] : r);
-    if (transport == AGX_GATHER_RCCL) {
+    const char *self_env = getenv("AGX_GROUP_RCCL_SELF");
+    const bool use_rccl = transport == AGX_GATHER_RCCL && (n_devices > 1 || (self_env && self_env[0] == '1'));
+    if (use_rccl) {
         // the library first: only the test suite's stand-in (it exports stub_rccl_stats) may take several ranks on one
         // device -- the real ncclCommInitAll would hang on them, whatever AGX_RCCL_LIBRARY says
         std::string err;
@@ -263,13 +271,14 @@ int agx_group_create(int family, const agx_params *params, const int *devices, i
                 (void)hipDeviceEnablePeerAccess(g->devices[r], 0);
             }
         (void)hipGetLastError();
-    } else {  // (one rank too: its slab then goes through the library as a send to itself, see agx_group_saddles_enqueue)
+    } else if (use_rccl) {  // (one rank only with AGX_GROUP_RCCL_SELF=1: its slabs then go through the library as a send to itself)
         g->comms.assign(n_devices, nullptr);
         const int rc = g->rccl.CommInitAll(g->comms.data(), n_devices, g->devices.data());
         if (rc != 0) {
             cleanup();
             return gfail(nullptr, AGX_ERR_HIP, std::string("ncclCommInitAll: ") + (g->rccl.GetErrorString ? g->rccl.GetErrorString(rc) : "error"));
         }
+        g->rccl_bound = true;
     }
     *out = g.release();
     return AGX_OK;
@@ -319,10 +328,11 @@ int agx_group_saddles_enqueue(agx_group *g, const void *const *d_frames, int fra
     // the one exchange step: gather the slabs on the root device, stream-ordered behind the chains
     hipStream_t root = (hipStream_t)agx_internal_stream(g->dets[0]);
     GHIP(g, hipSetDevice(g->devices[0]));
-    if (g->n == 1 && g->transport == AGX_GATHER_RCCL) {
-        // A group of one: the root's own slabs take the library's path too -- a send to itself and the matching receive in
-        // one ncclGroup on the root's stream.  (What a one-GPU box can exercise of the real librccl: the binding, the
-        // communicator, the datatype constant, the ordering behind the chain on a non-blocking stream.)
+    if (g->n == 1 && g->rccl_bound) {
+        // A group of one under AGX_GROUP_RCCL_SELF=1 (test switch): the root's own slabs take the library's path -- a send
+        // to itself and the matching receive in one ncclGroup on the root's stream.  (What a one-GPU box can exercise of
+        // the real librccl: the binding, the communicator, the datatype constant, the ordering behind the chain on a
+        // non-blocking stream.)  Without the switch a group of one never touches the library: two copies, below.
         int e = g->rccl.GroupStart();
         if (e == 0) e = g->rccl.Send(g->d_table[0], tab_bytes, kNcclUint8, 0, g->comms[0], root);
         if (e == 0) e = g->rccl.Recv(g->d_all_table, tab_bytes, kNcclUint8, 0, g->comms[0], root);
@@ -336,7 +346,7 @@ int agx_group_saddles_enqueue(agx_group *g, const void *const *d_frames, int fra
     }
     GHIP(g, hipMemcpyAsync(g->d_all_table, g->d_table[0], tab_bytes, hipMemcpyDeviceToDevice, root));
     GHIP(g, hipMemcpyAsync(g->d_all_saddles, g->d_saddles[0], sad_bytes, hipMemcpyDeviceToDevice, root));
-    if (g->n > 1 && g->transport == AGX_GATHER_RCCL) {
+    if (g->n > 1 && g->rccl_bound) {
         int e = g->rccl.GroupStart();
         for (int r = 1; r < g->n && e == 0; ++r) {
             hipStream_t st = (hipStream_t)agx_internal_stream(g->dets[r]);

@@ -204,8 +204,15 @@ public:
         int idx;
         bool operator<(const Hit &o) const { return d2 < o.d2 || (d2 == o.d2 && idx < o.idx); }
     };
-    explicit SaddleIndex(const std::vector<agx_saddle> &pts) : pts_(pts)
+    SaddleIndex() {}
+    explicit SaddleIndex(const std::vector<agx_saddle> &pts) { reset(pts); }
+    // (Re)build over another saddle set.  The object keeps its storage -- cell lists, candidate vector, the two
+    // memo tables -- between frames (detect_tail's per-thread scratch): only the slots the previous set used are cleared.
+    void reset(const std::vector<agx_saddle> &pts_in)
     {
+        pts_p_ = &pts_in;
+        const std::vector<agx_saddle> &pts = pts_in;
+        clear_tables();
         const int n = (int)pts.size();
         float x0 = 0, x1 = 1, y0 = 0, y1 = 1;
         if (n) {
@@ -223,20 +230,21 @@ public:
         nx_ = std::max(1, (int)std::floor(w / cell_) + 1);
         ny_ = std::max(1, (int)std::floor(h / cell_) + 1);
         start_.assign((size_t)nx_ * ny_ + 1, 0);
-        std::vector<int> cell_of(n);
+        cell_of_.resize((size_t)n);
         for (int i = 0; i < n; ++i) {
-            cell_of[i] = cell_y(pts[i].y) * nx_ + cell_x(pts[i].x);
-            start_[cell_of[i] + 1]++;
+            cell_of_[i] = cell_y(pts[i].y) * nx_ + cell_x(pts[i].x);
+            start_[cell_of_[i] + 1]++;
         }
         for (size_t c = 0; c < (size_t)nx_ * ny_; ++c) start_[c + 1] += start_[c];
-        items_.resize(n);
-        std::vector<int> fill(start_.begin(), start_.end() - 1);
-        for (int i = 0; i < n; ++i) items_[fill[cell_of[i]]++] = i;  // ascending index inside a cell
+        items_.resize((size_t)n);
+        fill_.assign(start_.begin(), start_.end() - 1);
+        for (int i = 0; i < n; ++i) items_[fill_[cell_of_[i]]++] = i;  // ascending index inside a cell
     }
 
     // k nearest, ascending; returns how many were found (min(k, n))
     int nearest(float qx, float qy, int k, Hit *out)
     {
+        const std::vector<agx_saddle> &pts_ = *pts_p_;
         const int n = (int)pts_.size();
         const int want = std::min(k, n);
         if (want <= 0) return 0;
@@ -289,6 +297,7 @@ public:
     };
     const PairCands &pair_candidates(int i0, int i1, float spacing_ratio)
     {
+        const std::vector<agx_saddle> &pts_ = *pts_p_;
         AGX_TAIL_COUNT(7, 1);
         const uint64_t key = 1ull + ((uint64_t)(uint32_t)i0 << 32 | (uint64_t)(uint32_t)i1);
         if (pair_tab_.empty()) pair_tab_.resize(1u << 12);
@@ -299,11 +308,13 @@ public:
             if (pair_tab_[h].key == key) return pair_tab_[h];
             if (pair_used_ * 2 >= pair_tab_.size()) {  // grow and re-insert, then look the slot up again
                 std::vector<PairCands> bigger(pair_tab_.size() * 2);
+                pair_touched_.clear();
                 for (const PairCands &e : pair_tab_)
                     if (e.key) {
                         size_t g = (size_t)((e.key * 0x9E3779B97F4A7C15ull) >> 32) & (bigger.size() - 1);
                         while (bigger[g].key) g = (g + 1) & (bigger.size() - 1);
                         bigger[g] = e;
+                        pair_touched_.push_back((uint32_t)g);
                     }
                 pair_tab_.swap(bigger);
                 continue;
@@ -326,6 +337,7 @@ public:
                         e.idx[side][e.n[side]++] = hits[i].idx;
             }
             pair_tab_[h] = e;
+            pair_touched_.push_back((uint32_t)h);
             ++pair_used_;
             return pair_tab_[h];
         }
@@ -336,6 +348,7 @@ public:
     // keyed by the four indices (16 bits each; larger sets are evaluated directly).
     bool valid_quad(int i0, int i1, int i2, int i3)
     {
+        const std::vector<agx_saddle> &pts_ = *pts_p_;
         if (pts_.size() >= 65535u) return is_valid_quad(pts_[i0], pts_[i1], pts_[i2], pts_[i3]);
         const uint64_t key = 1ull + ((uint64_t)i0 | ((uint64_t)i1 << 16) | ((uint64_t)i2 << 32) | ((uint64_t)i3 << 48));  // != 0
         if (quad_keys_.empty()) {
@@ -354,12 +367,14 @@ public:
             if (quad_used_ * 2 >= quad_keys_.size()) {  // grow, re-insert, look the slot up again
                 std::vector<uint64_t> ok(quad_keys_.size() * 2, 0ull);
                 std::vector<uint8_t> ov(ok.size(), 0);
+                quad_touched_.clear();
                 for (size_t i = 0; i < quad_keys_.size(); ++i)
                     if (quad_keys_[i]) {
                         size_t g = (size_t)((quad_keys_[i] * 0x9E3779B97F4A7C15ull) >> 32) & (ok.size() - 1);
                         while (ok[g]) g = (g + 1) & (ok.size() - 1);
                         ok[g] = quad_keys_[i];
                         ov[g] = quad_vals_[i];
+                        quad_touched_.push_back((uint32_t)g);
                     }
                 quad_keys_.swap(ok);
                 quad_vals_.swap(ov);
@@ -369,6 +384,7 @@ public:
             const bool v = is_valid_quad(pts_[i0], pts_[i1], pts_[i2], pts_[i3]);
             quad_keys_[h] = key;
             quad_vals_[h] = v ? 1 : 0;
+            quad_touched_.push_back((uint32_t)h);
             ++quad_used_;
             return v;
         }
@@ -383,6 +399,7 @@ private:
     // the hits within the radius, and their order, are the same as those of the unbounded search.
     int nearest_small(float qx, float qy, int want, Hit *out, float max_d2 = -1.0f)
     {
+        const std::vector<agx_saddle> &pts_ = *pts_p_;
         Hit best[3];
         int nb = 0;
         long seen = 0;
@@ -437,6 +454,7 @@ private:
     int cell_y(float y) const { return std::min(ny_ - 1, std::max(0, (int)std::floor(((double)y - oy_) / cell_))); }
     void scan(int xa, int xb, int ya, int yb, float qx, float qy)
     {
+        const std::vector<agx_saddle> &pts_ = *pts_p_;
         for (int y = ya; y <= yb; ++y)
             for (int x = xa; x <= xb; ++x) {
                 const size_t c = (size_t)y * nx_ + x;
@@ -448,10 +466,32 @@ private:
             }
     }
 
-    const std::vector<agx_saddle> &pts_;
+    // the memo tables of the previous saddle set: emptied slot by slot while few were used, wholesale otherwise
+    void clear_tables()
+    {
+        if (!pair_tab_.empty()) {
+            if (pair_touched_.size() * 8 < pair_tab_.size())
+                for (uint32_t h : pair_touched_) pair_tab_[h].key = 0ull;
+            else
+                for (PairCands &e : pair_tab_) e.key = 0ull;
+        }
+        pair_touched_.clear();
+        pair_used_ = 0;
+        if (!quad_keys_.empty()) {
+            if (quad_touched_.size() * 8 < quad_keys_.size())
+                for (uint32_t h : quad_touched_) quad_keys_[h] = 0ull;
+            else
+                std::fill(quad_keys_.begin(), quad_keys_.end(), 0ull);
+        }
+        quad_touched_.clear();
+        quad_used_ = 0;
+    }
+
+    const std::vector<agx_saddle> *pts_p_ = nullptr;
     double ox_ = 0, oy_ = 0, cell_ = 1;
     int nx_ = 1, ny_ = 1;
-    std::vector<int> start_, items_;
+    std::vector<int> start_, items_, cell_of_, fill_;
+    std::vector<uint32_t> pair_touched_, quad_touched_;  // occupied slots of the two tables
     std::vector<Hit> cand_;
     std::vector<PairCands> pair_tab_;
     size_t pair_used_ = 0;
@@ -824,36 +864,74 @@ bool find_best_board_parallel(const std::vector<agx_saddle> &refined, std::vecto
 
 }  // namespace
 
+namespace {
+// What one host thread keeps between frames: the tail of a frame allocates nothing once the thread has seen a frame
+// of that size (index, memo tables, board storage, the work lists).  agx_detect_batch runs thousands of tails per
+// second on a pool of threads; without this every tail built and zeroed ~0.6 MB of tables through the allocator.
+struct TailScratch {
+    SaddleIndex index;
+    BoardStorage storage[2];  // the best board so far keeps one, the next candidate is built in the other
+    std::vector<Quad> cand, quads;
+    std::vector<int> seeds;
+    std::vector<int> hist;    // round(theta) bins, -180 .. 180
+    std::vector<agx_saddle> refined;
+    std::vector<uint8_t> used;
+    std::vector<agx_tag> tags;
+};
+TailScratch &tail_scratch()
+{
+    static thread_local TailScratch s;
+    return s;
+}
+}  // namespace
+
 bool try_find_best_board(const std::vector<agx_saddle> &refined, std::vector<Quad> &quads, TailWorkers *workers)
 {
     quads.clear();
     if (refined.empty()) return false;
-    std::unique_ptr<SaddleIndex> index_holder;
+    TailScratch &sc = tail_scratch();
     {
         AGX_TAIL_TIME(0);
-        index_holder.reset(new SaddleIndex(refined));
+        sc.index.reset(refined);
     }
-    SaddleIndex &index = *index_holder;
+    SaddleIndex &index = sc.index;
     // seeds: the most populated round(theta) bin (ties -> smallest angle; the reference's
     // HashMap order makes its own tie-break arbitrary), popped from the back
-    std::unordered_map<int, int> hist;
-    for (const agx_saddle &s : refined) hist[(int)std::round(s.theta)]++;
     int best_angle = 0, best_len = -1;
-    for (const auto &kv : hist)
-        if (kv.second > best_len || (kv.second == best_len && kv.first < best_angle)) {
-            best_len = kv.second;
-            best_angle = kv.first;
+    bool small_angles = true;  // theta is half an atan2 in degrees: (-90, 90]; anything else (a caller's own list) takes the map
+    for (const agx_saddle &s : refined)
+        if (!(s.theta >= -180.0f && s.theta <= 180.0f)) {
+            small_angles = false;
+            break;
         }
-    std::vector<int> seeds;
+    if (small_angles) {
+        sc.hist.assign(361, 0);
+        for (const agx_saddle &s : refined) sc.hist[(size_t)((int)std::round(s.theta) + 180)]++;
+        for (int a = 0; a < 361; ++a)
+            if (sc.hist[(size_t)a] > best_len) {  // ascending angle: the first of equal counts is the smallest
+                best_len = sc.hist[(size_t)a];
+                best_angle = a - 180;
+            }
+    } else {
+        std::unordered_map<int, int> hist;
+        for (const agx_saddle &s : refined) hist[(int)std::round(s.theta)]++;
+        for (const auto &kv : hist)
+            if (kv.second > best_len || (kv.second == best_len && kv.first < best_angle)) {
+                best_len = kv.second;
+                best_angle = kv.first;
+            }
+    }
+    std::vector<int> &seeds = sc.seeds;
+    seeds.clear();
     for (size_t i = 0; i < refined.size(); ++i)
         if ((int)std::round(refined[i].theta) == best_angle) seeds.push_back((int)i);
 
     if (workers && workers->size() > 1 && seeds.size() > 1) return find_best_board_parallel(refined, seeds, index, quads, *workers);
 
     unsigned best_score = 0;
-    BoardStorage storage[2];  // the best board so far keeps one, the next candidate is built in the other
+    BoardStorage *storage = sc.storage;
     int cur = 0, best_at = -1;
-    std::vector<Quad> cand;
+    std::vector<Quad> &cand = sc.cand;
     int count = 0;
     while (!seeds.empty() && count < 30) {
         const int s0 = seeds.back();
@@ -990,15 +1068,20 @@ bool decode_quad(const FamilyInfo &fam, const uint8_t *luma8, uint32_t w, uint32
 
 }  // namespace
 
-void detect_tail(const FamilyInfo &fam, int max_num_of_boards, std::vector<agx_saddle> refined,
-                 const uint8_t *luma8, int width, int height, size_t row_stride, std::vector<agx_tag> &tags,
-                 TailWorkers *workers)
+namespace {
+// detect's loop body (detector.rs:510-539) over a working copy of the saddle list (consumed: the saddles of decoded
+// quads are removed between the rounds)
+void detect_tail_rounds(const FamilyInfo &fam, int max_num_of_boards, std::vector<agx_saddle> &refined,
+                        const uint8_t *luma8, int width, int height, size_t row_stride, std::vector<agx_tag> &tags,
+                        TailWorkers *workers)
 {
+    TailScratch &sc = tail_scratch();
     tags.clear();
-    std::vector<Quad> quads;
+    std::vector<Quad> &quads = sc.quads;
     for (int round = 0; round < max_num_of_boards; ++round) {
         if (!try_find_best_board(refined, quads, workers)) continue;
-        std::vector<uint8_t> used(refined.size(), 0);
+        std::vector<uint8_t> &used = sc.used;
+        used.assign(refined.size(), 0);
         for (const Quad &q : quads) {
             float qxy[8];
             for (int i = 0; i < 4; ++i) {
@@ -1023,6 +1106,23 @@ void detect_tail(const FamilyInfo &fam, int max_num_of_boards, std::vector<agx_s
             if (!used[i]) refined[keep++] = refined[i];
         refined.resize(keep);
     }
+}
+}  // namespace
+
+void detect_tail(const FamilyInfo &fam, int max_num_of_boards, std::vector<agx_saddle> refined,
+                 const uint8_t *luma8, int width, int height, size_t row_stride, std::vector<agx_tag> &tags,
+                 TailWorkers *workers)
+{
+    detect_tail_rounds(fam, max_num_of_boards, refined, luma8, width, height, row_stride, tags, workers);
+}
+
+const std::vector<agx_tag> &detect_tail_scratch(const FamilyInfo &fam, int max_num_of_boards, const agx_saddle *saddles, size_t n_saddles,
+                                                const uint8_t *luma8, int width, int height, size_t row_stride)
+{
+    TailScratch &sc = tail_scratch();
+    sc.refined.assign(saddles, saddles + n_saddles);
+    detect_tail_rounds(fam, max_num_of_boards, sc.refined, luma8, width, height, row_stride, sc.tags, nullptr);
+    return sc.tags;
 }
 
 int luma8(const void *pixels, int width, int height, size_t row_stride, int format, uint8_t *out)

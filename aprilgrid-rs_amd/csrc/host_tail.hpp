@@ -56,6 +56,11 @@ void detect_tail(const FamilyInfo &fam, int max_num_of_boards, std::vector<agx_s
                  const uint8_t *luma8, int width, int height, size_t row_stride, std::vector<agx_tag> &tags,
                  TailWorkers *workers = nullptr);
 
+// The same for a pool thread of agx_detect_batch: the list is copied into the calling thread's scratch, the tags are
+// returned in it (valid until the thread's next tail) -- no allocation once the thread has seen a frame of that size.
+const std::vector<agx_tag> &detect_tail_scratch(const FamilyInfo &fam, int max_num_of_boards, const agx_saddle *saddles, size_t n_saddles,
+                                                const uint8_t *luma8, int width, int height, size_t row_stride);
+
 // image 0.25.9 to_luma8 (call site detector.rs:507)
 int luma8(const void *pixels, int width, int height, size_t row_stride, int format, uint8_t *out);
 

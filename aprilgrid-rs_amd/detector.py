@@ -175,22 +175,26 @@ class TagDetector:
                                                 C.byref(n)))
         return {int(out[i].id): np.array(out[i].xy, np.float32).reshape(4, 2) for i in range(n.value)}
 
-    def detect_batch(self, frames, n_threads=0, cap=1024, device_frames=None, raise_on_overflow=True):
-        """detect() over a batch: frames = numpy [N,H,W] uint8 / uint16 or [N,H,W,3] uint8 in host
-        memory (optionally also resident on the GPU as the torch tensor device_frames).  The chain
-        runs on the device chunk by chunk while n_threads host threads (0 = all cores, <= 64) run the
-        board search + decode.  -> list of {tag_id: 4x2 corners}.  A frame with more than `cap` tags (or
-        over the detector's saddle capacity) raises by default; raise_on_overflow=False returns
-        (results, status) instead: status[i] != 0 marks such a frame (its entry is None), every other
-        frame keeps its result."""
+    TAG_DTYPE = np.dtype([("id", "u4"), ("xy", "f4", (8,))])
+
+    def detect_batch_raw(self, frames, n_threads=0, cap=1024, device_frames=None, out=None, counts=None, status=None):
+        """agx_detect_batch as a C / Rust caller uses it: frames = numpy [N,H,W] uint8 / uint16 or [N,H,W,3] uint8 in
+        host memory (optionally also resident on the GPU as the torch tensor device_frames); the tags go into the
+        caller's arrays out [N, cap] of TAG_DTYPE, counts [N] uint32, status [N] int32 (allocated when None).
+        -> (rc, out, counts, status); nothing is raised for a capacity status."""
         a = np.ascontiguousarray(frames)
         _, fmt, stride = _image_args(a[0])
         if fmt == _ffi.AGX_LF32:
             raise AgxError(_ffi.AGX_ERR_FORMAT, "detect_batch takes L8 / L16 / RGB8 frames")
         n, h, w = a.shape[:3]
-        out = np.zeros((n, cap), np.dtype([("id", "u4"), ("xy", "f4", (8,))]))
-        counts = np.zeros(n, np.uint32)
-        status = np.full(n, _ffi.AGX_ERR_STATE, np.int32)  # (every slot is written by the call; one that is not stays an error)
+        if out is None:
+            out = np.zeros((n, cap), self.TAG_DTYPE)
+        if counts is None:
+            counts = np.zeros(n, np.uint32)
+        if status is None:
+            status = np.zeros(n, np.int32)
+        assert out.shape == (n, cap) and out.dtype == self.TAG_DTYPE and counts.shape == (n,) and status.shape == (n,)
+        status[:] = _ffi.AGX_ERR_STATE  # (every slot is written by the call; one that is not stays an error)
         dptr = None
         if device_frames is not None:
             # the chain reads device_frames, the decode reads `frames`: they must be the same pixels
@@ -205,6 +209,19 @@ class TagDetector:
             dptr = t.data_ptr()
         rc = self._lib.agx_detect_batch(self._h, a.ctypes.data, dptr, n, w, h, stride, stride * h, fmt,
                                         out.ctypes.data, cap, counts.ctypes.data, status.ctypes.data, n_threads)
+        return rc, out, counts, status
+
+    def detect_batch(self, frames, n_threads=0, cap=1024, device_frames=None, raise_on_overflow=True):
+        """detect() over a batch: frames = numpy [N,H,W] uint8 / uint16 or [N,H,W,3] uint8 in host
+        memory (optionally also resident on the GPU as the torch tensor device_frames).  The chain
+        runs on the device chunk by chunk while n_threads host threads (0 = agx_host_parallelism(): the
+        CPUs this process may keep busy) run the uploads and the
+        board search + decode.  -> list of {tag_id: 4x2 corners}.  A frame with more than `cap` tags (or
+        over the detector's saddle capacity) raises by default; raise_on_overflow=False returns
+        (results, status) instead: status[i] != 0 marks such a frame (its entry is None), every other
+        frame keeps its result."""
+        rc, out, counts, status = self.detect_batch_raw(frames, n_threads, cap, device_frames)
+        n = len(counts)
         if rc != _ffi.AGX_OK and (raise_on_overflow or rc != _ffi.AGX_ERR_CAPACITY):
             self._check(rc)
         res = [None if status[i] != 0 else {int(t["id"]): t["xy"].reshape(4, 2).copy() for t in out[i, : counts[i]]} for i in range(n)]

@@ -370,6 +370,87 @@ def host_boundary_leg(torch, A, dev, n_frames, width, height, steps):
         torch.cuda.empty_cache()
 
 
+def detect_end_to_end_leg(torch, A, dev, n_frames, width, height, quick=False):
+    """TagDetector::detect over the batch, end to end (SURVEY.md 8(d) "what is NOT in t_chain ... reported separately as
+    end-to-end frames/s with the host-thread count stated"; reference shape benches/bench_detection.rs:24-36): configs[1]'s
+    frames in ordinary (pageable) HOST memory -> agx_detect_batch -> tag ids + corners in host arrays.  Upload, chain, fetch,
+    board search and decode are all inside; the host tail is the reference's exhaustive search (~1.5 ms per frame and
+    thread), so this rate is set by the host threads, never by the chain -- never `value`.  Timed: the C call alone
+    (caller-owned output arrays, as a C / Rust caller has them), by thread count up to what the process may keep busy
+    (agx_host_parallelism(): affinity mask or cgroup CPU quota, whichever is smaller)."""
+    import numpy as np
+    from aprilgrid_rs_amd import _ffi
+    frames, _ = make_workload(0, n_frames, width, height, "L8", 0, False, dev)
+    host = frames.cpu().numpy()
+    del frames
+    det = A.TagDetector(A.TagFamily.T36H11, None, device=dev.index)
+    quota = int(_ffi.lib().agx_host_parallelism())
+    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cap = 64
+    try:
+        # per-frame detect of a sample: what the batch call must reproduce bit for bit
+        sample = list(range(0, n_frames, max(1, n_frames // 8)))
+        ref = {i: det.detect(host[i]) for i in sample}
+        counts_t = [t for t in (1, 2, 4, 8, 16, 32, 64, 128, 256) if t < quota] + [quota]
+        if quick:
+            counts_t = sorted(set([1, quota]))
+        rows = {}
+        out = np.zeros((n_frames, cap), det.TAG_DTYPE)
+        counts = np.zeros(n_frames, np.uint32)
+        status = np.zeros(n_frames, np.int32)
+
+        def run(thr, n, reps):
+            det.detect_batch_raw(host[: min(n, 4 * thr)], n_threads=thr, cap=cap, out=out[: min(n, 4 * thr)], counts=counts[: min(n, 4 * thr)],
+                                 status=status[: min(n, 4 * thr)])  # pool start-up, staging, per-thread scratch: outside the clock
+            ts = []
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                rc, _, _, _ = det.detect_batch_raw(host[:n], n_threads=thr, cap=cap, out=out[:n], counts=counts[:n], status=status[:n])
+                ts.append(time.perf_counter() - t0)
+                assert rc == 0 and (status[:n] == 0).all(), (rc, status[:n])
+            return statistics.median(ts)
+
+        for thr in counts_t:
+            n = n_frames if thr >= 4 else max(16, min(n_frames, 32 * thr))
+            dt = run(thr, n, 3 if thr >= 4 else 1)
+            rows["threads_%d" % thr] = {"frames": n, "frames_per_s": round(n / dt, 1), "ms_per_frame_per_thread": round(1e3 * dt * thr / n, 3),
+                                        "tags_per_frame": round(float(counts[:n].mean()), 1)}
+            if thr == quota:  # the call just made covered every frame: compare the sample with per-frame detect
+                for i in sample:
+                    got = {int(t["id"]): t["xy"].reshape(4, 2) for t in out[i, : counts[i]]}
+                    assert sorted(got) == sorted(ref[i]) and all(np.array_equal(got[k], ref[i][k]) for k in got), "detect_batch differs from detect (frame %d)" % i
+        base = rows["threads_1"]["frames_per_s"]
+        for k, r in rows.items():
+            r["parallel_efficiency"] = round(r["frames_per_s"] / (base * int(k.split("_")[1])), 3)
+        best = rows["threads_%d" % quota]
+        res = {"workload": "configs[1]'s %d frames %dx%d L8 in pageable host memory -> tag ids + corners in host arrays (agx_detect_batch, the C call alone)" % (n_frames, width, height),
+               "frames_per_s": best["frames_per_s"], "threads": quota, "host_cores": affinity, "host_cpu_quota": quota,
+               "ms_per_frame_per_thread": best["ms_per_frame_per_thread"], "parallel_efficiency": best["parallel_efficiency"],
+               "by_threads": rows, "sample_equals_per_frame_detect": len(sample)}
+        if not quick:
+            # a longer stream of frames (the same 256 eight times over: 2 GB of host memory): start-up and drain amortised
+            big = np.concatenate([host] * max(1, 2048 // n_frames))
+            o2 = np.zeros((len(big), cap), det.TAG_DTYPE)
+            c2 = np.zeros(len(big), np.uint32)
+            s2 = np.zeros(len(big), np.int32)
+            t0 = time.perf_counter()
+            rc, _, _, _ = det.detect_batch_raw(big, n_threads=quota, cap=cap, out=o2, counts=c2, status=s2)
+            dt = time.perf_counter() - t0
+            assert rc == 0 and np.array_equal(c2[:n_frames], counts)
+            res["frames_per_s_%d_frames" % len(big)] = round(len(big) / dt, 1)
+            if quota < affinity:  # what threads beyond the quota cost (the reason the default stops at it)
+                thr = min(affinity, 4 * quota)
+                dt = run(thr, n_frames, 3)
+                res["beyond_quota"] = {"threads": thr, "frames_per_s": round(n_frames / dt, 1)}
+        res["note"] = ("never `value`: set by the host tail (the reference's exhaustive board search, one frame per thread) and by the CPUs the box "
+                       "gives the process (host_cpu_quota of the host_cores it shows: cgroup cpu.max); parallel_efficiency = frames/s over threads x the "
+                       "1-thread rate; the chain alone delivers config.frames_per_s")
+        return res
+    finally:
+        det.close()
+        torch.cuda.empty_cache()
+
+
 class CudaRuntime:
     """What main() needs from the device side.  tests/bench_stub.py provides the same interface on the CPU (gloo
     backend, the oracle behind the detector's enqueue call) so that the N > 1 control flow of main() -- settle-round
@@ -722,6 +803,7 @@ def main():
                                     16, True, st, args.warmup, 4 * vf),
         }
         result["host_boundary"] = host_boundary_leg(torch, A, dev, F, W, H, 20)
+        result["detect_end_to_end"] = detect_end_to_end_leg(torch, A, dev, F, W, H)
         # BASELINE.json configs[0] and the reference's own bench shape (benches/bench_detection.rs:24-36): ONE frame
         # through detect -- latency, GPU path beside the oracle on this box's host -- and the 7-image table
         sys.path.insert(0, os.path.join(ROOT, "tools"))

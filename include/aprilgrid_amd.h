@@ -229,11 +229,19 @@ int agx_saddles_batch_enqueue_to(agx_detector *det, const void *d_frames, int n_
 /* Block until everything enqueued on the detector's stream has finished. */
 int agx_detector_sync(agx_detector *det);
 
+/* How many host threads this process can keep busy: the smaller of its CPU affinity mask and its
+ * cgroup CPU quota (cpu.max / cpu.cfs_quota_us; a container given 16 CPUs of a 256-thread host reports
+ * 16), at least 1.  The default thread count of agx_detect_batch: threads beyond a quota make every
+ * thread of the process -- the one driving the device included -- sit out the rest of each scheduler
+ * period.  (The reference never spawns a thread, src/detector.rs:505; batches are this library's.) */
+int agx_host_parallelism(void);
+
 /* TagDetector::detect (src/detector.rs:505-540) over a batch of equally sized frames in HOST memory
  * (frame i at frames + i*frame_stride_bytes; formats AGX_L8 / AGX_L16 / AGX_RGB8).  The saddle
- * chain of a chunk of frames runs on the device while n_threads host threads (0 = one per host
- * core, at most 64; the pool lives as long as the detector) run the board search + decode of the
- * previous chunk.  d_frames: optional device copy of the same frames (skips the upload), else
+ * chain of a chunk of frames (about one frame per thread, 8 .. 64) runs on the device while n_threads
+ * host threads (0 = agx_host_parallelism(); the pool lives as long as the detector) upload the next
+ * chunks and run the board search + decode of the previous ones; no barrier between chunks.
+ * d_frames: optional device copy of the same frames (skips the upload), else
  * NULL.  out: n_frames * cap_per_frame tags, frame i at out + i*cap_per_frame; counts[i] = tags of
  * frame i; frame_status[i] (may be NULL) = AGX_OK or AGX_ERR_CAPACITY.  Returns the first non-OK
  * frame status, else AGX_OK. */

@@ -324,6 +324,31 @@ def test_rccl_prototypes_group_cpp_binds_by_name():
     assert "kNcclUint8 = 1" in src
 
 
+def test_group_of_several_ranks_reports_an_unloadable_rccl_instead_of_crashing(lib):
+    """ADVICE r4: load_rccl built its message from a second dlerror() call (NULL: the first consumed it) -- std::string +
+    nullptr, a crash no guard catches, on any box where librccl cannot be loaded.  The library is bound before any device
+    is touched, so the path runs without a GPU: a two-rank RCCL group with an unloadable library is an error + message."""
+    from aprilgrid_rs_amd import _ffi
+    os.environ["AGX_RCCL_LIBRARY"] = "/nonexistent/librccl_not_here.so"
+    try:
+        g = C.c_void_p()
+        devs = (C.c_int * 2)(0, 1)
+        st = lib.agx_group_create(3, None, devs, 2, _ffi.AGX_GATHER_RCCL, C.byref(g))
+        assert st == _ffi.AGX_ERR_HIP and not g.value
+        msg = lib.agx_group_last_error(None).decode()
+        assert "dlopen librccl" in msg and "librccl_not_here" in msg, msg
+        # a group of ONE never needs the library (two device-to-device copies move its slabs): with the same unloadable
+        # library its creation gets as far as the device -- which this machine lacks --, not to dlopen
+        devs1 = (C.c_int * 1)(0)
+        st = lib.agx_group_create(3, None, devs1, 1, _ffi.AGX_GATHER_RCCL, C.byref(g))
+        if st != _ffi.AGX_OK:
+            assert "dlopen" not in lib.agx_group_last_error(None).decode()
+        else:  # (a GPU box running the CPU suite)
+            lib.agx_group_destroy(g)
+    finally:
+        del os.environ["AGX_RCCL_LIBRARY"]
+
+
 def test_stand_in_rccl_builds_and_exports_the_bound_symbols(tmp_path):
     """tests/stub_rccl compiles here (host code only) and exports every entry point group.cpp binds."""
     import subprocess

@@ -114,14 +114,19 @@ def test_group_reports_overflow_per_frame(oracle):
 
 def test_group_rccl_transport(oracle):
     """The RCCL gather (ncclSend / ncclRecv over xGMI) through the REAL librccl on every visible device.  With one GPU the
-    group has a single rank, and its slabs still take the library's path -- a send to itself and the matching receive in
-    one ncclGroup on the rank's non-blocking stream --: the dlopen / dlsym binding of group.cpp, ncclCommInitAll, the
-    datatype constant and the ordering behind the chain run against librccl.so itself, not the test suite's stand-in."""
+    group has a single rank; the test switch AGX_GROUP_RCCL_SELF=1 makes its slabs take the library's path -- a send to
+    itself and the matching receive in one ncclGroup on the rank's non-blocking stream --: the dlopen / dlsym binding of
+    group.cpp, ncclCommInitAll, the datatype constant and the ordering behind the chain run against librccl.so itself, not
+    the test suite's stand-in.  (Without the switch a group of one does not touch the library: next test.)"""
     import torch
     import aprilgrid_rs_amd as A
     assert "AGX_RCCL_LIBRARY" not in os.environ
     n_dev = torch.cuda.device_count()
-    grp = A.DetectorGroup("t36h11", list(range(n_dev)), transport="rccl")
+    os.environ["AGX_GROUP_RCCL_SELF"] = "1"
+    try:
+        grp = A.DetectorGroup("t36h11", list(range(n_dev)), transport="rccl")
+    finally:
+        del os.environ["AGX_GROUP_RCCL_SELF"]
     maps = open("/proc/self/maps").read()
     assert "librccl" in maps, "the RCCL transport did not load librccl"
     assert "librccl_stub" not in maps
@@ -139,6 +144,30 @@ def test_group_rccl_transport(oracle):
     grp.close()
     with pytest.raises(A.AgxError):
         A.DetectorGroup("t36h11", [0, 0], transport="rccl")  # duplicate devices: refused, not hung
+
+
+def test_group_of_one_rank_does_not_need_librccl(oracle):
+    """a single rank must not need librccl at all, whatever the transport asked for: with an unloadable
+    library named in AGX_RCCL_LIBRARY a one-rank "rccl" group is created and gathers (two device-to-device copies);
+    a two-rank group with the same environment fails with the loader's message."""
+    import aprilgrid_rs_amd as A
+    os.environ["AGX_RCCL_LIBRARY"] = "/nonexistent/librccl_not_here.so"
+    try:
+        grp = A.DetectorGroup("t36h11", [0], transport="rccl")
+        frames = [_frames(75, 3, "cuda:0")]
+        import torch
+        torch.cuda.synchronize(0)
+        grp.saddles_enqueue(frames)
+        res, status = grp.saddles_fetch()
+        assert (status == 0).all()
+        refs = oracle_saddles_parallel(oracle, frames[0].cpu().numpy(), threads=3)
+        for i in range(len(res)):
+            check_saddles(res[i], refs[i], "frame %d" % i)
+        grp.close()
+        with pytest.raises(A.AgxError, match="dlopen librccl"):
+            A.DetectorGroup("t36h11", [0, 0], transport="rccl")
+    finally:
+        del os.environ["AGX_RCCL_LIBRARY"]
 
 
 def test_group_rccl_branch_with_stand_in_library(oracle, tmp_path):
