@@ -135,18 +135,48 @@ void orc_gaussian_blur_f32(const float *img, int w, int h, float sigma, float *o
     float *temp = (float *)calloc((size_t)w * h, sizeof(float));
     memset(out, 0, (size_t)w * h * sizeof(float));
 
-    /* horizontal pass, :137-185.  The three regions of the reference (left border,
-     * centre, right border) all evaluate  val = 0; val += img[clamp(x+i-r)] * k[i]
-     * for i ascending; the centre simply never clamps. */
+    /* horizontal pass, :137-185, in the reference's three regions: left border (:144-153) and right border
+     * (:170-184, skipping columns the left loop has already written when w < 2r, :173-175) clamp every tap;
+     * the centre (:156-167, only when w > 2r) never clamps and is written to vectorise, as the reference's is --
+     * it matters for the cpu_baseline timing, not for the values: all three evaluate
+     * val = 0; val += img[clamp(x+i-r)] * k[i] for i ascending. */
+    const int left_end = radius < w ? radius : w;
+    const int right_start = w - radius > 0 ? w - radius : 0;
     for (int y = 0; y < h; ++y) {
-        const float *row = img + (size_t)y * w;
-        float *trow = temp + (size_t)y * w;
-        for (int x = 0; x < w; ++x) {
+        const float *restrict row = img + (size_t)y * w;
+        float *restrict trow = temp + (size_t)y * w;
+        for (int x = 0; x < left_end; ++x) {
             float val = 0.0f;
-            for (int i = 0; i < size; ++i) {
-                int kx = clampi(x + i - radius, 0, w - 1);
-                val += row[kx] * kernel[i];
+            for (int i = 0; i < size; ++i) val += row[clampi(x + i - radius, 0, w - 1)] * kernel[i];
+            trow[x] = val;
+        }
+        if (w > 2 * radius) {
+            const int n_centre = w - 2 * radius;
+            if (size == 7) { /* sigma 1.5, the only value the detector uses: the taps unrolled */
+                const float k0 = kernel[0], k1 = kernel[1], k2 = kernel[2], k3 = kernel[3], k4 = kernel[4], k5 = kernel[5], k6 = kernel[6];
+                for (int i = 0; i < n_centre; ++i) {
+                    float val = 0.0f;
+                    val += row[i] * k0;
+                    val += row[i + 1] * k1;
+                    val += row[i + 2] * k2;
+                    val += row[i + 3] * k3;
+                    val += row[i + 4] * k4;
+                    val += row[i + 5] * k5;
+                    val += row[i + 6] * k6;
+                    trow[radius + i] = val;
+                }
+            } else {
+                for (int i = 0; i < n_centre; ++i) {
+                    float val = 0.0f;
+                    for (int k = 0; k < size; ++k) val += row[i + k] * kernel[k];
+                    trow[radius + i] = val;
+                }
             }
+        }
+        for (int x = right_start; x < w; ++x) {
+            if (x < radius) continue;
+            float val = 0.0f;
+            for (int i = 0; i < size; ++i) val += row[clampi(x + i - radius, 0, w - 1)] * kernel[i];
             trow[x] = val;
         }
     }
