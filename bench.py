@@ -134,6 +134,16 @@ def verify_against_oracle(results, frames_host, what, threads=8):
     return len(refs)
 
 
+def host_parallelism():
+    """CPUs this process may keep busy = min(affinity mask, cgroup CPU quota): the library's agx_host_parallelism() when it
+    is loadable, else the affinity mask."""
+    try:
+        from aprilgrid_rs_amd import _ffi
+        return max(1, int(_ffi.lib().agx_host_parallelism()))
+    except Exception:
+        return max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+
+
 def cpu_baseline(frames_host, fmt, budget_s):
     """Oracle (C port of the reference CPU path, -O3 -march=native, still no FMA contraction),
     one thread, chain only (refined_saddle_points), on as many of the bench's own frames as fit
@@ -166,7 +176,9 @@ def cpu_baseline(frames_host, fmt, budget_s):
     # SURVEY.md 8(d) baseline #2: the same code, frame-parallel over the host cores this process may
     # use (ctypes releases the GIL; every thread has its own output buffer) -- a short extra sample
     import threading
-    n_thr = max(1, min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 64))
+    # every CPU the process may keep busy: its affinity mask narrowed by its cgroup CPU quota (a 1-GPU box of this pool shows
+    # 256 CPUs and grants 16: cpu.max "1600000 100000"; threads beyond the quota only get the whole process throttled)
+    n_thr = host_parallelism()
     counts = [0] * n_thr
     t_end = time.perf_counter() + min(5.0, budget_s)
 
@@ -188,6 +200,7 @@ def cpu_baseline(frames_host, fmt, budget_s):
     t_mt = time.perf_counter() - t_mt
     return {"value": round(mpix, 3), "unit": "Mpix/s", "cores": 1, "kind": "port",
             "all_cores": {"value": round(sum(counts) * w * h / t_mt / 1e6, 1), "unit": "Mpix/s", "cores": n_thr,
+                          "host_cores_shown": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1),
                           "sample": "%d frames in %.1f s on %d threads" % (sum(counts), t_mt, n_thr)},
             "sample": "%d frames %dx%d %s, chain only (refined_saddle_points), oracle/agx_oracle.c -O3 "
                       "-march=native -ffp-contract=off, %.1f s" % (n_done, w, h, fmt, t_used),
@@ -781,7 +794,8 @@ def main():
                                                                   threads=min(16, os.cpu_count() or 1))
             if not args.no_cpu_baseline:
                 result["cpu_baseline"] = cpu_baseline(host, args.format, args.cpu_seconds)
-                result["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+                result["cpu_baseline"]["host_cores_available"] = host_parallelism()  # = all_cores.cores: affinity mask or cgroup quota
+                result["cpu_baseline"]["host_cores_shown"] = os.cpu_count()
     pipe.close()
     del pipe
     if world == 1 and rank == 0 and not args.no_extra:
