@@ -42,7 +42,10 @@ struct FrameCounters {
     uint32_t n_cand;       // generic path: candidate pixels
     uint32_t n_roots;      // generic path: union-find roots
     uint32_t n_big;        // seeds handed to the wave-wide second flood tier
-    uint32_t refine_done;  // (unused since the emission moved into k_rare)
+    uint32_t refine_done;  // emit_large_split (k_rare with several workgroups per frame): lock + state of the frame's place in the
+                           // compact output -- 0 free, 1 taken by the part that arrived first (CAS), 2 allocated and it fits,
+                           // 3 allocated but over capacity; the frame's other parts spin on it until it is >= 2.  Must be 0 at
+                           // batch start (the counters' clearing provides that).  Not touched on any other path.
     uint32_t n_clusters2;  // (unused since the second flood tier runs inside k_flood_refine; always 0)
     uint32_t stats[20];    // debug_ablation & 128: verify statistics by word row within a 128-row segment
 };
@@ -130,6 +133,11 @@ struct ChainArgs {
     uint32_t *frame_table;   // optional caller-owned [n_frames][4]: count, offset, status, clusters
     float min_angle, max_angle;
 };
+
+// Tuning overrides from the environment (AGX_K1_*, AGX_G_*, AGX_RARE_PARTS, AGX_SPARSE_PATH: measurement only).  A name is read
+// from the environment once per process and kept; tuning_env_reload() forgets what was read (option "reload_tuning_env").
+int tuning_env(const char *name, int dflt);
+void tuning_env_reload();
 
 // Choose K1's tiling for a frame size / batch size.  Returns false if unsupported.
 bool plan_k1(ChainArgs &a, int override_rows_per_seg);

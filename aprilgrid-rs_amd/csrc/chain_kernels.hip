@@ -31,6 +31,10 @@
 //                       the large-list sort (> 1024 refined records per frame)
 #include <hip/hip_runtime.h>
 
+#include <map>
+#include <mutex>
+#include <string>
+
 #include "chain_kernels.h"
 
 namespace agx {
@@ -2804,11 +2808,29 @@ __global__ void __launch_bounds__(1024) k_sparse_frame(ChainArgs a, RefineConsts
 // ------------------------------------------------------------------------------------------
 // host side: tiling plan and launches
 // ------------------------------------------------------------------------------------------
-static int env_int(const char *name, int dflt)
-{
-    const char *s = getenv(name);
-    return (s && *s) ? atoi(s) : dflt;
+// Tuning overrides from the environment (measurement only; the defaults are the product).  Each name is read from the
+// environment ONCE per process -- not on every launch -- and kept; tuning_env_reload() (option "reload_tuning_env": the
+// sweep tools that change os.environ between runs of one process) forgets what was read.
+namespace {
+std::mutex g_env_mutex;
+std::map<std::string, std::pair<bool, int>> g_env_cache;  // name -> (set, value)
 }
+int tuning_env(const char *name, int dflt)
+{
+    std::lock_guard<std::mutex> lk(g_env_mutex);
+    auto it = g_env_cache.find(name);
+    if (it == g_env_cache.end()) {
+        const char *s = getenv(name);
+        it = g_env_cache.emplace(name, std::make_pair(s && *s, (s && *s) ? atoi(s) : 0)).first;
+    }
+    return it->second.first ? it->second.second : dflt;
+}
+void tuning_env_reload()
+{
+    std::lock_guard<std::mutex> lk(g_env_mutex);
+    g_env_cache.clear();
+}
+static int env_int(const char *name, int dflt) { return tuning_env(name, dflt); }
 
 constexpr long long K1_ASYNC_POLL_MAX_WAVES = 4608;  // measured crossover: 1280x800 x 16 (2 400 waves) and 1920x1080 x 16 (4 352) gain, 1280x800 x 32 (4 800) loses (profiles/r4_k1_async_poll.txt)
 bool plan_k1(ChainArgs &a, int override_rows_per_seg)

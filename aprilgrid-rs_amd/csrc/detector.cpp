@@ -46,6 +46,8 @@ struct agx_detector {
     int k1_rows = 0;
     int sparse_path = 0;  // option "sparse_path": 0 = by batch size, 1 = K2 + K3 + K4 (three launches), 2 = k_sparse_frame (one)
     bool last_sparse_frame = false;  // the last batch ran K1 + K_SPARSE
+    int last_sparse_path = 1;        // 1 three launches, 2 k_sparse_frame alone, 3 k_verify_seeds + k_sparse_frame
+    int n_cus = 0;                   // compute units of the device (hipDeviceProp_t::multiProcessorCount)
     int dbg = 0;
     float *d_dbg_resp = nullptr;  // lazily allocated plane for agx_debug_fetch(AGX_DBG_RESP_RECOMPUTED)
     long long dbg_resp_plane = 0;
@@ -418,14 +420,19 @@ int enqueue_chunk(agx_detector *d, int f0, int nf, hipStream_t st)
     // The sparse phase: one workgroup per frame doing all of it (k_sparse_frame) when the batch fills the chip that way,
     // else the three batch-wide launches.  (Timing ablations and the wave timeline instrument the three launches.)
     int path = d->sparse_path;
-    if (const char *e = getenv("AGX_SPARSE_PATH")) path = atoi(e);
+    {   // measurement override (read from the environment once per process, chain_kernels.h): 0 .. 3 or ignored
+        const int forced = tuning_env("AGX_SPARSE_PATH", -1);
+        if (forced >= 0 && forced <= 3) path = forced;
+    }
     const int sparse_dbg = 32 | 64 | 128 | 256 | 2048 | 4096 | 8192 | 16384;  // debug_ablation bits that instrument K2 / K3 / K4
     // by batch size: one workgroup per frame pays when the frames fill the chip's 256 CUs in whole rounds (the last round at least
     // three quarters full); then k_verify_seeds keeps its launch (8 waves per SIMD, balanced over the whole batch: 40 us against the
     // 33 .. 75 us per frame of the verify stage inside k_sparse_frame) and flood + refine + emission share one (path 3)
-    if (path == 0) path = (nf >= 192 && (nf % 256 == 0 || nf % 256 >= 192)) ? 3 : 1;
+    const int cus = d->n_cus > 0 ? d->n_cus : 256, nearly = cus - cus / 4;  // (MI355X: 256 CUs, 192)
+    if (path == 0) path = (nf >= nearly && (nf % cus == 0 || nf % cus >= nearly)) ? 3 : 1;
     const bool fused = (path == 2 || path == 3) && !(a.dbg & sparse_dbg);
     d->last_sparse_frame = fused;
+    d->last_sparse_path = fused ? path : 1;
     a.sparse_after_verify = fused && path == 3;
     const int plan_fused[] = {K_BLUR_HESSIAN, K_SPARSE}, plan_multi[] = {K_BLUR_HESSIAN, K_THRESHOLD, K_FLOOD_REFINE, K_RARE},
               plan_v_fe[] = {K_BLUR_HESSIAN, K_THRESHOLD, K_SPARSE};
@@ -692,12 +699,14 @@ int agx_detector_create(int family, const agx_params *params, int device, agx_de
             delete p;
         }
     };
+    tuning_env_reload();  // the AGX_* measurement overrides are read when a detector is created (and kept: no getenv per launch)
     std::unique_ptr<agx_detector, Unwind> d(new agx_detector());
     d->family = family;
     d->fam = fam;
     if (params) d->params = *params;
     else agx_default_params(&d->params);
     d->device = device;
+    d->n_cus = prop.multiProcessorCount;
     if (const char *rz = std::getenv("AGX_REDZONE_BYTES")) {  // tests: guard bytes around every workspace buffer
         const long v = std::atol(rz);
         if (v > 0 && v <= (1 << 24)) d->redzone = ((size_t)v + 255) & ~(size_t)255;  // keeps the buffers' alignment
@@ -794,6 +803,7 @@ int agx_detector_set_option(agx_detector *det, const char *name, int value)
     else if (!std::strcmp(name, "store_response")) det->store_resp = value != 0;
     else if (!std::strcmp(name, "profile_stride")) det->prof_stride = value > 1 ? value : 1;
     else if (!std::strcmp(name, "profile_kernel")) det->prof_kernel = value >= 0 && value < K_COUNT ? value : K_BLUR_HESSIAN;
+    else if (!std::strcmp(name, "reload_tuning_env")) tuning_env_reload();  // (process-wide: the AGX_* overrides are read again)
     else if (!std::strcmp(name, "tail_threads")) {
         const int n = value < 1 ? 1 : (value > 64 ? 64 : value);
         if (n != det->tail_threads) {
@@ -820,7 +830,7 @@ int agx_detector_get_option(const agx_detector *det, const char *name, int *valu
     // the blur kernel's tiling of the last enqueued batch (0 before the first one)
     else if (!std::strcmp(name, "k1_rows_per_segment")) *value = a.rows_per_seg;
     else if (!std::strcmp(name, "sparse_path")) *value = det->sparse_path;
-    else if (!std::strcmp(name, "last_sparse_path")) *value = det->last_sparse_frame ? 2 : 1;
+    else if (!std::strcmp(name, "last_sparse_path")) *value = det->last_sparse_path;
     else if (!std::strcmp(name, "k1_segments")) *value = a.n_segs;
     else if (!std::strcmp(name, "k1_strips")) *value = a.n_strips;
     else if (!std::strcmp(name, "k1_strip_columns")) *value = a.strip_cols;

@@ -19,11 +19,24 @@ def shard_range(rank, world, frames_per_rank):
     return lo, lo + frames_per_rank
 
 
+def alloc_packed(n_frames, device, slab_records=SLAB_RECORDS):
+    """One rank's result slab as ONE device buffer: [n_frames * 4 table words | n_frames * slab_records * 5 record
+    floats] (float32 storage; the table is an int32 view of its head).  -> (flat, saddles, table): the two views are the
+    caller-owned buffers of agx_saddles_batch_enqueue_to, `flat` is what the gather moves -- one message per rank and
+    step instead of two."""
+    flat = torch.zeros(n_frames * 4 + n_frames * slab_records * 5, dtype=torch.float32, device=device)
+    return (flat,) + split_packed(flat, n_frames)
+
+
+def split_packed(flat, n_frames):
+    """(saddles [n, 5] f32, table [n_frames, 4] i32) views of a packed slab."""
+    return flat[n_frames * 4:].view(-1, 5), flat[: n_frames * 4].view(torch.int32).view(n_frames, 4)
+
+
 def alloc_result_buffers(n_frames, device, slab_records=SLAB_RECORDS):
     """(saddles [n_frames*slab_records, 5] f32, table [n_frames, 4] i32: count, offset, status,
-    clusters) -- the caller-owned device buffers of agx_saddles_batch_enqueue_to."""
-    return (torch.zeros((n_frames * slab_records, 5), dtype=torch.float32, device=device),
-            torch.zeros((n_frames, 4), dtype=torch.int32, device=device))
+    clusters) -- the caller-owned device buffers of agx_saddles_batch_enqueue_to (views of one packed slab)."""
+    return alloc_packed(n_frames, device, slab_records)[1:]
 
 
 def gather_results(saddles, table, dst=0, group=None):
@@ -46,64 +59,75 @@ def gather_results(saddles, table, dst=0, group=None):
 
 class GatherPipeline:
     """Double-buffered result buffers with asynchronous gathers, so that the gather of step i
-    overlaps the chain of step i+1 (which writes the other buffer pair).
+    overlaps the chain of step i+1 (which writes the other buffer pair).  A rank's frame table and its
+    records live in ONE packed buffer (alloc_packed), so a step's gather is one message per rank: on
+    rank 0 of an 8-GPU node 7 receives of 2.6 MB per step instead of 14 (tables and records apart).
+    `every` > 1 gathers only every n-th submitted step (and always the last one before finish()): what a
+    consumer that polls results at a lower rate than the chain produces them would ask for; the default,
+    and what bench.py times, is every step.
 
         pipe = GatherPipeline(n_frames, device)
         for step in ...:
             out, table = pipe.acquire()      # waits (stream-side) for the gather that last used them
             det.saddles_batch_enqueue_to(frames, out, table)
-            pipe.submit()                    # async gather of (out, table) to rank `dst`
+            pipe.submit()                    # async gather of the packed slab to rank `dst`
         gathered = pipe.finish()             # on dst: (list_of_saddles, list_of_tables) of the LAST step
     """
 
     def __init__(self, n_frames, device, dst=0, group=None, depth=2, always_depth=False, slab_records=SLAB_RECORDS,
-                 force_collective=False):
+                 force_collective=False, every=1):
         # force_collective: a world of ONE rank still sends its slabs through the backend's gather (bench.py
         # --collective-world-1: what a one-GPU box can exercise of the nccl = RCCL path)
         self.dst, self.group = dst, group
+        self.n_frames = n_frames
         self.multi = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force_collective)
         self.world = dist.get_world_size(group) if self.multi else 1
         self.rank = dist.get_rank(group) if self.multi else 0
+        self.every = max(1, int(every))
         # one rank alone needs a single buffer pair unless several batches are in flight (ChainPipeline)
-        self.bufs = [alloc_result_buffers(n_frames, device, slab_records)
-                     for _ in range(depth if (self.multi or always_depth) else 1)]
+        packed = [alloc_packed(n_frames, device, slab_records) for _ in range(depth if (self.multi or always_depth) else 1)]
+        self.flat = [p[0] for p in packed]
+        self.bufs = [(p[1], p[2]) for p in packed]
         self.recv = None
         if self.multi and self.rank == dst:
-            self.recv = [([torch.empty_like(s) for _ in range(self.world)], [torch.empty_like(t) for _ in range(self.world)])
-                         for (s, t) in self.bufs]
+            self.recv = [[torch.empty_like(f) for _ in range(self.world)] for f in self.flat]
         self.works = [None] * len(self.bufs)
         self.i = -1
+        self.submitted = 0
+        self.gathered_i = None  # buffer index of the last step that went through the gather
 
     def acquire(self):
         self.i = (self.i + 1) % len(self.bufs)
         w = self.works[self.i]
         if w is not None:
-            for h in w:
-                h.wait()  # the current stream waits for the gather that was reading these buffers
+            w.wait()  # the current stream waits for the gather that was reading these buffers
             self.works[self.i] = None
         return self.bufs[self.i]
 
+    def _gather(self):
+        f = self.flat[self.i]
+        self.works[self.i] = dist.gather(f, self.recv[self.i] if self.rank == self.dst else None, dst=self.dst, group=self.group,
+                                         async_op=True)
+        self.gathered_i = self.i
+
     def submit(self):
-        if not self.multi:
-            return
-        s, t = self.bufs[self.i]
-        if self.rank == self.dst:
-            gs, gt = self.recv[self.i]
-            self.works[self.i] = [dist.gather(t, gt, dst=self.dst, group=self.group, async_op=True),
-                                  dist.gather(s, gs, dst=self.dst, group=self.group, async_op=True)]
-        else:
-            self.works[self.i] = [dist.gather(t, None, dst=self.dst, group=self.group, async_op=True),
-                                  dist.gather(s, None, dst=self.dst, group=self.group, async_op=True)]
+        self.submitted += 1
+        if self.multi and self.submitted % self.every == 0:
+            self._gather()
 
     def finish(self):
+        if self.multi and self.gathered_i != self.i and self.i >= 0:
+            self._gather()  # (every > 1: the last step's results are always delivered)
         for w in self.works:
             if w is not None:
-                for h in w:
-                    h.wait()
+                w.wait()
         self.works = [None] * len(self.bufs)
         if not self.multi:
             return [self.bufs[self.i][0]], [self.bufs[self.i][1]]
-        return self.recv[self.i] if self.rank == self.dst else (None, None)
+        if self.rank != self.dst:
+            return None, None
+        views = [split_packed(f, self.n_frames) for f in self.recv[self.i]]
+        return [v[0] for v in views], [v[1] for v in views]
 
 
 class ChainPipeline:
@@ -120,7 +144,7 @@ class ChainPipeline:
     """
 
     def __init__(self, tag_family, n_frames, device, depth=2, params=None, dst=0, group=None, slab_records=SLAB_RECORDS,
-                 detector_cls=None, force_collective=False):
+                 detector_cls=None, force_collective=False, gather_every=1):
         # detector_cls: a stand-in with TagDetector's enqueue interface (the CPU test of bench.py's N > 1 control flow)
         if detector_cls is None:
             from .detector import TagDetector
@@ -135,7 +159,8 @@ class ChainPipeline:
         # depth 1 stays on the caller's stream (no cross-stream events at all)
         self.streams = [torch.cuda.Stream(dev) for _ in range(self.depth)] if self.depth > 1 else [None]
         self.gather = GatherPipeline(n_frames, dev, dst=dst, group=group, depth=max(2, self.depth),
-                                     always_depth=self.depth > 1, slab_records=slab_records, force_collective=force_collective)
+                                     always_depth=self.depth > 1, slab_records=slab_records, force_collective=force_collective,
+                                     every=gather_every)
         self.i = -1
         self.last_table = None
 

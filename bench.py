@@ -88,6 +88,9 @@ def parse_args():
     ap.add_argument("--collective-world-1", action="store_true",
                     help="N = 1 only: initialise the nccl (= RCCL) process group with a world of one rank anyway and send every "
                          "step's result slabs through its gather -- what a one-GPU box can exercise of the multi-GPU path")
+    ap.add_argument("--gather-every", type=int, default=1,
+                    help="N > 1: gather the result slabs to rank 0 every n-th step (and the last one) instead of every step; "
+                         "the default -- and what the headline is quoted on -- is every step")
     ap.add_argument("--pmc-traffic", type=float, default=None,
                     help="HBM bytes per K1 launch from a separate rocprofv3 --pmc run (profiles/)")
     return ap.parse_args()
@@ -543,7 +546,7 @@ def main():
     # collective of the path -- so the gather of a step overlaps the chain of the next.
     slab = 8192 if args.noise else sharding.SLAB_RECORDS  # pure noise: ~7100 saddles per 1280x800 frame
     pipe = sharding.ChainPipeline(A.TagFamily.T36H11, F, dev, depth=args.pipeline, dst=0, slab_records=slab,
-                                  detector_cls=rt.detector_cls, force_collective=coll1)
+                                  detector_cls=rt.detector_cls, force_collective=coll1, gather_every=args.gather_every)
 
     def step():
         pipe.submit(frames)
@@ -764,7 +767,8 @@ def main():
                 "a_mat_bytes_per_px": a_mat,
                 "kernel_ms_per_step": {k: round(v[0] / max(v[1], 1), 5) for k, v in prof.items()},
                 "sparse_path": {1: "k_verify_seeds + k_flood_refine + k_rare (three launches)",
-                                2: "k_verify_seeds + k_sparse_frame (one workgroup per frame: floods, refinement, emission)"}.get(det.get_option("last_sparse_path")),
+                                2: "k_sparse_frame alone (one workgroup per frame: verify, seeds, floods, refinement, emission)",
+                                3: "k_verify_seeds + k_sparse_frame (one workgroup per frame: floods, refinement, emission)"}.get(det.get_option("last_sparse_path")),
                 "sum_kernel_ms_per_step": round(chain_ms, 5),
                 "a_mat_equivalent_GBps": round(px_per_step_rank * a_mat / (chain_ms * 1e-3) / 1e9, 1),
                 "a_mat_equivalent_frac_of_peak": round(px_per_step_rank * a_mat / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),

@@ -129,6 +129,9 @@ int agx_detector_set_limits(agx_detector *det, uint32_t max_candidates, uint32_t
  *                          kernel, the default).  One kernel at a time keeps its neighbours back to back on the
  *                          stream, so the figure is the kernel's own duration; level 2 (all at once) opens a gap
  *                          in front of every kernel
+ *   "reload_tuning_env"    (any value) the AGX_* measurement overrides of the environment (AGX_K1_ROWS, AGX_SPARSE_PATH, ...:
+ *                          README.md "Tuning switches") are read once per process and kept; this forgets them, so that a
+ *                          tool which changes its environment between runs of one process sees the change
  *   "tail_threads"         n > 1: agx_detect / agx_detect_planes / agx_detect_from_saddles search the boards of
  *                          ONE frame on n host threads (the up-to-30 seed saddles of try_find_best_board,
  *                          detector.rs:611-625, in waves of n, merged in the reference's order: same result;
@@ -144,7 +147,8 @@ int agx_detector_set_limits(agx_detector *det, uint32_t max_candidates, uint32_t
 int agx_detector_set_option(agx_detector *det, const char *name, int value);
 /* Read an option back; additionally the tiling the blur kernel used for the last enqueued batch:
  * "k1_rows_per_segment" (effective value), "k1_segments", "k1_strips", "k1_strip_columns", and
- * "last_sparse_path": 1 = the last batch took the three launches, 2 = a workgroup per frame. */
+ * "last_sparse_path": how the last batch's sparse stages ran: 1 = the three launches, 2 = one workgroup per frame for all
+ * of it, 3 = the verify launch, then a workgroup per frame (the values of option "sparse_path"). */
 int agx_detector_get_option(const agx_detector *det, const char *name, int *value);
 
 /* Stream selection.  external != 0: launch on the caller's stream `hip_stream` (hipStream_t as

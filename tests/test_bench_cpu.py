@@ -56,3 +56,46 @@ def test_bench_two_rank_control_flow_under_gloo():
     # whole-job value: both ranks' pixels over the slowest rank's time
     assert abs(out["value"] - 2 * 2 * 192 * 128 * 3 / (out["ms_per_step"] * 3 * 1e-3) / 1e6) < 0.02 * out["value"]
     assert "configs[2]" in out["config"]["workload"] and "chain_frac" in out["roofline"] and "a_min_frac" in out["roofline"]
+
+
+def _launch(world, extra, timeout=900):
+    import json
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {**os.environ, "AGX_BENCH_STUB": "1", "PYTHONPATH": ROOT, "OMP_NUM_THREADS": "1", "MKL_NUM_THREADS": "1"}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world)] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=timeout, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # ONE line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_eight_rank_control_flow_under_gloo():
+    """The run nobody has seen (SCALE has been skipped every round): bench.main() exactly as the driver launches it for
+    N = 8 -- torch.distributed.run, 8 processes, `--gpus 8` -- with configs[2]'s sharding: 256 frames per rank, 2 048 in
+    all, rank r owns frames [256 r, 256 r + 256) of the generator.  gloo + tests/bench_stub.py stand in for the devices
+    (small frames: the stub's chain is the oracle).  Rank 0 must find all eight ranks' tables in the gather, its own slab
+    unchanged, and the FIRST FRAME OF EVERY OTHER RANK -- re-rendered from its global index -- equal to the oracle's list:
+    rank-major order, nothing dropped, no collective out of step on any of the 8 ranks (a mismatch hangs or fails here)."""
+    out = _launch(8, ["--steps", "2", "--warmup", "1", "--frames", "256", "--width", "192", "--height", "128", "--settle-ms", "0",
+                      "--no-extra", "--no-cpu-baseline"])
+    assert out["n_gpus"] == 8 and out["steps"] == 2 and out["scaling"] == "weak" and out["backend"] == "cpu-stub"
+    gc = out["gather_check"]
+    assert gc["ranks"] == 8 and gc["frames"] == 2048 and gc["oracle_checked_remote_frames"] == 7 and gc["through_collective"] is True
+    assert out["config"]["frames_per_gpu"] == 256 and "x8" in out["config"]["parallelism"]
+    # whole-job value: all eight ranks' pixels over the slowest rank's time
+    assert abs(out["value"] - 8 * 256 * 192 * 128 * 2 / (out["ms_per_step"] * 2 * 1e-3) / 1e6) < 0.02 * out["value"]
+
+
+def test_bench_gathers_every_nth_step_and_always_the_last():
+    """--gather-every 3 over 4 timed steps on 3 ranks (a world that is neither 1, 2 nor a power of two): the last step's
+    results still arrive complete on rank 0 and are checked like any other run's."""
+    out = _launch(3, ["--steps", "4", "--warmup", "1", "--frames", "3", "--width", "192", "--height", "128", "--settle-ms", "0",
+                      "--no-extra", "--no-cpu-baseline", "--gather-every", "3"])
+    gc = out["gather_check"]
+    assert out["n_gpus"] == 3 and gc["ranks"] == 3 and gc["frames"] == 9 and gc["oracle_checked_remote_frames"] == 2

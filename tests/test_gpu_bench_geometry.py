@@ -96,7 +96,7 @@ def test_config2_top_shard_frames(det, oracle):
     frames, uniq = bench.make_workload(first, 256, 1280, 800, "L8", 0, False, torch.device("cuda", 0))
     assert uniq == 256
     res = run_batch(det, frames)
-    assert det.get_option("last_sparse_path") == 2 and det.get_option("k1_rows_per_segment") == 96
+    assert det.get_option("last_sparse_path") == 3 and det.get_option("k1_rows_per_segment") == 96
     host = host_frames(frames, "L8")
     refs = oracle_saddles_parallel(oracle, host, threads=16)
     for i in range(256):

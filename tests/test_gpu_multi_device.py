@@ -213,6 +213,59 @@ def test_group_rccl_branch_with_stand_in_library(oracle, tmp_path):
         del os.environ["AGX_RCCL_LIBRARY"]
 
 
+def test_group_of_eight_ranks_through_the_rccl_branch_one_rank_overflowing(oracle, tmp_path):
+    """The shape of the 8-GPU node, rehearsed on whatever is visible: EIGHT ranks through group.cpp's RCCL transport
+    (tests/stub_rccl behind AGX_RCCL_LIBRARY, the ranks round-robin over the visible devices), one ncclGroup with 14
+    sends and 14 receives per batch, rank-major frame order -- and rank 5's detector given room for 40 saddles per frame,
+    so that exactly ITS frames report AGX_ERR_CAPACITY while the 14 frames of the other seven ranks come back complete and
+    equal to the oracle's."""
+    import ctypes as C
+    import subprocess
+    import torch
+    import aprilgrid_rs_amd as A
+    from tests.util import ROOT
+    so = str(tmp_path / "librccl_stub.so")
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "-O2", "-fPIC", "-shared", "-o", so, os.path.join(ROOT, "tests", "stub_rccl", "stub_rccl.cpp")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    os.environ["AGX_RCCL_LIBRARY"] = so
+    try:
+        ranks, fpr, bad = 8, 2, 5
+        n_dev = torch.cuda.device_count()
+        devices = [q % n_dev for q in range(ranks)]
+        grp = A.DetectorGroup("t36h11", devices, transport="rccl")
+        assert len(grp) == ranks
+        lib = grp._lib
+        lib.agx_group_detector.restype = C.c_void_p
+        lib.agx_group_detector.argtypes = [C.c_void_p, C.c_int]
+        h = lib.agx_group_detector(grp._g, bad)
+        assert h and lib.agx_detector_set_limits(C.c_void_p(h), 0, 0, 40) == 0
+        frames = [_frames(300 + fpr * q, fpr, "cuda:%d" % devices[q]) for q in range(ranks)]
+        for d in set(devices):
+            torch.cuda.synchronize(d)
+        for rep in range(2):
+            grp.saddles_enqueue(frames)
+            res, status = grp.saddles_fetch(raise_on_overflow=False)
+        assert len(res) == ranks * fpr
+        want_bad = [bad * fpr + f for f in range(fpr)]
+        assert [i for i in range(len(res)) if status[i] != 0] == want_bad and all(status[i] == -3 for i in want_bad), status
+        host = np.concatenate([f.cpu().numpy() for f in frames])
+        refs = oracle_saddles_parallel(oracle, host, threads=4)
+        for i in range(len(res)):
+            if i in want_bad:
+                assert len(res[i]) == 0 and len(refs[i]) > 40
+            else:
+                check_saddles(res[i], refs[i], "global frame %d (rank %d)" % (i, i // fpr))
+        stub = C.CDLL(so)
+        st = (C.c_int * 8)()
+        stub.stub_rccl_stats(st)
+        groups, sends, recvs, kib, errors, created, destroyed, max_ops = list(st)
+        assert errors == 0 and groups == 2 and created == ranks and sends == recvs == 2 * 2 * (ranks - 1) and max_ops == 4 * (ranks - 1)
+        grp.close()
+    finally:
+        del os.environ["AGX_RCCL_LIBRARY"]
+
+
 def test_plain_c_group_client(oracle, tmp_path):
     """examples/c_group_client.c -- no Python / torch in that process: 3 ranks round-robin over the
     visible devices with the peer-copy gather, and one rank per device with the RCCL gather; the

@@ -272,6 +272,8 @@ def test_verify_kernel_linear_grid_equals_tile_grid(det, monkeypatch):
             assert a.tobytes() == b.tobytes()
     finally:
         d2.close()
+        monkeypatch.delenv("AGX_G_VERIFY")
+        det.set_option("reload_tuning_env", 1)  # (the overrides are read at detector creation and kept)
 
 
 @pytest.mark.parametrize("depth", [1, 2, 3])

@@ -23,7 +23,7 @@ def det(request):
     d = A.TagDetector(A.TagFamily.T36H11, None, device=0)
     d.set_option("sparse_path", request.param)
     yield d
-    assert d.get_option("last_sparse_path") == 2  # the forced path was the one that ran
+    assert d.get_option("last_sparse_path") == request.param  # the forced path was the one that ran
     d.close()
 
 
@@ -80,7 +80,7 @@ def test_batch_size_selects_the_path():
     import aprilgrid_rs_amd as A
     synth = synth_module()
     d = A.TagDetector("t36h11", None, device=0)
-    for n, expect in ((64, 1), (256, 2), (300, 1)):
+    for n, expect in ((64, 1), (256, 3), (300, 1)):
         frames, _ = synth.render_batch(0, 4, 320, 200, device="cuda")
         frames = frames.repeat((n // 4 + 1, 1, 1))[:n].contiguous()
         d.saddles_batch_enqueue(frames)
@@ -110,4 +110,6 @@ def test_k1_poll_forms_agree_bit_for_bit(monkeypatch, fmt):
         d.close()
     assert got["0"] == got["1"]
     monkeypatch.delenv("AGX_K1_ASYNC_POLL")
+    d = A.TagDetector("t36h11", None, device=0)  # (creating a detector reads the environment again: the override is gone)
+    d.close()
     torch.cuda.synchronize()
