@@ -317,9 +317,14 @@ __device__ __forceinline__ int H_full_segs(const ChainArgs &a) { return a.H / a.
 #ifndef AGX_IN_LOAD_AUX
 #define AGX_IN_LOAD_AUX 0  // cache policy bits of the frame's buffer loads
 #endif
-template <int FMT, bool A4, bool RESP = false>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((A4 && !RESP && AGX_K1_WPE) ? ((FMT == 0 || FMT == 1) ? (AGX_K1_WPE_MAX < 5 ? AGX_K1_WPE_MAX : 5) : 4) : 1, AGX_K1_WPE_MAX))) k_blur_hessian(ChainArgs a)
+// UF (round 5; L8 only, with A4 false): frames whose width is not a multiple of 4 or whose rows / base are not 4-byte aligned
+// keep the aligned form's loads and tap table -- one (unaligned) dword per lane and row through the buffer resource, the lane's
+// four pixels picked out of it by a per-lane byte selector that also replicates the edge pixel (clamp-to-edge) -- instead of
+// gathering bytes row by row: the generic form ran 3.4 - 4.8 x slower per pixel than the aligned one (profiles/r5_k1_unaligned_*).
+template <int FMT, bool A4, bool RESP = false, bool UF = false>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(((A4 || UF) && !RESP && AGX_K1_WPE) ? ((FMT == 0 || FMT == 1) ? (AGX_K1_WPE_MAX < 5 ? AGX_K1_WPE_MAX : 5) : 4) : 1, AGX_K1_WPE_MAX))) k_blur_hessian(ChainArgs a)
 {
+    static_assert(!UF || (FMT == 0 && !A4), "the unaligned fast form exists for L8 frames only");
     const int lane = threadIdx.x & 63;
     // u8 -> the pixel's four distinct tap products of the horizontal pass: entry v holds
     // (v/255)*w0 .. (v/255)*w3 (true division and the same multiplications the pass would do, once
@@ -512,10 +517,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((A4 &&
     // FAST: 8-bit luma (L8, RGB8) and W % 4 == 0.  RGB8 rows arrive as 3 dwords per lane and are
     // reduced to the packed luma dword of the image crate's integer formula when the group starts;
     // from there on the two formats share everything.
-    constexpr bool FAST = (FMT == 0 || FMT == 2) && A4;
+    constexpr bool FAST = ((FMT == 0 || FMT == 2) && A4) || UF;
     // BUF: W % 4 == 0, any format -- the rows of a group are fetched together through the buffer
     // resource one group ahead (L16 keeps its raw 2 dwords per row and converts row by row).
-    constexpr bool BUF = A4;
+    constexpr bool BUF = A4 || UF;
     constexpr int RW = FMT == 2 ? 3 : (FMT == 1 ? 2 : (FMT == 3 ? 4 : 1));  // input dwords per lane and row
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
@@ -523,7 +528,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((A4 &&
     RawPx<FMT> raw_a, raw_b, raw_c, raw_d;
     const int cc = c0 < 0 ? 0 : (c0 > W - 4 ? W - 4 : c0);  // FAST: clamped column of this lane's dword
     // byte selector of v_perm_b32: identity, or the first / last byte of the dword four times
-    const uint32_t edge_sel = c0 < 0 ? 0x00000000u : (c0 >= W ? 0x03030303u : 0x03020100u);
+    // (UF: W is any width >= 4 -- pixel j of the lane is column clamp(c0 + j, 0, W - 1), byte (that column - cc) of the dword at cc;
+    // the lane that straddles the right edge repeats the last pixel: e.g. W = 1282, c0 = 1280 -> dword at 1278, selector 0x03030302)
+    uint32_t edge_sel = c0 < 0 ? 0x00000000u : (c0 >= W ? 0x03030303u : 0x03020100u);
+    if (UF) {
+        edge_sel = 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int col = c0 + j;
+            col = col < 0 ? 0 : (col > W - 1 ? W - 1 : col);
+            edge_sel |= (uint32_t)(col - cc) << (8 * j);
+        }
+    }
     // A4 kernels address the frame and its blur plane through raw buffer resources: the base is
     // wave-uniform (SGPRs), the lane's column offset is one constant VGPR and the row offset an
     // SGPR, so a row's load / store costs no address arithmetic on the vector ALU.  Range rule
@@ -676,11 +692,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((A4 &&
             // that the number of memory operations per row is fixed and the compiler can wait
             // with a counted vmcnt(N) instead of draining the stores before every row
             if (store_ok) {
-                if (A4) {  // valid lanes hold 4 in-image pixels; rows outside the segment are dropped
+                if (A4 || UF) {  // valid lanes hold 4 in-image pixels (UF: the last one of a row may hold fewer); rows outside the segment are dropped
                     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                     const u32x4 v4 = __builtin_bit_cast(u32x4, bc);
                     const uint32_t row_off = (b >= ys && b < ye) ? (uint32_t)((a.dbg & 8) ? (b & 7) : b) * (uint32_t)W * 4u : blur_bytes;
-                    __builtin_amdgcn_raw_buffer_store_b128(v4, rs_blur, c0 * 4, (int)row_off, AGX_BLUR_STORE_AUX);
+                    if (A4 || c0 + 3 < W) {  // (UF: rows of the plane are only 4-byte aligned; a 16-byte store needs no more)
+                        __builtin_amdgcn_raw_buffer_store_b128(v4, rs_blur, c0 * 4, (int)row_off, AGX_BLUR_STORE_AUX);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 3; ++j)
+                            if (c0 + j < W) __builtin_amdgcn_raw_buffer_store_b32(v4[j], rs_blur, (c0 + j) * 4, (int)row_off, AGX_BLUR_STORE_AUX);
+                    }
                 } else {
                     float *dst = (b >= ys && b < ye) ? blur_f + (size_t)((a.dbg & 8) ? (b & 7) : b) * W + c0 : a.dummy + c0;
 #pragma unroll
@@ -2899,6 +2921,15 @@ static hipError_t launch_k1(const ChainArgs &a, hipStream_t st)
     // the aligned form addresses a frame and its blur plane with 32-bit buffer offsets
     const bool small = a.plane * 4 < (1ll << 31) && (long long)a.H * a.row_stride < (1ll << 31);
     const bool a4 = (a.W & 3) == 0 && small && !a.byte_rows;
+    // L8 frames that miss the aligned form only by their width or alignment: its loads and tap table on unaligned dwords (UF)
+    const bool uf = FMT == 0 && !a4 && small && a.W >= 4 && env_int("AGX_K1_UNALIGNED_FAST", 1) != 0;
+    if constexpr (FMT == 0) {
+        if (uf) {
+            if (a.resp_dbg) hipLaunchKernelGGL((k_blur_hessian<FMT, false, true, true>), grid, block, k1_lds, st, a);
+            else hipLaunchKernelGGL((k_blur_hessian<FMT, false, false, true>), grid, block, k1_lds, st, a);
+            return hipGetLastError();
+        }
+    }
     if (a.resp_dbg) {  // parity-test instantiation: also stores the response it evaluates
         if (a4) hipLaunchKernelGGL((k_blur_hessian<FMT, true, true>), grid, block, k1_lds, st, a);
         else hipLaunchKernelGGL((k_blur_hessian<FMT, false, true>), grid, block, k1_lds, st, a);

@@ -255,15 +255,23 @@ def recorded_traffic(key):
     return None, None
 
 
-def extra_leg(torch, A, dev, name, workload, n_frames, width, height, fmt, unique, noise, steps, warmup, verify_n):
+def extra_leg(torch, A, dev, name, workload, n_frames, width, height, fmt, unique, noise, steps, warmup, verify_n, pitch=None):
     """One extra configuration on its own detector, strictly serial: wall-clock value, per-step
-    median, K1 roofline from hipEvents in the timed region, oracle check of the first frames."""
+    median, K1 roofline from hipEvents in the timed region, oracle check of the first frames.
+    pitch (L8 only): bytes per row of the device allocation the frames are cut out of (padding after every row)."""
     frames, uniq = make_workload(0, n_frames, width, height, fmt, unique, noise, dev)
     det = A.TagDetector(A.TagFamily.T36H11, None, device=dev.index)
     px = n_frames * width * height
+    enqueue = lambda: det.saddles_batch_enqueue(frames)
+    if pitch is not None:
+        from aprilgrid_rs_amd import _ffi
+        assert fmt == "L8" and pitch >= width
+        padded = torch.full((n_frames, height, pitch), 0xA5, dtype=torch.uint8, device=dev)  # (the padding holds garbage)
+        padded[:, :, :width] = frames
+        enqueue = lambda: det.saddles_batch_enqueue_ptr(padded.data_ptr(), n_frames, width, height, pitch, pitch * height, _ffi.AGX_L8)
     try:
         for _ in range(max(warmup, 1) + 2):
-            det.saddles_batch_enqueue(frames)
+            enqueue()
         torch.cuda.synchronize(dev)
         det.set_option("profile_stride", 5 if steps >= 20 else 1)
         det.profile_enable(1)
@@ -273,7 +281,7 @@ def extra_leg(torch, A, dev, name, workload, n_frames, width, height, fmt, uniqu
         t0 = time.perf_counter()
         for i in range(steps):
             evs[i].record()
-            det.saddles_batch_enqueue(frames)
+            enqueue()
         evs[steps].record()
         torch.cuda.synchronize(dev)
         dt = time.perf_counter() - t0
@@ -816,6 +824,11 @@ def main():
                                          False, st, args.warmup, 64 * vf),
             "L16": extra_leg(torch, A, dev, "L16", "256 synthetic 1280x800 L16 frames (64 distinct, tiled)", 256, 1280, 800,
                              "L16", 64, False, st, args.warmup, 64 * vf),
+            # frames that miss K1's aligned form: a width that is not a multiple of 4, rows that are not 4-byte aligned
+            "unaligned_width": extra_leg(torch, A, dev, "1282 wide", "64 synthetic 1282x800 L8 frames, tightly packed (width % 4 = 2: rows start "
+                                         "at odd multiples of 2 bytes; K1's unaligned-dword form)", 64, 1282, 800, "L8", 64, False, st, args.warmup, 4 * vf),
+            "unaligned_pitch": extra_leg(torch, A, dev, "pitch 1283", "64 synthetic 1280x800 L8 frames cut out of an allocation with 1283 bytes "
+                                         "per row (odd pitch; K1's unaligned-dword form)", 64, 1280, 800, "L8", 64, False, st, args.warmup, 4 * vf, pitch=1283),
             "pure_noise": extra_leg(torch, A, dev, "noise", "sensitivity row: 64 pure-noise 1280x800 L8 frames (16 distinct, "
                                     "tiled; ~7000 saddles per frame: worst case for the sparse stages)", 64, 1280, 800, "L8",
                                     16, True, st, args.warmup, 4 * vf),

@@ -439,6 +439,44 @@ def test_unaligned_width_device_batches(det, oracle, fmt, width):
         check_saddles(res[i], ref, "%s width %d frame %d" % (fmt, width, i))
 
 
+@pytest.mark.parametrize("width,pitch", [(1282, 1282), (1281, 1283), (1280, 1281), (1283, 1284), (6, 7)])
+def test_unaligned_l8_frames_take_the_dword_form_with_the_same_results(oracle, monkeypatch, width, pitch):
+    """Round 5: L8 frames whose width is not a multiple of 4 or whose rows are not 4-byte aligned run K1 with the aligned form's
+    loads and tap table on unaligned dwords (template parameter UF) instead of gathering bytes.  Full-height frames at the
+    bench's size: every intermediate product against the oracle (blur plane, the response K1 evaluates in registers, minimum,
+    clusters, lists), and the byte-gathering form (AGX_K1_UNALIGNED_FAST=0) gives the same bytes."""
+    import torch
+    import aprilgrid_rs_amd as A
+    from aprilgrid_rs_amd import _ffi
+    synth = synth_module()
+    n, h = 3, 800 if width > 100 else 37
+    fr, _ = synth.render_batch(123, n, (max(width, 8) + 3) // 4 * 4, h, device="cuda")
+    tight = fr[:, :, :width].contiguous()
+    host = tight.cpu().numpy()
+    big = torch.full((n * h * pitch + 64,), 0x5A, dtype=torch.uint8, device="cuda")
+    big[: n * h * pitch].view(n, h, pitch)[:, :, :width] = tight
+    torch.cuda.synchronize()
+    got = {}
+    for form in ("1", "0"):
+        monkeypatch.setenv("AGX_K1_UNALIGNED_FAST", form)
+        d = A.TagDetector("t36h11", None, device=0)  # (reads the override)
+        try:
+            for store_resp in (0, 1):
+                d.set_option("store_response", store_resp)
+                d.saddles_batch_enqueue_ptr(big.data_ptr(), n, width, h, pitch, pitch * h, _ffi.AGX_L8)
+                res, status = d.saddles_batch_fetch()
+                assert (status == 0).all()
+                for i in range(n):
+                    ref = check_frame(d, oracle, host[i], i, "width %d pitch %d form %s frame %d" % (width, pitch, form, i))
+                    check_saddles(res[i], ref, "width %d pitch %d form %s frame %d" % (width, pitch, form, i))
+                got[(form, store_resp)] = [r.tobytes() for r in res]
+        finally:
+            d.close()
+    monkeypatch.delenv("AGX_K1_UNALIGNED_FAST")
+    A.TagDetector("t36h11", None, device=0).close()  # (the override is read at creation: gone again)
+    assert got[("1", 0)] == got[("0", 0)] == got[("1", 1)] == got[("0", 1)]
+
+
 @pytest.mark.parametrize("fmt,width,pad_bytes,gap_rows", [("L8", 300, 20, 3), ("L8", 301, 2, 0), ("L16", 250, 12, 1),
                                                           ("RGB8", 100, 4, 2), ("RGB8", 203, 7, 0), ("L8", 1280, 256, 5)])
 def test_padded_row_and_frame_strides_on_the_device(det, oracle, fmt, width, pad_bytes, gap_rows):
