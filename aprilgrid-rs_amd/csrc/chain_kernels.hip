@@ -317,14 +317,16 @@ __device__ __forceinline__ int H_full_segs(const ChainArgs &a) { return a.H / a.
 #ifndef AGX_IN_LOAD_AUX
 #define AGX_IN_LOAD_AUX 0  // cache policy bits of the frame's buffer loads
 #endif
-// UF (round 5; L8 only, with A4 false): frames whose width is not a multiple of 4 or whose rows / base are not 4-byte aligned
-// keep the aligned form's loads and tap table -- one (unaligned) dword per lane and row through the buffer resource, the lane's
-// four pixels picked out of it by a per-lane byte selector that also replicates the edge pixel (clamp-to-edge) -- instead of
-// gathering bytes row by row: the generic form ran 3.4 - 4.8 x slower per pixel than the aligned one (profiles/r5_k1_unaligned_*).
+// UF (round 5; with A4 false): frames whose width is not a multiple of 4 or whose rows / base are not 4-byte aligned keep the
+// aligned form's loads and tap table -- one (unaligned) 4 / 8 / 12 / 16-byte load per lane and row through the buffer resource
+// (gfx9 in the HSA runtime's unaligned access mode), the lane's four pixels picked out of it by per-lane selectors that also
+// replicate the edge pixel (clamp-to-edge) -- instead of gathering bytes row by row: the generic form ran 3.4 - 4.8 x slower per
+// pixel than the aligned one (profiles/r5_k1_unaligned_*).  The generic form remains for widths below 4 and frames beyond the
+// 32-bit buffer offsets.
 template <int FMT, bool A4, bool RESP = false, bool UF = false>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(((A4 || UF) && !RESP && AGX_K1_WPE) ? ((FMT == 0 || FMT == 1) ? (AGX_K1_WPE_MAX < 5 ? AGX_K1_WPE_MAX : 5) : 4) : 1, AGX_K1_WPE_MAX))) k_blur_hessian(ChainArgs a)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(((A4 || UF) && !RESP && AGX_K1_WPE) ? ((FMT == 0 || (FMT == 1 && !UF)) ? (AGX_K1_WPE_MAX < 5 ? AGX_K1_WPE_MAX : 5) : 4) : 1, AGX_K1_WPE_MAX))) k_blur_hessian(ChainArgs a)
 {
-    static_assert(!UF || (FMT == 0 && !A4), "the unaligned fast form exists for L8 frames only");
+    static_assert(!UF || !A4, "UF is the aligned form's data path for frames that are not aligned");
     const int lane = threadIdx.x & 63;
     // u8 -> the pixel's four distinct tap products of the horizontal pass: entry v holds
     // (v/255)*w0 .. (v/255)*w3 (true division and the same multiplications the pass would do, once
@@ -517,7 +519,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(((A4 |
     // FAST: 8-bit luma (L8, RGB8) and W % 4 == 0.  RGB8 rows arrive as 3 dwords per lane and are
     // reduced to the packed luma dword of the image crate's integer formula when the group starts;
     // from there on the two formats share everything.
-    constexpr bool FAST = ((FMT == 0 || FMT == 2) && A4) || UF;
+    constexpr bool FAST = (FMT == 0 || FMT == 2) && (A4 || UF);
     // BUF: W % 4 == 0, any format -- the rows of a group are fetched together through the buffer
     // resource one group ahead (L16 keeps its raw 2 dwords per row and converts row by row).
     constexpr bool BUF = A4 || UF;
@@ -531,12 +533,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(((A4 |
     // (UF: W is any width >= 4 -- pixel j of the lane is column clamp(c0 + j, 0, W - 1), byte (that column - cc) of the dword at cc;
     // the lane that straddles the right edge repeats the last pixel: e.g. W = 1282, c0 = 1280 -> dword at 1278, selector 0x03030302)
     uint32_t edge_sel = c0 < 0 ? 0x00000000u : (c0 >= W ? 0x03030303u : 0x03020100u);
+    int src_px[4] = {0, 1, 2, 3};  // UF: which of the four loaded pixels (columns cc .. cc + 3) the lane's pixel j is
     if (UF) {
         edge_sel = 0u;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             int col = c0 + j;
             col = col < 0 ? 0 : (col > W - 1 ? W - 1 : col);
+            src_px[j] = col - cc;
             edge_sel |= (uint32_t)(col - cc) << (8 * j);
         }
     }
@@ -573,8 +577,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(((A4 |
     };
     // L16 edge lanes: 16-bit selectors of v_perm_b32 over (dword1:dword0) -- identity, or the first /
     // last pixel of the 8 bytes in both halves
-    const uint32_t sel16_lo = c0 < 0 ? 0x01000100u : (c0 >= W ? 0x07060706u : 0x03020100u);
-    const uint32_t sel16_hi = c0 < 0 ? 0x01000100u : (c0 >= W ? 0x07060706u : 0x07060504u);
+    uint32_t sel16_lo = c0 < 0 ? 0x01000100u : (c0 >= W ? 0x07060706u : 0x03020100u);
+    uint32_t sel16_hi = c0 < 0 ? 0x01000100u : (c0 >= W ? 0x07060706u : 0x07060504u);
+    if (UF) {  // pixel j = halfword src_px[j] of the eight bytes
+        sel16_lo = (uint32_t)(2 * src_px[0]) | ((uint32_t)(2 * src_px[0] + 1) << 8) | ((uint32_t)(2 * src_px[1]) << 16) | ((uint32_t)(2 * src_px[1] + 1) << 24);
+        sel16_hi = (uint32_t)(2 * src_px[2]) | ((uint32_t)(2 * src_px[2] + 1) << 8) | ((uint32_t)(2 * src_px[3]) << 16) | ((uint32_t)(2 * src_px[3] + 1) << 24);
+    }
     if (BUF) {
 #pragma unroll
         for (int k = 0; k < 7; ++k) issue_load(r0 + k, ring[k]);
@@ -623,7 +631,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(((A4 |
             } else if (BUF && FMT == 3) {  // LF32, aligned: lanes left / right of the image replicate the edge pixel
                 const uint32_t first = got[k][0], last = got[k][RW > 3 ? 3 : 0];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) m[j] = __uint_as_float(c0 < 0 ? first : (c0 >= W ? last : got[k][RW > j ? j : 0]));
+                for (int j = 0; j < 4; ++j) {
+                    if (UF) {
+                        const int q = src_px[j];
+                        m[j] = __uint_as_float(q == 0 ? got[k][0] : (q == 1 ? got[k][RW > 1 ? 1 : 0] : (q == 2 ? got[k][RW > 2 ? 2 : 0] : got[k][RW > 3 ? 3 : 0])));
+                    } else {
+                        m[j] = __uint_as_float(c0 < 0 ? first : (c0 >= W ? last : got[k][RW > j ? j : 0]));
+                    }
+                }
             } else if (BUF) {  // L16, aligned: 4 x u16 in two dwords, edge lanes replicate by permute
                 const uint32_t d0 = got[k][0], d1 = got[k][RW > 1 ? 1 : 0];
                 const uint32_t e0 = __builtin_amdgcn_perm(d1, d0, sel16_lo), e1 = __builtin_amdgcn_perm(d1, d0, sel16_hi);
@@ -2922,13 +2937,11 @@ static hipError_t launch_k1(const ChainArgs &a, hipStream_t st)
     const bool small = a.plane * 4 < (1ll << 31) && (long long)a.H * a.row_stride < (1ll << 31);
     const bool a4 = (a.W & 3) == 0 && small && !a.byte_rows;
     // L8 frames that miss the aligned form only by their width or alignment: its loads and tap table on unaligned dwords (UF)
-    const bool uf = FMT == 0 && !a4 && small && a.W >= 4 && env_int("AGX_K1_UNALIGNED_FAST", 1) != 0;
-    if constexpr (FMT == 0) {
-        if (uf) {
-            if (a.resp_dbg) hipLaunchKernelGGL((k_blur_hessian<FMT, false, true, true>), grid, block, k1_lds, st, a);
-            else hipLaunchKernelGGL((k_blur_hessian<FMT, false, false, true>), grid, block, k1_lds, st, a);
-            return hipGetLastError();
-        }
+    const bool uf = !a4 && small && a.W >= 4 && env_int("AGX_K1_UNALIGNED_FAST", 1) != 0;
+    if (uf) {
+        if (a.resp_dbg) hipLaunchKernelGGL((k_blur_hessian<FMT, false, true, true>), grid, block, k1_lds, st, a);
+        else hipLaunchKernelGGL((k_blur_hessian<FMT, false, false, true>), grid, block, k1_lds, st, a);
+        return hipGetLastError();
     }
     if (a.resp_dbg) {  // parity-test instantiation: also stores the response it evaluates
         if (a4) hipLaunchKernelGGL((k_blur_hessian<FMT, true, true>), grid, block, k1_lds, st, a);

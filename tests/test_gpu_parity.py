@@ -439,23 +439,32 @@ def test_unaligned_width_device_batches(det, oracle, fmt, width):
         check_saddles(res[i], ref, "%s width %d frame %d" % (fmt, width, i))
 
 
-@pytest.mark.parametrize("width,pitch", [(1282, 1282), (1281, 1283), (1280, 1281), (1283, 1284), (6, 7)])
-def test_unaligned_l8_frames_take_the_dword_form_with_the_same_results(oracle, monkeypatch, width, pitch):
-    """Round 5: L8 frames whose width is not a multiple of 4 or whose rows are not 4-byte aligned run K1 with the aligned form's
-    loads and tap table on unaligned dwords (template parameter UF) instead of gathering bytes.  Full-height frames at the
-    bench's size: every intermediate product against the oracle (blur plane, the response K1 evaluates in registers, minimum,
-    clusters, lists), and the byte-gathering form (AGX_K1_UNALIGNED_FAST=0) gives the same bytes."""
+@pytest.mark.parametrize("fmt,width,pad", [("L8", 1282, 0), ("L8", 1281, 2), ("L8", 1280, 1), ("L8", 1283, 1), ("L8", 6, 1), ("L16", 1282, 0),
+                                            ("L16", 1281, 2), ("L16", 1280, 2), ("RGB8", 1282, 0), ("RGB8", 1281, 1), ("RGB8", 1280, 3), ("L16", 5, 0),
+                                            ("RGB8", 7, 2)])
+def test_unaligned_frames_take_the_dword_form_with_the_same_results(oracle, monkeypatch, fmt, width, pad):
+    """Round 5: frames whose width is not a multiple of 4 or whose rows are not 4-byte aligned run K1 with the aligned form's
+    loads and tap table on unaligned 4 / 8 / 12-byte loads (template parameter UF) instead of gathering bytes.  Full-height
+    frames at the bench's size (pad = extra bytes after every row): every intermediate product against the oracle (blur plane,
+    the response K1 evaluates in registers, minimum, clusters, lists), and the byte-gathering form (AGX_K1_UNALIGNED_FAST=0)
+    gives the same bytes."""
     import torch
     import aprilgrid_rs_amd as A
     from aprilgrid_rs_amd import _ffi
     synth = synth_module()
     n, h = 3, 800 if width > 100 else 37
-    fr, _ = synth.render_batch(123, n, (max(width, 8) + 3) // 4 * 4, h, device="cuda")
+    fr, _ = synth.render_batch(123, n, (max(width, 8) + 3) // 4 * 4, h, device="cuda", fmt=fmt)
     tight = fr[:, :, :width].contiguous()
     host = tight.cpu().numpy()
+    if fmt == "L16":
+        host = host.view(np.uint16)
+    bpp = {"L8": 1, "L16": 2, "RGB8": 3}[fmt]
+    row_bytes = width * bpp
+    pitch = row_bytes + pad
     big = torch.full((n * h * pitch + 64,), 0x5A, dtype=torch.uint8, device="cuda")
-    big[: n * h * pitch].view(n, h, pitch)[:, :, :width] = tight
+    big[: n * h * pitch].view(n, h, pitch)[:, :, :row_bytes] = tight.view(torch.uint8).reshape(n, h, row_bytes)
     torch.cuda.synchronize()
+    code = {"L8": _ffi.AGX_L8, "L16": _ffi.AGX_L16, "RGB8": _ffi.AGX_RGB8}[fmt]
     got = {}
     for form in ("1", "0"):
         monkeypatch.setenv("AGX_K1_UNALIGNED_FAST", form)
@@ -463,12 +472,12 @@ def test_unaligned_l8_frames_take_the_dword_form_with_the_same_results(oracle, m
         try:
             for store_resp in (0, 1):
                 d.set_option("store_response", store_resp)
-                d.saddles_batch_enqueue_ptr(big.data_ptr(), n, width, h, pitch, pitch * h, _ffi.AGX_L8)
+                d.saddles_batch_enqueue_ptr(big.data_ptr(), n, width, h, pitch, pitch * h, code)
                 res, status = d.saddles_batch_fetch()
                 assert (status == 0).all()
                 for i in range(n):
-                    ref = check_frame(d, oracle, host[i], i, "width %d pitch %d form %s frame %d" % (width, pitch, form, i))
-                    check_saddles(res[i], ref, "width %d pitch %d form %s frame %d" % (width, pitch, form, i))
+                    ref = check_frame(d, oracle, host[i], i, "%s width %d pitch %d form %s frame %d" % (fmt, width, pitch, form, i))
+                    check_saddles(res[i], ref, "%s width %d pitch %d form %s frame %d" % (fmt, width, pitch, form, i))
                 got[(form, store_resp)] = [r.tobytes() for r in res]
         finally:
             d.close()
