@@ -1,6 +1,6 @@
 """Per-kernel times of the chain for a list of tuning environments, alternating in ONE process (6 rounds, the order
 reversed every other round).  usage: python tools/env_sweep.py ['{"AGX_G_FLOOD": "20"}' '{}' ...]   (each argument one
-environment as JSON; default: today's defaults against the settings they replaced; env WIDTH, HEIGHT, FRAMES, UNIQUE, FORMAT)"""
+environment as JSON; default: today's defaults against the settings they replaced; env WIDTH, HEIGHT, FRAMES, UNIQUE, FORMAT, NOISE)"""
 import json, os, sys, time, statistics
 sys.path.insert(0, ".")
 import torch
@@ -8,7 +8,7 @@ import aprilgrid_rs_amd as A
 from aprilgrid_rs_amd import synth
 W_, H_, F_ = int(os.environ.get("WIDTH", "1280")), int(os.environ.get("HEIGHT", "800")), int(os.environ.get("FRAMES", "256"))
 U_ = int(os.environ.get("UNIQUE", str(F_)))
-base, _ = synth.render_batch(0, U_, W_, H_, device="cuda", fmt=os.environ.get("FORMAT", "L8"))
+base, _ = synth.render_batch(0, U_, W_, H_, device="cuda", fmt=os.environ.get("FORMAT", "L8"), pure_noise=os.environ.get("NOISE", "0") == "1")
 frames = base.repeat((F_ // U_ + 1,) + (1,) * (base.dim() - 1))[:F_].contiguous()
 det = A.TagDetector("t36h11")
 def run(env):
