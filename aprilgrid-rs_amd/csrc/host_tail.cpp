@@ -226,7 +226,10 @@ public:
         ox_ = x0;
         oy_ = y0;
         const double w = std::max(1e-3, (double)x1 - x0), h = std::max(1e-3, (double)y1 - y0);
-        cell_ = std::max(1.0, std::sqrt(w * h / std::max(1, n)) * 1.5);  // ~2 points per cell
+#ifndef AGX_TAIL_CELL_FACTOR
+#define AGX_TAIL_CELL_FACTOR 1.0
+#endif
+        cell_ = std::max(1.0, std::sqrt(w * h / std::max(1, n)) * AGX_TAIL_CELL_FACTOR);  // ~1 point per cell: a 3-NN query settles on its first 3 x 3 block of ~9 points (1.5: ~20 points; 674 -> 769 tails per second and thread, profiles/r5_host_tail_speed.txt)
         nx_ = std::max(1, (int)std::floor(w / cell_) + 1);
         ny_ = std::max(1, (int)std::floor(h / cell_) + 1);
         start_.assign((size_t)nx_ * ny_ + 1, 0);
@@ -239,6 +242,13 @@ public:
         items_.resize((size_t)n);
         fill_.assign(start_.begin(), start_.end() - 1);
         for (int i = 0; i < n; ++i) items_[fill_[cell_of_[i]]++] = i;  // ascending index inside a cell
+        // the coordinates again in cell order: a row of cells is one contiguous run of floats (nearest_within)
+        px_.resize((size_t)n);
+        py_.resize((size_t)n);
+        for (int t = 0; t < n; ++t) {
+            px_[t] = pts[items_[t]].x;
+            py_[t] = pts[items_[t]].y;
+        }
     }
 
     // k nearest, ascending; returns how many were found (min(k, n))
@@ -391,39 +401,40 @@ public:
     }
 
 private:
-    // nearest() for want <= 3 without the candidate vector and its sorts: the same blocks of cells are
-    // examined in the same order under the same stopping rule, the best `want` hits are kept in order
-    // (ascending distance, ties by index) while scanning -- the result is the one partial_sort gives.
+    // nearest() for want <= 3 without the candidate vector and its sorts: blocks of cells around the query are
+    // examined under the same stopping rule, the best `want` hits are kept in order (ascending distance, ties by
+    // index: a total order, so the result does not depend on the order of examination) while scanning -- the
+    // result is the one partial_sort gives.
     // max_d2 >= 0: the caller keeps only hits with d2 <= max_d2 (find_closest_potential_saddle_idxs,
     // board.rs:207-213), so the search also stops once everything unexamined lies beyond that radius --
     // the hits within the radius, and their order, are the same as those of the unbounded search.
     int nearest_small(float qx, float qy, int want, Hit *out, float max_d2 = -1.0f)
     {
-        const std::vector<agx_saddle> &pts_ = *pts_p_;
         Hit best[3];
         int nb = 0;
         long seen = 0;
+        // a block of cells row by row: the cells xa .. xb of a row are one contiguous run of coordinates (px_ / py_ in cell order)
         auto scan_small = [&](int xa, int xb, int ya, int yb) {
-            for (int y = ya; y <= yb; ++y)
-                for (int x = xa; x <= xb; ++x) {
-                    const size_t c = (size_t)y * nx_ + x;
-                    for (int t = start_[c]; t < start_[c + 1]; ++t) {
-                        const int i = items_[t];
-                        const float dx = qx - pts_[i].x, dy = qy - pts_[i].y;
-                        const Hit h{(0.0f + dx * dx) + dy * dy, i};
-                        ++seen;
-                        if (nb == want && !(h < best[nb - 1])) continue;
-                        int p = nb < want ? nb++ : nb - 1;  // slot that falls off / is appended
-                        while (p > 0 && h < best[p - 1]) {
-                            best[p] = best[p - 1];
-                            --p;
-                        }
-                        best[p] = h;
+            for (int y = ya; y <= yb; ++y) {
+                const int t1 = start_[(size_t)y * nx_ + xb + 1];
+                for (int t = start_[(size_t)y * nx_ + xa]; t < t1; ++t) {
+                    const float dx = qx - px_[t], dy = qy - py_[t];
+                    const Hit h{(0.0f + dx * dx) + dy * dy, items_[t]};
+                    ++seen;
+                    if (nb == want && !(h < best[nb - 1])) continue;
+                    int p = nb < want ? nb++ : nb - 1;  // slot that falls off / is appended
+                    while (p > 0 && h < best[p - 1]) {
+                        best[p] = best[p - 1];
+                        --p;
                     }
+                    best[p] = h;
                 }
+            }
         };
+        // the first block is the query's cell with its eight neighbours at once (a cell holds ~2 points: the single cell
+        // almost never settles a 3-NN query); the stopping rules below hold for any examined block
         const int cx = cell_x(qx), cy = cell_y(qy);
-        int xlo = cx, xhi = cx, ylo = cy, yhi = cy;  // examined block of cells (inclusive)
+        int xlo = std::max(0, cx - 1), xhi = std::min(nx_ - 1, cx + 1), ylo = std::max(0, cy - 1), yhi = std::min(ny_ - 1, cy + 1);
         scan_small(xlo, xhi, ylo, yhi);
         for (;;) {
             const bool all = xlo == 0 && ylo == 0 && xhi == nx_ - 1 && yhi == ny_ - 1;
@@ -450,8 +461,11 @@ private:
         return nb;
     }
 
-    int cell_x(float x) const { return std::min(nx_ - 1, std::max(0, (int)std::floor(((double)x - ox_) / cell_))); }
-    int cell_y(float y) const { return std::min(ny_ - 1, std::max(0, (int)std::floor(((double)y - oy_) / cell_))); }
+    // floor(t) clamped to [0, n - 1] without a call into libm (the baseline x86-64 target has no rounding instruction):
+    // truncation is floor for t > 0, anything else (NaN included) is cell 0, and the clamp comes before the conversion
+    static int clamped_cell(double t, int n) { return !(t > 0.0) ? 0 : (t >= (double)n ? n - 1 : (int)t); }
+    int cell_x(float x) const { return clamped_cell(((double)x - ox_) / cell_, nx_); }
+    int cell_y(float y) const { return clamped_cell(((double)y - oy_) / cell_, ny_); }
     void scan(int xa, int xb, int ya, int yb, float qx, float qy)
     {
         const std::vector<agx_saddle> &pts_ = *pts_p_;
@@ -491,6 +505,7 @@ private:
     double ox_ = 0, oy_ = 0, cell_ = 1;
     int nx_ = 1, ny_ = 1;
     std::vector<int> start_, items_, cell_of_, fill_;
+    std::vector<float> px_, py_;  // pts_[items_[t]].x / .y
     std::vector<uint32_t> pair_touched_, quad_touched_;  // occupied slots of the two tables
     std::vector<Hit> cand_;
     std::vector<PairCands> pair_tab_;
@@ -733,18 +748,21 @@ void init_quads(const std::vector<agx_saddle> &refined, SaddleIndex &index, int 
         v0x[d] = p.x - s0.x; v0y[d] = p.y - s0.y;
         v30x[d] = s0.x - p.x; v30y[d] = s0.y - p.y;
     }
-    // the (d0, d1) combinations that pass part 0, in the reference's order (a < b, a ascending, then b):
-    // the loops over s1 below walk this list instead of all nd * (nd - 1) / 2 pairs
-    uint8_t pa[50 * 49 / 2], pb[50 * 49 / 2];
+    // the (d0, d1) combinations that pass part 0 as one bit row per a (bit b > a set: the pair is a candidate), and their
+    // running number in the reference's order (a ascending, then b): base[a] + the bits of row a below b.  The loops over s1
+    // below visit only the pairs whose two saddles also lie on s1's side of s0 (a second bit row per s1), in that same order.
+    uint64_t p0[50];
+    int base[51];
     static thread_local std::vector<LazyAngle> a3_store;  // a3 = angle(v30, v01) per listed pair, on demand
     int n_pairs = 0;
-    for (int a = 0; a < nd; ++a)
+    for (int a = 0; a < nd; ++a) {
+        uint64_t row = 0;
         for (int b = a + 1; b < nd; ++b)
-            if (quad_part0(refined[diff[a]], refined[diff[b]])) {
-                pa[n_pairs] = (uint8_t)a;
-                pb[n_pairs] = (uint8_t)b;
-                ++n_pairs;
-            }
+            if (quad_part0(refined[diff[a]], refined[diff[b]])) row |= 1ull << b;
+        p0[a] = row;
+        base[a] = n_pairs;
+        n_pairs += __builtin_popcountll(row);
+    }
     if (!n_pairs) return;
     a3_store.assign((size_t)n_pairs, LazyAngle());
     LazyAngle *a3v = a3_store.data();
@@ -757,30 +775,35 @@ void init_quads(const std::vector<agx_saddle> &refined, SaddleIndex &index, int 
         const float v02x = s1.x - s0.x, v02y = s1.y - s0.y;
         float cA[50], cB[50], c01[50], v12x[50], v12y[50], v23x[50], v23y[50];
         LazyAngle a0v[50], a2v[50];
-        uint8_t dok[50];
+        uint64_t ok = 0;  // bit d: dot(v0d, v02) >= 0 (saddle.rs:62-64), needed of both d0 and d1
         for (int d = 0; d < nd; ++d) {
             const agx_saddle &p = refined[diff[d]];
             cA[d] = cross2(v0x[d], v0y[d], v02x, v02y);   // c0 with d as d0 (also the winding test)
             cB[d] = cross2(v02x, v02y, v0x[d], v0y[d]);   // c1 with d as d1
-            dok[d] = !(dot2(v0x[d], v0y[d], v02x, v02y) < 0.0f);
+            if (!(dot2(v0x[d], v0y[d], v02x, v02y) < 0.0f)) ok |= 1ull << d;
             v12x[d] = s1.x - p.x; v12y[d] = s1.y - p.y;   // d as d0
             v23x[d] = p.x - s1.x; v23y[d] = p.y - s1.y;   // d as d1
             c01[d] = cross2(v0x[d], v0y[d], v12x[d], v12y[d]);
         }
-        for (int pi = 0; pi < n_pairs; ++pi) {
-            const int a = pa[pi], b = pb[pi];
-            if (!dok[a] || !dok[b]) continue;
-            if (cA[a] * cB[b] < 0.0f) continue;
-            if (c01[a] * cross2(v12x[a], v12y[a], v23x[b], v23y[b]) < 0.0f) continue;
-            if (!a0v[a].is_set) a0v[a].set(v0x[a], v0y[a], v12x[a], v12y[a]);
-            if (!a2v[b].is_set) a2v[b].set(v23x[b], v23y[b], v30x[b], v30y[b]);
-            if (angles_differ_by_more_than(a0v[a], a2v[b], 10.0f)) continue;
-            if (!a3v[pi].is_set) a3v[pi].set(v30x[b], v30y[b], v0x[a], v0y[a]);
-            LazyAngle a1;
-            a1.set(v12x[a], v12y[a], v23x[b], v23y[b]);
-            if (angles_differ_by_more_than(a1, a3v[pi], 10.0f)) continue;
-            if (cA[a] > 0.0f) out.push_back({s0_idx, diff[a], s1_idx, diff[b]});
-            else out.push_back({s0_idx, diff[b], s1_idx, diff[a]});
+        for (uint64_t as = ok; as;) {
+            const int a = __builtin_ctzll(as);
+            as &= as - 1;
+            for (uint64_t bs = p0[a] & ok; bs;) {
+                const int b = __builtin_ctzll(bs);
+                bs &= bs - 1;
+                if (cA[a] * cB[b] < 0.0f) continue;
+                if (c01[a] * cross2(v12x[a], v12y[a], v23x[b], v23y[b]) < 0.0f) continue;
+                if (!a0v[a].is_set) a0v[a].set(v0x[a], v0y[a], v12x[a], v12y[a]);
+                if (!a2v[b].is_set) a2v[b].set(v23x[b], v23y[b], v30x[b], v30y[b]);
+                if (angles_differ_by_more_than(a0v[a], a2v[b], 10.0f)) continue;
+                const int pi = base[a] + __builtin_popcountll(p0[a] & ((1ull << b) - 1ull));
+                if (!a3v[pi].is_set) a3v[pi].set(v30x[b], v30y[b], v0x[a], v0y[a]);
+                LazyAngle a1;
+                a1.set(v12x[a], v12y[a], v23x[b], v23y[b]);
+                if (angles_differ_by_more_than(a1, a3v[pi], 10.0f)) continue;
+                if (cA[a] > 0.0f) out.push_back({s0_idx, diff[a], s1_idx, diff[b]});
+                else out.push_back({s0_idx, diff[b], s1_idx, diff[a]});
+            }
         }
     }
 }
@@ -993,13 +1016,18 @@ uint64_t rotate_bits(uint64_t bits, int edge_bits)
     return out;
 }
 
-bool best_tag(uint64_t bits, int thres, const uint64_t *codes, int n_codes, int edge_bits, int &idx, int &rot)
+// best_tag, src/detector.rs:142-169: up to four rotations x every code of the family (587 for T36H11), one XOR + population
+// count each.  The library is built for baseline x86-64, which has no POPCNT instruction (the builtin becomes ~15 instructions
+// of bit arithmetic); the same loop compiled for POPCNT is taken where the CPU has it -- every x86-64 since 2008 -- : the decode
+// of a quad 2.9 -> 1.9 us, 5 % of the host tail.  Same result either way.
+template <typename Popcount>
+static inline bool best_tag_impl(uint64_t bits, int thres, const uint64_t *codes, int n_codes, int edge_bits, int &idx, int &rot, Popcount pop)
 {
     for (int rotated = 0; rotated < 4; ++rotated) {
         int best = 0;
-        unsigned best_score = (unsigned)__builtin_popcountll(codes[0] ^ bits);
+        unsigned best_score = pop(codes[0] ^ bits);
         for (int i = 1; i < n_codes; ++i) {
-            const unsigned s = (unsigned)__builtin_popcountll(codes[i] ^ bits);
+            const unsigned s = pop(codes[i] ^ bits);
             if (s < best_score) {
                 best_score = s;
                 best = i;
@@ -1014,6 +1042,21 @@ bool best_tag(uint64_t bits, int thres, const uint64_t *codes, int n_codes, int 
         bits = rotate_bits(bits, edge_bits);
     }
     return false;
+}
+#if defined(__x86_64__)
+__attribute__((target("popcnt"))) static bool best_tag_popcnt(uint64_t bits, int thres, const uint64_t *codes, int n_codes, int edge_bits,
+                                                              int &idx, int &rot)
+{
+    return best_tag_impl(bits, thres, codes, n_codes, edge_bits, idx, rot, [](uint64_t v) __attribute__((target("popcnt"))) { return (unsigned)__builtin_popcountll(v); });
+}
+#endif
+bool best_tag(uint64_t bits, int thres, const uint64_t *codes, int n_codes, int edge_bits, int &idx, int &rot)
+{
+#if defined(__x86_64__)
+    static const bool has_popcnt = __builtin_cpu_supports("popcnt") != 0;
+    if (has_popcnt) return best_tag_popcnt(bits, thres, codes, n_codes, edge_bits, idx, rot);
+#endif
+    return best_tag_impl(bits, thres, codes, n_codes, edge_bits, idx, rot, [](uint64_t v) { return (unsigned)__builtin_popcountll(v); });
 }
 
 namespace {
