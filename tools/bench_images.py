@@ -159,11 +159,14 @@ def blur_table(det, cpu, runs, names=BLUR):
     return out
 
 
-def detect_batch_table(det, thread_counts=(1, 8, 32, 64)):
+def detect_batch_table(det, thread_counts=None):
     """End-to-end detect() over a batch (agx_detect_batch): chain per chunk on the device, board search +
     decode on a pool of host threads -- frames per second by thread count (the host tail is the
     reference's exhaustive search: this rate is set by the host, never the bench's `value`)."""
-    from aprilgrid_rs_amd import synth
+    from aprilgrid_rs_amd import synth, _ffi
+    if thread_counts is None:  # up to what the process may keep busy (affinity mask or cgroup CPU quota: 16 on a 1-GPU box of this pool)
+        quota = int(_ffi.lib().agx_host_parallelism())
+        thread_counts = sorted(set(t for t in (1, 8, 16, 32, 64) if t < quota) | {quota})
     fr, _ = synth.render_batch(0, 256, 1280, 800, device="cuda")
     host = fr.cpu().numpy()
     out = {}
