@@ -1120,6 +1120,15 @@ int agx_debug_angle_pairs(const float *vectors, size_t n, float *exact, float *a
     });
 }
 
+int agx_debug_angle_pairs_coarse(const float *vectors, size_t n, float *coarse, uint8_t *has_coarse)
+{
+    return agx_guard(nullptr, [&]() -> int {
+    if (!vectors || !coarse || !has_coarse) return AGX_ERR_ARG;
+    debug_angle_pairs(vectors, n, nullptr, nullptr, nullptr, coarse, has_coarse);
+    return AGX_OK;
+    });
+}
+
 int agx_luma8(const void *pixels, int width, int height, size_t row_stride_bytes, int format, uint8_t *out)
 {
     return agx_guard(nullptr, [&]() -> int {

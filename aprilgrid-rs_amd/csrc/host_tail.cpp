@@ -77,28 +77,57 @@ float angle_degree(float v0x, float v0y, float v1x, float v1y)
 //   angle_degree| < 2e-4 degrees.  kAngleBand is 25 times that; agx_debug_angle_pair + the CPU suite
 //   check the bound on millions of inputs.
 constexpr float kAngleBand = 0.005f;
+// Round 5: a coarser first level in front of it.  The search evaluates ~16 000 of these angles per frame and nearly all
+// comparisons are degrees away from their threshold, so most are decided from a three-term odd polynomial in float (max error
+// 0.035 degrees against the true angle, tools/fit_atan.py; + 1e-4 of angle_degree's own rounding: < 0.04 degrees from
+// angle_degree).  kCoarseBand is 2.5 times that.  Inside the coarse band the fine approximation above decides, inside its band
+// the reference's expression -- the decisions are exactly the reference's at every level.
+constexpr float kCoarseBand = 0.1f;
 struct LazyAngle {
     float ax, ay, bx, by;  // angle_degree(ax, ay, bx, by)
-    float approx = 0.0f, exact_v = 0.0f;
-    uint8_t has_approx = 0, has_exact = 0, is_set = 0;
+    float yf, xf;          // what angle_degree hands to atan2f
+    float coarse = 0.0f, approx = 0.0f, exact_v = 0.0f;
+    uint8_t has_coarse = 0, has_approx = 0, fine_done = 0, has_exact = 0, is_set = 0;
     void set(float v0x, float v0y, float v1x, float v1y)
     {
         ax = v0x; ay = v0y; bx = v1x; by = v1y;
         is_set = 1;
         has_exact = 0;
-        const float yf = v1y * v0x - v1x * v0y, xf = v0x * v1x + v0y * v1y;  // what angle_degree hands to atan2f
-        const double ya = std::fabs((double)yf), xa = std::fabs((double)xf);
-        const double mx = xa > ya ? xa : ya, mn = xa > ya ? ya : xa;
+        fine_done = 0;
+        has_approx = 0;
+        yf = v1y * v0x - v1x * v0y;
+        xf = v0x * v1x + v0y * v1y;
+        const float ya = std::fabs(yf), xa = std::fabs(xf);
+        const float mx = xa > ya ? xa : ya, mn = xa > ya ? ya : xa;
         // zero, infinite or NaN operands and the sign-of-zero cases of atan2: the exact expression only
-        has_approx = (mx > 0.0 && mx < 1e300 && yf != 0.0f) ? 1 : 0;
-        if (!has_approx) return;
-        const double z = mn / mx, z2 = z * z;
-        double a = z * (0.9999961115936159 + z2 * (-0.3331736811416821 + z2 * (0.19807815786497726 + z2 * (-0.13233342317278815 +
-                   z2 * (0.07962366987276416 + z2 * (-0.03360421491419842 + z2 * 0.006811790682567682))))));
-        if (ya > xa) a = 1.5707963267948966 - a;
-        if (xf < 0.0f) a = 3.141592653589793 - a;
+        has_coarse = (mx > 0.0f && mx < 3.0e38f && yf != 0.0f) ? 1 : 0;
+        if (!has_coarse) return;
+        const float z = mn / mx, z2 = z * z;
+        float a = z * (0.9953585f + z2 * (-0.2886936f + z2 * 0.07934251f));
+        if (ya > xa) a = 1.5707964f - a;
+        if (xf < 0.0f) a = 3.1415927f - a;
         if (yf < 0.0f) a = -a;
-        approx = (float)(a * 57.29577951308232);
+        coarse = a * 57.29578f;
+    }
+    // the fine approximation (binary64 polynomial, one rounding); false where it is not used
+    bool fine()
+    {
+        if (!fine_done) {
+            fine_done = 1;
+            const double ya = std::fabs((double)yf), xa = std::fabs((double)xf);
+            const double mx = xa > ya ? xa : ya, mn = xa > ya ? ya : xa;
+            has_approx = (mx > 0.0 && mx < 1e300 && yf != 0.0f) ? 1 : 0;
+            if (has_approx) {
+                const double z = mn / mx, z2 = z * z;
+                double a = z * (0.9999961115936159 + z2 * (-0.3331736811416821 + z2 * (0.19807815786497726 + z2 * (-0.13233342317278815 +
+                           z2 * (0.07962366987276416 + z2 * (-0.03360421491419842 + z2 * 0.006811790682567682))))));
+                if (ya > xa) a = 1.5707963267948966 - a;
+                if (xf < 0.0f) a = 3.141592653589793 - a;
+                if (yf < 0.0f) a = -a;
+                approx = (float)(a * 57.29577951308232);
+            }
+        }
+        return has_approx != 0;
     }
     float exact()
     {
@@ -112,7 +141,12 @@ struct LazyAngle {
 // fabs(p - q) > limit, p and q being angle_degree values
 static inline bool angles_differ_by_more_than(LazyAngle &p, LazyAngle &q, float limit)
 {
-    if (p.has_approx && q.has_approx) {
+    if (p.has_coarse && q.has_coarse) {
+        const float d = std::fabs(p.coarse - q.coarse);
+        if (d > limit + 2.0f * kCoarseBand) return true;
+        if (d < limit - 2.0f * kCoarseBand) return false;
+    }
+    if (p.fine() && q.fine()) {
         const float d = std::fabs(p.approx - q.approx);
         if (d > limit + 2.0f * kAngleBand) return true;
         if (d < limit - 2.0f * kAngleBand) return false;
@@ -122,7 +156,12 @@ static inline bool angles_differ_by_more_than(LazyAngle &p, LazyAngle &q, float 
 // lo <= fabs(p) <= hi
 static inline bool abs_angle_within(LazyAngle &p, float lo, float hi)
 {
-    if (p.has_approx) {
+    if (p.has_coarse) {
+        const float a = std::fabs(p.coarse);
+        if (a > lo + kCoarseBand && a < hi - kCoarseBand) return true;
+        if (a < lo - kCoarseBand || a > hi + kCoarseBand) return false;
+    }
+    if (p.fine()) {
         const float a = std::fabs(p.approx);
         if (a > lo + kAngleBand && a < hi - kAngleBand) return true;
         if (a < lo - kAngleBand || a > hi + kAngleBand) return false;
@@ -174,14 +213,20 @@ static inline bool quad_rest(const agx_saddle &s0, const agx_saddle &d0, const a
     return true;
 }
 
-void debug_angle_pairs(const float *v, size_t n, float *exact, float *approx, uint8_t *has_approx)
+void debug_angle_pairs(const float *v, size_t n, float *exact, float *approx, uint8_t *has_approx, float *coarse, uint8_t *has_coarse)
 {
     for (size_t i = 0; i < n; ++i) {
         LazyAngle a;
         a.set(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
-        exact[i] = a.exact();
-        approx[i] = a.approx;
-        has_approx[i] = a.has_approx;
+        if (exact) exact[i] = a.exact();
+        if (approx) {
+            has_approx[i] = a.fine() ? 1 : 0;
+            approx[i] = a.approx;
+        }
+        if (coarse) {
+            coarse[i] = a.coarse;
+            has_coarse[i] = a.has_coarse;
+        }
     }
 }
 

@@ -27,7 +27,9 @@ float theta_distance_degree(float t0, float t1);
 float angle_degree(float v0x, float v0y, float v1x, float v1y);
 // test hook: angle_degree next to the bounded approximation the board search decides with outside
 // its guard bands (has_approx 0: the approximation is not used for these operands); v = n x 4 floats
-void debug_angle_pairs(const float *v, size_t n, float *exact, float *approx, uint8_t *has_approx);
+// (coarse / has_coarse, optional: the cheaper first-level approximation and where it is used)
+void debug_angle_pairs(const float *v, size_t n, float *exact, float *approx, uint8_t *has_approx, float *coarse = nullptr,
+                       uint8_t *has_coarse = nullptr);
 // saddle.rs:17-67
 bool is_valid_quad(const agx_saddle &s0, const agx_saddle &d0, const agx_saddle &s1, const agx_saddle &d1);
 

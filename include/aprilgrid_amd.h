@@ -355,6 +355,9 @@ typedef struct agx_cluster_info {
  * to decide threshold comparisons that are not close (csrc/host_tail.cpp, LazyAngle); has_approx[i] = 0
  * where the approximation is not used (zero / non-finite operands).  The CPU suite checks the bound. */
 int agx_debug_angle_pairs(const float *vectors, size_t n, float *exact, float *approx, uint8_t *has_approx);
+/* The coarser first-level approximation in front of it (a three-term polynomial in float, max error 0.04 degrees, guard band
+ * 0.1): most of the search's ~16 000 angle comparisons per frame are decided from it.  Same hook, same check. */
+int agx_debug_angle_pairs_coarse(const float *vectors, size_t n, float *coarse, uint8_t *has_coarse);
 int agx_debug_fetch(agx_detector *det, int frame, int what, void *host_out, size_t cap_bytes,
                     size_t *n_items);
 

@@ -268,6 +268,13 @@ def test_bounded_angle_approximation_of_the_board_search(lib):
     # operands the approximation refuses: zero cross product (sign of zero decides 0 / +-180) and zero vectors
     y = (v[:, 3] * v[:, 0] - v[:, 2] * v[:, 1]).astype(np.float32)
     assert not used[y == 0].any()
+    # round 5: the coarser level in front of it (three-term float polynomial, guard band 0.1 degrees per angle)
+    coarse, hasc = np.zeros(m, np.float32), np.zeros(m, np.uint8)
+    assert lib.agx_debug_angle_pairs_coarse(v.ctypes.data, m, coarse.ctypes.data, hasc.ctypes.data) == 0
+    usedc = hasc != 0
+    assert usedc.mean() > 0.9 and not usedc[y == 0].any()
+    errc = np.abs(coarse[usedc].astype(np.float64) - exact[usedc].astype(np.float64))
+    assert errc.max() < 0.04, errc.max()                                         # 0.4 of the coarse band
 
 
 @pytest.mark.parametrize("family", ["T16H5", "T25H7", "T25H9", "T36H11B1"])

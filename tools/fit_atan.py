@@ -20,8 +20,8 @@ def fit(terms):
 
 
 if __name__ == "__main__":
-    for terms in (5, 6, 7, 8):
+    for terms in (3, 5, 6, 7, 8):  # 3: the coarse first level (float), 7: the fine one (binary64)
         c, err = fit(terms)
         print("%d terms: max error %.3e rad = %.3e degrees" % (terms, err, np.degrees(err)))
-        if terms == 7:
+        if terms in (3, 7):
             print("  coefficients:", ", ".join(repr(float(v)) for v in c))
