@@ -49,6 +49,20 @@ bool family_info(int family, FamilyInfo &out)
 
 static const float kPi = 3.14159274101257324219f;
 
+// f32::round (half away from zero) without the call into libm the baseline x86-64 target makes of std::round (no SSE4.1
+// rounding instruction): x - trunc(x) is exact in binary32, so the comparison with 0.5 decides exactly what roundf decides.
+// Values of magnitude >= 2^23 (and NaN / inf) are their own rounding.  (The sign of a zero result may differ from roundf's --
+// every use below converts the result to an integer.  Compared with roundf on all 2^32 bit patterns: equal.)
+static inline float round_half_away(float x)
+{
+    if (!(std::fabs(x) < 8388608.0f)) return x;
+    float t = (float)(int32_t)x;
+    const float d = x - t;
+    if (d >= 0.5f) t += 1.0f;
+    else if (d <= -0.5f) t -= 1.0f;
+    return t;
+}
+
 float theta_distance_degree(float t0, float t1)
 {
     float d = t0 - t1 + 90.0f;
@@ -1006,7 +1020,7 @@ bool try_find_best_board(const std::vector<agx_saddle> &refined, std::vector<Qua
         }
     if (small_angles) {
         sc.hist.assign(361, 0);
-        for (const agx_saddle &s : refined) sc.hist[(size_t)((int)std::round(s.theta) + 180)]++;
+        for (const agx_saddle &s : refined) sc.hist[(size_t)((int)round_half_away(s.theta) + 180)]++;
         for (int a = 0; a < 361; ++a)
             if (sc.hist[(size_t)a] > best_len) {  // ascending angle: the first of equal counts is the smallest
                 best_len = sc.hist[(size_t)a];
@@ -1014,7 +1028,7 @@ bool try_find_best_board(const std::vector<agx_saddle> &refined, std::vector<Qua
             }
     } else {
         std::unordered_map<int, int> hist;
-        for (const agx_saddle &s : refined) hist[(int)std::round(s.theta)]++;
+        for (const agx_saddle &s : refined) hist[(int)round_half_away(s.theta)]++;
         for (const auto &kv : hist)
             if (kv.second > best_len || (kv.second == best_len && kv.first < best_angle)) {
                 best_len = kv.second;
@@ -1024,7 +1038,7 @@ bool try_find_best_board(const std::vector<agx_saddle> &refined, std::vector<Qua
     std::vector<int> &seeds = sc.seeds;
     seeds.clear();
     for (size_t i = 0; i < refined.size(); ++i)
-        if ((int)std::round(refined[i].theta) == best_angle) seeds.push_back((int)i);
+        if ((int)round_half_away(refined[i].theta) == best_angle) seeds.push_back((int)i);
 
     if (workers && workers->size() > 1 && seeds.size() > 1) return find_best_board_parallel(refined, seeds, index, quads, *workers);
 
@@ -1143,7 +1157,7 @@ bool decode_quad(const FamilyInfo &fam, const uint8_t *luma8, uint32_t w, uint32
                  const float quad_xy[8], int &tag_id, float corners[8])
 {
     for (int i = 0; i < 4; ++i) {
-        const uint32_t x = f32_as_u32(std::round(quad_xy[2 * i])), y = f32_as_u32(std::round(quad_xy[2 * i + 1]));
+        const uint32_t x = f32_as_u32(round_half_away(quad_xy[2 * i])), y = f32_as_u32(round_half_away(quad_xy[2 * i + 1]));
         if (x >= w || y >= h) return false;
     }
     float aff[6];
@@ -1155,7 +1169,7 @@ bool decode_quad(const FamilyInfo &fam, const uint8_t *luma8, uint32_t w, uint32
             const float fx = (float)gx, fy = (float)gy;
             const float px = aff[0] * fx + aff[1] * fy + aff[2] * 1.0f;
             const float py = aff[3] * fx + aff[4] * fy + aff[5] * 1.0f;
-            const uint32_t ix = f32_as_u32(std::round(px)), iy = f32_as_u32(std::round(py));
+            const uint32_t ix = f32_as_u32(round_half_away(px)), iy = f32_as_u32(round_half_away(py));
             if (ix >= w || iy >= h) return false;
             samples[n++] = luma8[(size_t)iy * stride + ix];
         }
@@ -1165,7 +1179,7 @@ bool decode_quad(const FamilyInfo &fam, const uint8_t *luma8, uint32_t w, uint32
         hi = std::max<int>(hi, samples[i]);
     }
     if (hi - lo < 50) return false;
-    const int mid = (int)(uint8_t)f32_as_u32(std::round(((float)lo + (float)hi) / 2.0f));
+    const int mid = (int)(uint8_t)f32_as_u32(round_half_away(((float)lo + (float)hi) / 2.0f));
     uint64_t bits = 0;
     uint32_t invalid = 0;
     for (int i = 0; i < n; ++i) {  // first sample is the most significant bit
