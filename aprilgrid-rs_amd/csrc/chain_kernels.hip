@@ -655,13 +655,23 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(((A4 |
             }
 
             // horizontal pass, image_util.rs:137-185: taps in index order, mul then add
+            // SHARE (round 5: every format on the aligned / unaligned data paths): a pixel's four distinct tap products (w[i] ==
+            // w[6 - i] bit for bit) are formed ONCE, by the lane that owns the pixel, and the three pixels on either side are taken
+            // as products from the neighbouring lane -- 16 multiplications per lane and row instead of 28 and no separate
+            // neighbour moves (the DPP shift folds into the add).  The 8-bit formats read the products from the LDS table (FAST),
+            // L16 / LF32 multiply.  The same products either way: x * w_i rounds identically in whichever lane evaluates it.
+            constexpr bool SHARE = FAST || BUF;
+            if (SHARE && !FAST) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) P[j] = make_float4(m[j] * w0, m[j] * w1, m[j] * w2, m[j] * w3);
+            }
             float x[10];
-            if (!FAST) {
+            if (!SHARE) {
                 x[0] = from_left(m[1]); x[1] = from_left(m[2]); x[2] = from_left(m[3]);
                 x[3] = m[0]; x[4] = m[1]; x[5] = m[2]; x[6] = m[3];
                 x[7] = from_right(m[0]); x[8] = from_right(m[1]); x[9] = from_right(m[2]);
             }
-            // FAST: x[n] * w_i comes out of the table -- of the own pixels directly, of the three
+            // SHARE: x[n] * w_i comes out of the table -- of the own pixels directly, of the three
             // pixels on either side through the neighbouring lane (the DPP shift folds into the add)
             auto prod = [&](int n, int i) -> float {
                 const int t = i <= 3 ? i : 6 - i;
@@ -673,8 +683,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(((A4 |
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float v;
-                if (FAST) {
-                    v = prod(j, 0);
+                if (SHARE) {
+                    // (LF32: the reference folds from 0.0 -- image_util.rs:146,160,178 -- and 0.0 + (-0.0) is +0.0, which only an
+                    // arbitrary f32 plane can produce)
+                    v = FMT == 3 ? 0.0f + prod(j, 0) : prod(j, 0);
                     v = v + prod(j + 1, 1);
                     v = v + prod(j + 2, 2);
                     v = v + prod(j + 3, 3);
