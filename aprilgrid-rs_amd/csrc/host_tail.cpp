@@ -100,12 +100,14 @@ constexpr float kCoarseBand = 0.1f;
 struct LazyAngle {
     float ax, ay, bx, by;  // angle_degree(ax, ay, bx, by)
     float yf, xf;          // what angle_degree hands to atan2f
-    float coarse = 0.0f, approx = 0.0f, exact_v = 0.0f;
-    uint8_t has_coarse = 0, has_approx = 0, fine_done = 0, has_exact = 0, is_set = 0;
+    // (no member initialisers: init_quads keeps ~100 of these per s1 on its stack and must not pay for clearing them;
+    // set() writes every field the levels read, "already set?" is the caller's bit mask)
+    float coarse, approx, exact_v;
+    uint8_t has_coarse, has_approx, fine_done, has_exact;
     void set(float v0x, float v0y, float v1x, float v1y)
     {
         ax = v0x; ay = v0y; bx = v1x; by = v1y;
-        is_set = 1;
+        coarse = approx = exact_v = 0.0f;
         has_exact = 0;
         fine_done = 0;
         has_approx = 0;
@@ -844,7 +846,8 @@ void init_quads(const std::vector<agx_saddle> &refined, SaddleIndex &index, int 
     // below visit only the pairs whose two saddles also lie on s1's side of s0 (a second bit row per s1), in that same order.
     uint64_t p0[50];
     int base[51];
-    static thread_local std::vector<LazyAngle> a3_store;  // a3 = angle(v30, v01) per listed pair, on demand
+    static thread_local std::vector<LazyAngle> a3_store;  // a3 = angle(v30, v01) per listed pair, on demand ...
+    static thread_local std::vector<uint64_t> a3_set;      // ... one bit per listed pair: evaluated yet?
     int n_pairs = 0;
     for (int a = 0; a < nd; ++a) {
         uint64_t row = 0;
@@ -855,7 +858,8 @@ void init_quads(const std::vector<agx_saddle> &refined, SaddleIndex &index, int 
         n_pairs += __builtin_popcountll(row);
     }
     if (!n_pairs) return;
-    a3_store.assign((size_t)n_pairs, LazyAngle());
+    if (a3_store.size() < (size_t)n_pairs) a3_store.resize((size_t)n_pairs);
+    a3_set.assign(((size_t)n_pairs + 63) / 64, 0ull);
     LazyAngle *a3v = a3_store.data();
     const float th0 = s0.theta / 180.0f * kPi;
     const float cos0 = std::cos(th0), sin0 = std::sin(th0);  // part 1's direction of s0, once instead of per s1
@@ -866,6 +870,7 @@ void init_quads(const std::vector<agx_saddle> &refined, SaddleIndex &index, int 
         const float v02x = s1.x - s0.x, v02y = s1.y - s0.y;
         float cA[50], cB[50], c01[50], v12x[50], v12y[50], v23x[50], v23y[50];
         LazyAngle a0v[50], a2v[50];
+        uint64_t a0_set = 0, a2_set = 0;  // which of them have been evaluated for this s1
         uint64_t ok = 0;  // bit d: dot(v0d, v02) >= 0 (saddle.rs:62-64), needed of both d0 and d1
         for (int d = 0; d < nd; ++d) {
             const agx_saddle &p = refined[diff[d]];
@@ -884,11 +889,20 @@ void init_quads(const std::vector<agx_saddle> &refined, SaddleIndex &index, int 
                 bs &= bs - 1;
                 if (cA[a] * cB[b] < 0.0f) continue;
                 if (c01[a] * cross2(v12x[a], v12y[a], v23x[b], v23y[b]) < 0.0f) continue;
-                if (!a0v[a].is_set) a0v[a].set(v0x[a], v0y[a], v12x[a], v12y[a]);
-                if (!a2v[b].is_set) a2v[b].set(v23x[b], v23y[b], v30x[b], v30y[b]);
+                if (!(a0_set >> a & 1ull)) {
+                    a0v[a].set(v0x[a], v0y[a], v12x[a], v12y[a]);
+                    a0_set |= 1ull << a;
+                }
+                if (!(a2_set >> b & 1ull)) {
+                    a2v[b].set(v23x[b], v23y[b], v30x[b], v30y[b]);
+                    a2_set |= 1ull << b;
+                }
                 if (angles_differ_by_more_than(a0v[a], a2v[b], 10.0f)) continue;
                 const int pi = base[a] + __builtin_popcountll(p0[a] & ((1ull << b) - 1ull));
-                if (!a3v[pi].is_set) a3v[pi].set(v30x[b], v30y[b], v0x[a], v0y[a]);
+                if (!(a3_set[(size_t)pi >> 6] >> (pi & 63) & 1ull)) {
+                    a3v[pi].set(v30x[b], v30y[b], v0x[a], v0y[a]);
+                    a3_set[(size_t)pi >> 6] |= 1ull << (pi & 63);
+                }
                 LazyAngle a1;
                 a1.set(v12x[a], v12y[a], v23x[b], v23y[b]);
                 if (angles_differ_by_more_than(a1, a3v[pi], 10.0f)) continue;
