@@ -872,10 +872,17 @@ void init_quads(const std::vector<agx_saddle> &refined, SaddleIndex &index, int 
         LazyAngle a0v[50], a2v[50];
         uint64_t a0_set = 0, a2_set = 0;  // which of them have been evaluated for this s1
         uint64_t ok = 0;  // bit d: dot(v0d, v02) >= 0 (saddle.rs:62-64), needed of both d0 and d1
+        // the winding test cA[a] * cB[b] < 0 (saddle.rs:44-46) as bit rows: with both factors at least 2^-60 in magnitude the
+        // product is a normal number of the factors' signs -- no underflow to a zero that would fail the `< 0` --, so opposite
+        // signs decide it; smaller factors (never seen on image coordinates) keep the explicit product below
+        uint64_t b_pos = 0, b_neg = 0;
+        constexpr float kTiny = 8.67361737988403547e-19f;  // 2^-60
         for (int d = 0; d < nd; ++d) {
             const agx_saddle &p = refined[diff[d]];
             cA[d] = cross2(v0x[d], v0y[d], v02x, v02y);   // c0 with d as d0 (also the winding test)
             cB[d] = cross2(v02x, v02y, v0x[d], v0y[d]);   // c1 with d as d1
+            if (cB[d] >= kTiny) b_pos |= 1ull << d;
+            else if (cB[d] <= -kTiny) b_neg |= 1ull << d;
             if (!(dot2(v0x[d], v0y[d], v02x, v02y) < 0.0f)) ok |= 1ull << d;
             v12x[d] = s1.x - p.x; v12y[d] = s1.y - p.y;   // d as d0
             v23x[d] = p.x - s1.x; v23y[d] = p.y - s1.y;   // d as d1
@@ -884,7 +891,8 @@ void init_quads(const std::vector<agx_saddle> &refined, SaddleIndex &index, int 
         for (uint64_t as = ok; as;) {
             const int a = __builtin_ctzll(as);
             as &= as - 1;
-            for (uint64_t bs = p0[a] & ok; bs;) {
+            const uint64_t wound_wrong = cA[a] >= kTiny ? b_neg : (cA[a] <= -kTiny ? b_pos : 0ull);  // cA[a] * cB[b] < 0 for certain
+            for (uint64_t bs = p0[a] & ok & ~wound_wrong; bs;) {
                 const int b = __builtin_ctzll(bs);
                 bs &= bs - 1;
                 if (cA[a] * cB[b] < 0.0f) continue;
