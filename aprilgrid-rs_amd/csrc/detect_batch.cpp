@@ -1,9 +1,9 @@
 // detect_batch.cpp -- TagDetector::detect (reference src/detector.rs:505-540) over a batch of
 // frames: the saddle chain of a chunk of frames runs on the device while a pool of host threads
-// runs the board search + decode (detect's loop body, :510-539) of the previous chunk.  The host
-// tail is the reference's exhaustive search (several milliseconds per frame and thread), so the
-// end-to-end rate is set by the number of host threads; the pool keeps them busy and the device
-// work disappears behind them.
+// runs the uploads and the board search + decode (detect's loop body, :510-539) of the chunks around it.
+// The host tail is the reference's exhaustive search (about a millisecond per frame and thread), so the
+// end-to-end rate is set by the number of host threads the process is granted; the pool keeps them busy
+// and the device work disappears behind them.
 #include <hip/hip_runtime_api.h>
 
 #include <sched.h>
@@ -272,7 +272,7 @@ static int detect_batch_impl(agx_detector *det, const void *frames, const void *
     const int device = agx_internal_device(det);
 
     // Chunks of about one frame per worker (8 .. 64): the chain of a chunk takes 0.1 ms on the device, a frame's board
-    // search 1.5 ms on a host thread, so small chunks cost nothing and the workers start after the first 8 .. 64 frames
+    // search about a millisecond on a host thread, so small chunks cost nothing and the workers start after the first 8 .. 64 frames
     // instead of after a quarter of the batch.  Three kinds of work, none of which waits for another chunk's:
     //   uploads   (host frames only) pool tasks that jump the queue: pageable memory goes to the device through the
     //             runtime's staging copies on the calling thread, i.e. it is host work -- it runs on the workers, up to
