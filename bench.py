@@ -457,7 +457,10 @@ def detect_end_to_end_leg(torch, A, dev, n_frames, width, height, quick=False):
         if not quick:
             # a longer stream of frames (the same 256 thirty-two times over: 8 GB of host memory, ~0.5 s): start-up and drain
             # amortised, and long enough (several 100 ms scheduler periods) that a CPU quota binds -- the sustained rate
-            big = np.concatenate([host] * max(1, 8192 // n_frames))
+            try:
+                big = np.concatenate([host] * max(1, 8192 // n_frames))
+            except MemoryError:  # (a host with a tight memory limit: a shorter stream)
+                big = np.concatenate([host] * max(1, 2048 // n_frames))
             o2 = np.zeros((len(big), cap), det.TAG_DTYPE)
             c2 = np.zeros(len(big), np.uint32)
             s2 = np.zeros(len(big), np.int32)
