@@ -56,6 +56,7 @@ SYMBOLS = {
     "agx_saddles_batch_enqueue_to": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_int,
                                                _P, C.c_uint32, _P]),
     "agx_host_parallelism": (C.c_int, []),
+    "agx_debug_cgroup_cpu_quota": (C.c_int, [C.c_char_p, C.c_char_p]),
     "agx_detect_batch": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_int, _P, C.c_uint32,
                                    _P, _P, C.c_int]),
     "agx_group_create": (C.c_int, [C.c_int, C.POINTER(Params), C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(_P)]),

@@ -151,7 +151,7 @@ using namespace agx;
 
 // CPUs of this process: affinity mask, narrowed by the CPU quota of its cgroup and of the cgroups above it
 // (v2: cpu.max "quota period" | "max period"; v1: cpu.cfs_quota_us / cpu.cfs_period_us)
-static int cgroup_cpu_quota()
+static int cgroup_cpu_quota(const std::string &cg_root = "/sys/fs/cgroup", const char *proc_cgroup = "/proc/self/cgroup")
 {
     auto read_pair = [](const std::string &path, long long &a, long long &b) -> bool {
         FILE *f = std::fopen(path.c_str(), "r");
@@ -171,7 +171,7 @@ static int cgroup_cpu_quota()
     };
     // this process's cgroup path (v2: "0::/path"; v1: "N:cpu,cpuacct:/path")
     std::string v2_path, v1_path;
-    if (FILE *f = std::fopen("/proc/self/cgroup", "r")) {
+    if (FILE *f = std::fopen(proc_cgroup, "r")) {
         char line[512];
         while (std::fgets(line, sizeof line, f)) {
             std::string l(line);
@@ -186,15 +186,15 @@ static int cgroup_cpu_quota()
     }
     for (std::string p = v2_path;;) {  // the cgroup and every ancestor (inside a container the namespace root is "/")
         long long q = -1, per = 100000;
-        if (read_pair("/sys/fs/cgroup" + p + (p.empty() || p.back() != '/' ? "/" : "") + "cpu.max", q, per)) take(q, per);
+        if (read_pair(cg_root + p + (p.empty() || p.back() != '/' ? "/" : "") + "cpu.max", q, per)) take(q, per);
         if (p.empty() || p == "/") break;
         const size_t cut = p.find_last_of('/');
         p = cut == std::string::npos || cut == 0 ? "/" : p.substr(0, cut);
     }
-    for (const char *root : {"/sys/fs/cgroup/cpu", "/sys/fs/cgroup/cpu,cpuacct"}) {
+    for (const char *ctrl : {"/cpu", "/cpu,cpuacct"}) {
         for (std::string p = v1_path.empty() ? "/" : v1_path;;) {
             long long q = -1, per = -1, dummy = 0;
-            const std::string dir = std::string(root) + p + (p.back() != '/' ? "/" : "");
+            const std::string dir = cg_root + ctrl + p + (p.back() != '/' ? "/" : "");
             if (read_pair(dir + "cpu.cfs_quota_us", q, dummy) && read_pair(dir + "cpu.cfs_period_us", per, dummy)) take(q, per);
             if (p == "/") break;
             const size_t cut = p.find_last_of('/');
@@ -202,6 +202,16 @@ static int cgroup_cpu_quota()
         }
     }
     return best < 0 ? 0 : (int)std::min<long long>(best, 1 << 20);
+}
+
+extern "C" int agx_debug_cgroup_cpu_quota(const char *cgroup_root, const char *proc_self_cgroup)
+{
+    try {
+        if (!cgroup_root || !proc_self_cgroup) return AGX_ERR_ARG;
+        return cgroup_cpu_quota(cgroup_root, proc_self_cgroup);
+    } catch (...) {
+        return AGX_ERR_NOMEM;
+    }
 }
 
 extern "C" int agx_host_parallelism(void)

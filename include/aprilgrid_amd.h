@@ -239,6 +239,10 @@ int agx_detector_sync(agx_detector *det);
  * thread of the process -- the one driving the device included -- sit out the rest of each scheduler
  * period.  (The reference never spawns a thread, src/detector.rs:505; batches are this library's.) */
 int agx_host_parallelism(void);
+/* Test hook: the CPU-quota half of that rule on a given cgroup mount point and stand-in for /proc/self/cgroup (v2 cpu.max
+ * and v1 cpu.cfs_quota_us / cpu.cfs_period_us of the process's cgroup and every ancestor, the smallest, rounded up to whole
+ * CPUs); 0 = no quota found.  Nothing is cached. */
+int agx_debug_cgroup_cpu_quota(const char *cgroup_root, const char *proc_self_cgroup);
 
 /* TagDetector::detect (src/detector.rs:505-540) over a batch of equally sized frames in HOST memory
  * (frame i at frames + i*frame_stride_bytes; formats AGX_L8 / AGX_L16 / AGX_RGB8).  The saddle

@@ -424,3 +424,32 @@ def test_status_codes_of_the_header_and_the_ctypes_table_agree():
     for name, val in re.findall(r"\b(AGX_(?:OK|ERR_[A-Z_]+))\s*=\s*(-?\d+)", hdr):
         assert getattr(_ffi, name) == int(val), name
     assert _ffi.AGX_ERR_NOMEM == -8
+
+
+def test_host_parallelism_reads_the_cgroup_cpu_quota(lib, tmp_path):
+    """agx_host_parallelism() = affinity mask AND cgroup CPU quota (the default thread count of agx_detect_batch: a 1-GPU box of
+    this pool shows 256 CPUs and grants 16).  The quota half on made-up cgroup trees: v2 cpu.max of the process's cgroup and its
+    ancestors (the smallest wins, "max" = none, fractions round up), v1 cfs files, nothing found = 0."""
+    def quota(files, proc):
+        root = tmp_path / ("cg%d" % quota.n)
+        quota.n += 1
+        for rel, text in files.items():
+            f = root / rel
+            f.parent.mkdir(parents=True, exist_ok=True)
+            f.write_text(text)
+        pc = root / "proc_self_cgroup"
+        pc.parent.mkdir(parents=True, exist_ok=True)
+        pc.write_text(proc)
+        return lib.agx_debug_cgroup_cpu_quota(str(root).encode(), str(pc).encode())
+    quota.n = 0
+    assert quota({"cpu.max": "1600000 100000\n"}, "0::/\n") == 16                      # the GPU boxes of this pool
+    assert quota({"cpu.max": "max 100000\n"}, "0::/\n") == 0
+    assert quota({"cpu.max": "150000 100000\n"}, "0::/\n") == 2                        # 1.5 CPUs -> 2 threads
+    assert quota({"cpu.max": "max 100000\n", "a/cpu.max": "800000 100000\n", "a/b/cpu.max": "max 100000\n"}, "0::/a/b\n") == 8
+    assert quota({"cpu.max": "400000 100000\n", "a/b/cpu.max": "3200000 100000\n"}, "0::/a/b\n") == 4   # an ancestor's is tighter
+    assert quota({"cpu/cpu.cfs_quota_us": "-1\n", "cpu/cpu.cfs_period_us": "100000\n"}, "3:cpuset:/jobs\n1:cpu:/\n0::/\n") == 0
+    assert quota({"cpu/cpu.cfs_quota_us": "600000\n", "cpu/cpu.cfs_period_us": "100000\n"}, "2:cpuacct:/\n1:cpu:/\n") == 6
+    assert quota({"cpu,cpuacct/k/cpu.cfs_quota_us": "250000\n", "cpu,cpuacct/k/cpu.cfs_period_us": "50000\n"}, "4:cpu,cpuacct:/k\n") == 5
+    assert quota({}, "") == 0
+    n = lib.agx_host_parallelism()
+    assert 1 <= n <= (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count())

@@ -537,6 +537,21 @@ def test_plain_c_client_of_the_abi(oracle, tmp_path):
     assert "first saddle (%.3f, %.3f) k=%.5f" % (ref["x"][0], ref["y"][0], ref["k"][0]) in r.stdout, r.stdout
 
 
+def test_plain_c_client_runs_a_batch_through_agx_detect_batch(oracle, tmp_path):
+    """examples/c_client.c with five frames in one file: agx_detect_batch from plain C (no Python / torch in the process; the
+    default thread count = agx_host_parallelism()) returns the oracle's tag count for every frame."""
+    import subprocess
+    from tests.test_abi_cpu import _build_c_client
+    synth = synth_module()
+    frames = np.stack([np.asarray(synth.render_frame(40 + i, 640, 480)[0]) for i in range(5)])
+    raw = tmp_path / "frames.raw"
+    frames.tofile(raw)
+    r = subprocess.run([_build_c_client(tmp_path), str(raw), "640", "480", "5"], capture_output=True, text=True)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    want = [len(oracle.detect(f)) for f in frames]
+    assert "batch of 5 frames" in r.stdout and (":" + "".join(" %d" % n for n in want) + " tags") in r.stdout, (r.stdout, want)
+
+
 def test_capacity_overflow_is_reported_not_truncated(oracle):
     import aprilgrid_rs_amd as A
     d = A.TagDetector("T36H11", None, device=0)
