@@ -835,9 +835,10 @@ void init_quads(const std::vector<agx_saddle> &refined, SaddleIndex &index, int 
     }
     if (!ns || nd < 2) return;
     // (d): v0d = d - s0 (v01 / v03), v30 = s0 - d;  (d0, d1): part 0, a3 on demand
-    float v0x[50], v0y[50], v30x[50], v30y[50];
+    float v0x[50], v0y[50], v30x[50], v30y[50], dpx[50], dpy[50];  // (dpx / dpy: the d saddles' coordinates side by side for the loops over s1)
     for (int d = 0; d < nd; ++d) {
         const agx_saddle &p = refined[diff[d]];
+        dpx[d] = p.x; dpy[d] = p.y;
         v0x[d] = p.x - s0.x; v0y[d] = p.y - s0.y;
         v30x[d] = s0.x - p.x; v30y[d] = s0.y - p.y;
     }
@@ -877,16 +878,20 @@ void init_quads(const std::vector<agx_saddle> &refined, SaddleIndex &index, int 
         // signs decide it; smaller factors (never seen on image coordinates) keep the explicit product below
         uint64_t b_pos = 0, b_neg = 0;
         constexpr float kTiny = 8.67361737988403547e-19f;  // 2^-60
+        float dt[50];
+        const float s1x = s1.x, s1y = s1.y;
+        for (int d = 0; d < nd; ++d) {  // (plain arrays in, plain arrays out: the compiler vectorises this loop)
+            cA[d] = v0x[d] * v02y - v0y[d] * v02x;        // cross(v0d, v02): c0 with d as d0 (also the winding test)
+            cB[d] = v02x * v0y[d] - v02y * v0x[d];        // cross(v02, v0d): c1 with d as d1
+            dt[d] = v0x[d] * v02x + v0y[d] * v02y;        // dot(v0d, v02)
+            v12x[d] = s1x - dpx[d]; v12y[d] = s1y - dpy[d];   // d as d0
+            v23x[d] = dpx[d] - s1x; v23y[d] = dpy[d] - s1y;   // d as d1
+            c01[d] = v0x[d] * v12y[d] - v0y[d] * v12x[d];  // cross(v01, v12)
+        }
         for (int d = 0; d < nd; ++d) {
-            const agx_saddle &p = refined[diff[d]];
-            cA[d] = cross2(v0x[d], v0y[d], v02x, v02y);   // c0 with d as d0 (also the winding test)
-            cB[d] = cross2(v02x, v02y, v0x[d], v0y[d]);   // c1 with d as d1
             if (cB[d] >= kTiny) b_pos |= 1ull << d;
             else if (cB[d] <= -kTiny) b_neg |= 1ull << d;
-            if (!(dot2(v0x[d], v0y[d], v02x, v02y) < 0.0f)) ok |= 1ull << d;
-            v12x[d] = s1.x - p.x; v12y[d] = s1.y - p.y;   // d as d0
-            v23x[d] = p.x - s1.x; v23y[d] = p.y - s1.y;   // d as d1
-            c01[d] = cross2(v0x[d], v0y[d], v12x[d], v12y[d]);
+            if (!(dt[d] < 0.0f)) ok |= 1ull << d;
         }
         for (uint64_t as = ok; as;) {
             const int a = __builtin_ctzll(as);
