@@ -150,6 +150,26 @@ def host_parallelism():
         return max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
 
 
+def native_oracle_library():
+    """oracle/agx_oracle.c built -O3 -march=native ON THIS MACHINE (the prebuilt oracle/liborc_native.so travels with the
+    snapshot and was compiled for the build container's CPU: -march=native of another machine is neither safe nor the best
+    this host can do).  Falls back to the prebuilt file where there is no compiler."""
+    import subprocess
+    import tempfile
+    src = os.path.join(ROOT, "oracle", "agx_oracle.c")
+    prebuilt = os.path.join(ROOT, "oracle", "liborc_native.so")
+    out = os.path.join(tempfile.gettempdir(), "liborc_native_%d.so" % os.getuid())
+    try:
+        if not (os.path.exists(out) and os.path.getmtime(out) >= os.path.getmtime(src)):
+            tmp = out + ".%d.tmp" % os.getpid()
+            subprocess.run(["gcc", "-O3", "-march=native", "-std=c99", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
+                            "-o", tmp, src, "-lm"], check=True, capture_output=True)
+            os.replace(tmp, out)
+        return out, "built on this host"
+    except Exception:
+        return prebuilt, "prebuilt (no compiler on this host)"
+
+
 def cpu_baseline(frames_host, fmt, budget_s):
     """Oracle (C port of the reference CPU path, -O3 -march=native, still no FMA contraction),
     one thread, chain only (refined_saddle_points), on as many of the bench's own frames as fit
@@ -158,7 +178,7 @@ def cpu_baseline(frames_host, fmt, budget_s):
     import numpy as np
     from oracle import oracle as O
     O.build()
-    native = os.path.join(ROOT, "oracle", "liborc_native.so")
+    native, native_how = native_oracle_library()
     lib = C.CDLL(native)
     lib.orc_refined_saddle_points.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_long, C.c_int, C.c_void_p,
                                               C.c_void_p, C.c_int, C.c_void_p]
@@ -209,7 +229,7 @@ def cpu_baseline(frames_host, fmt, budget_s):
                           "host_cores_shown": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1),
                           "sample": "%d frames in %.1f s on %d threads" % (sum(counts), t_mt, n_thr)},
             "sample": "%d frames %dx%d %s, chain only (refined_saddle_points), oracle/agx_oracle.c -O3 "
-                      "-march=native -ffp-contract=off, %.1f s" % (n_done, w, h, fmt, t_used),
+                      "-march=native (%s) -ffp-contract=off, %.1f s" % (n_done, w, h, fmt, native_how, t_used),
             "ms_per_frame": round(1e3 * t_used / n_done, 3)}
 
 

@@ -51,7 +51,8 @@ class Cpu:
         from oracle import oracle as O
         O.build()
         self.O = O
-        self.native = C.CDLL(os.path.join(ROOT, "oracle", "liborc_native.so"))
+        import bench
+        self.native = C.CDLL(bench.native_oracle_library()[0])  # -march=native of THIS host, not of the build container
         self.native.orc_detect.argtypes = O.lib().orc_detect.argtypes
         self.native.orc_gaussian_blur_f32.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p]
         self.native.orc_refined_saddle_points.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_long, C.c_int, C.c_void_p,
