@@ -843,20 +843,21 @@ void init_quads(const std::vector<agx_saddle> &refined, SaddleIndex &index, int 
         v30x[d] = s0.x - p.x; v30y[d] = s0.y - p.y;
     }
     // the (d0, d1) combinations that pass part 0 as one bit row per a (bit b > a set: the pair is a candidate), and their
-    // running number in the reference's order (a ascending, then b): base[a] + the bits of row a below b.  The loops over s1
+    // running number in the reference's order (a ascending, then b).  The loops over s1
     // below visit only the pairs whose two saddles also lie on s1's side of s0 (a second bit row per s1), in that same order.
     uint64_t p0[50];
-    int base[51];
+    static thread_local uint16_t pair_no[50 * 50];         // the running number of pair (a, b), written where the bit is set
     static thread_local std::vector<LazyAngle> a3_store;  // a3 = angle(v30, v01) per listed pair, on demand ...
     static thread_local std::vector<uint64_t> a3_set;      // ... one bit per listed pair: evaluated yet?
     int n_pairs = 0;
     for (int a = 0; a < nd; ++a) {
         uint64_t row = 0;
         for (int b = a + 1; b < nd; ++b)
-            if (quad_part0(refined[diff[a]], refined[diff[b]])) row |= 1ull << b;
+            if (quad_part0(refined[diff[a]], refined[diff[b]])) {
+                row |= 1ull << b;
+                pair_no[a * 50 + b] = (uint16_t)n_pairs++;
+            }
         p0[a] = row;
-        base[a] = n_pairs;
-        n_pairs += __builtin_popcountll(row);
     }
     if (!n_pairs) return;
     if (a3_store.size() < (size_t)n_pairs) a3_store.resize((size_t)n_pairs);
@@ -911,7 +912,7 @@ void init_quads(const std::vector<agx_saddle> &refined, SaddleIndex &index, int 
                     a2_set |= 1ull << b;
                 }
                 if (angles_differ_by_more_than(a0v[a], a2v[b], 10.0f)) continue;
-                const int pi = base[a] + __builtin_popcountll(p0[a] & ((1ull << b) - 1ull));
+                const int pi = pair_no[a * 50 + b];
                 if (!(a3_set[(size_t)pi >> 6] >> (pi & 63) & 1ull)) {
                     a3v[pi].set(v30x[b], v30y[b], v0x[a], v0y[a]);
                     a3_set[(size_t)pi >> 6] |= 1ull << (pi & 63);
