@@ -453,3 +453,31 @@ def test_host_parallelism_reads_the_cgroup_cpu_quota(lib, tmp_path):
     assert quota({}, "") == 0
     n = lib.agx_host_parallelism()
     assert 1 <= n <= (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count())
+
+
+def test_host_tail_survives_non_finite_saddles():
+    """agx_detect_tail takes a caller's saddle list (agx_detect_from_saddles: any floats).  NaN / infinite coordinates and
+    angles must not crash or hang the search (the grid index clamps its cells, the selection orders keys, the angle
+    approximations refuse such operands); what it returns for them is unspecified."""
+    import aprilgrid_rs_amd as A
+    from aprilgrid_rs_amd.detector import SADDLE_DTYPE
+    rng = np.random.default_rng(0)
+    g = np.full((200, 300), 128, np.uint8)
+    for trial in range(120):
+        n = int(rng.integers(1, 400)) if trial % 10 else 1500  # (1500: beyond the brute-force 50-NN's range)
+        s = np.zeros(n, SADDLE_DTYPE)
+        s["x"], s["y"] = rng.uniform(0, 300, n), rng.uniform(0, 200, n)
+        s["k"], s["phi"] = 1.0, 45.0
+        s["theta"] = rng.choice([10.0, -80.0], n) + rng.normal(0, 1, n)
+        bad = rng.integers(0, n, max(1, n // 10))
+        kind = trial % 4
+        if kind == 0:
+            s["x"][bad] = np.nan
+        elif kind == 1:
+            s["y"][bad] = np.inf
+        elif kind == 2:
+            s["theta"][bad] = np.nan
+        else:
+            s["x"][bad] = -np.inf
+            s["theta"][bad] = 1e30
+        A.TagDetector.detect_tail("t36h11", s, g)
