@@ -1,3 +1,5 @@
+"""Inserts rdtsc section counters (pair-candidate misses, valid_quad misses, Board construction, init_quads and its 50-NN, decode_quad,
+the memo look-ups, the index build) into a copy of host_tail.cpp: python tsc_patch.py <host_tail.cpp> <out.cpp>; tp_tsc.cpp prints them."""
 import re,sys
 src=open(sys.argv[1]).read()
 # add tsc accumulators
@@ -12,7 +14,8 @@ src=src.replace('        st_.begin(refined.size());\n        for (int i = 1; i <
 src=src.replace('    out.clear();\n    const agx_saddle &s0 = refined[s0_idx];\n    SaddleIndex::Hit near[50];','    Tsc tsc_iq(3);\n    out.clear();\n    const agx_saddle &s0 = refined[s0_idx];\n    SaddleIndex::Hit near[50];')
 src=src.replace('        m = index.nearest(s0.x, s0.y, 50, near);','        Tsc tsc_nn(4);\n        m = index.nearest(s0.x, s0.y, 50, near);')
 # decode
-src=src.replace('    for (int i = 0; i < 4; ++i) {\n        const uint32_t x = f32_as_u32(std::round(quad_xy[2 * i]))','    Tsc tsc_dec(5);\n    for (int i = 0; i < 4; ++i) {\n        const uint32_t x = f32_as_u32(std::round(quad_xy[2 * i]))')
+for fn in ('std::round', 'round_half_away'):
+    src=src.replace('    for (int i = 0; i < 4; ++i) {\n        const uint32_t x = f32_as_u32(%s(quad_xy[2 * i]))' % fn,'    Tsc tsc_dec(5);\n    for (int i = 0; i < 4; ++i) {\n        const uint32_t x = f32_as_u32(%s(quad_xy[2 * i]))' % fn)
 # pair_candidates total
 src=src.replace('        const std::vector<agx_saddle> &pts_ = *pts_p_;\n        AGX_TAIL_COUNT(7, 1);','        const std::vector<agx_saddle> &pts_ = *pts_p_;\n        Tsc tsc_pc(6);\n        AGX_TAIL_COUNT(7, 1);')
 # valid_quad total
