@@ -2862,7 +2862,7 @@ __global__ void __launch_bounds__(1024) k_sparse_frame(ChainArgs a, RefineConsts
 // sweep tools that change os.environ between runs of one process) forgets what was read.
 namespace {
 std::mutex g_env_mutex;
-std::map<std::string, std::pair<bool, int>> g_env_cache;  // name -> (set, value)
+std::map<std::string, std::pair<bool, int>, std::less<>> g_env_cache;  // name -> (set, value); std::less<>: looked up by const char * without a temporary string
 }
 int tuning_env(const char *name, int dflt)
 {
