@@ -511,6 +511,21 @@ def detect_end_to_end_leg(torch, A, dev, n_frames, width, height, quick=False):
                 rc, _, _, _ = det.detect_batch_raw(big, n_threads=thr, cap=cap, out=o2, counts=c2, status=s2)
                 res["beyond_quota"]["frames_per_s_%d_frames" % len(big)] = round(len(big) / (time.perf_counter() - t0), 1)
             del big, o2, c2, s2
+        if not quick:
+            # L16 / RGB8 batches: the u8 luma the decode needs is computed on the device behind the chain and comes back with the saddles
+            for fmt2 in ("RGB8", "L16"):
+                fr2, _ = make_workload(0, n_frames, width, height, fmt2, 64, False, dev)
+                h2 = host_view(fr2, fmt2)
+                del fr2
+                det.detect_batch_raw(h2[:64], n_threads=quota, cap=cap, out=out[:64], counts=counts[:64], status=status[:64])
+                ts = []
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    rc, _, _, _ = det.detect_batch_raw(h2, n_threads=quota, cap=cap, out=out, counts=counts, status=status)
+                    ts.append(time.perf_counter() - t0)
+                    assert rc == 0 and (status == 0).all()
+                res["frames_per_s_" + fmt2] = round(n_frames / statistics.median(ts), 1)
+                del h2
         res["note"] = ("never `value`: set by the host tail (the reference's exhaustive board search, one frame per thread) and by the CPUs the box "
                        "gives the process (host_cpu_quota of the host_cores it shows: cgroup cpu.max); parallel_efficiency = frames/s over threads x the "
                        "1-thread rate; the chain alone delivers config.frames_per_s")
