@@ -284,9 +284,9 @@ static int detect_batch_impl(agx_detector *det, const void *frames, const void *
     // Chunks of about one frame per worker (8 .. 64): the chain of a chunk takes 0.1 ms on the device, a frame's board
     // search about a millisecond on a host thread, so small chunks cost nothing and the workers start after the first 8 .. 64 frames
     // instead of after a quarter of the batch.  Three kinds of work, none of which waits for another chunk's:
-    //   uploads   (host frames only) pool tasks that jump the queue: pageable memory goes to the device through the
-    //             runtime's staging copies on the calling thread, i.e. it is host work -- it runs on the workers, up to
-    //             AGX_UPLOAD_STREAMS chunks ahead, not on the thread that drives the device;
+    //   uploads   (host frames only) pool tasks that jump the queue: a copy from pageable memory occupies the calling thread
+    //             for its duration (0.3 ms per 16 MB chunk at the PCIe rate: profiles/r5_ubench_h2d_pageable.txt) -- it runs
+    //             on the workers, up to AGX_UPLOAD_STREAMS chunks ahead, not on the thread that drives the device;
     //   chain     this thread: enqueue, luma (L16 / RGB8), one wait per chunk, the compact list into the chunk's slot;
     //   tails     pool tasks, one per frame, reading the slot; a slot is refilled when ITS tails are done (a counter per
     //             slot) -- no barrier over the pool between chunks.

@@ -489,8 +489,8 @@ def detect_end_to_end_leg(torch, A, dev, n_frames, width, height, quick=False):
             dt = time.perf_counter() - t0
             assert rc == 0 and np.array_equal(c2[:n_frames], counts)
             res["frames_per_s_%d_frames" % len(big)] = round(len(big) / dt, 1)
-            # the same frames in PINNED host memory (hipHostMalloc / torch pin_memory): the uploads become plain DMA transfers
-            # instead of copies through the runtime's staging buffers on the worker threads (~0.1 ms of CPU per 1 MB frame)
+            # the same frames in PINNED host memory (hipHostMalloc / torch pin_memory), for comparison: the runtime's pageable path
+            # already runs at the PCIe rate (profiles/r5_ubench_h2d_pageable.txt), so little changes
             pinned_t = torch.empty((n_frames, height, width), dtype=torch.uint8, pin_memory=True)
             pinned_t.copy_(torch.from_numpy(host))
             pinned = pinned_t.numpy()
