@@ -58,24 +58,28 @@ def gather_results(saddles, table, dst=0, group=None):
 
 
 class GatherPipeline:
-    """Double-buffered result buffers with asynchronous gathers, so that the gather of step i
-    overlaps the chain of step i+1 (which writes the other buffer pair).  A rank's frame table and its
-    records live in ONE packed buffer (alloc_packed), so a step's gather is one message per rank: on
-    rank 0 of an 8-GPU node 7 receives of 2.6 MB per step instead of 14 (tables and records apart).
-    `every` > 1 gathers only every n-th submitted step (and always the last one before finish()): what a
-    consumer that polls results at a lower rate than the chain produces them would ask for; the default,
-    and what bench.py times, is every step.
+    """Result buffers with asynchronous gathers, so that the gather of a step overlaps the chain of the
+    following ones (which write other buffers).  A rank's frame table and its records live in ONE packed
+    buffer (alloc_packed), so a gather is one message per rank: on rank 0 of an 8-GPU node 7 receives
+    instead of 14 (tables and records apart).
+
+    `steps_per_gather` = k > 1: the slabs of k consecutive steps are one contiguous buffer and go to rank
+    `dst` in ONE collective when the k-th is enqueued (every step's results are delivered, the first of a
+    group k - 1 steps late; finish() sends a group that is not full yet) -- fewer, larger messages: the cost
+    of a collective beside the chain is mostly per collective, not per byte.
+    `every` > 1 (with k = 1) gathers only every n-th submitted step and always the last one before finish():
+    what a consumer that polls results at a lower rate than the chain produces them would ask for.
 
         pipe = GatherPipeline(n_frames, device)
         for step in ...:
             out, table = pipe.acquire()      # waits (stream-side) for the gather that last used them
             det.saddles_batch_enqueue_to(frames, out, table)
-            pipe.submit()                    # async gather of the packed slab to rank `dst`
+            pipe.submit()                    # async gather of the packed slab(s) to rank `dst`
         gathered = pipe.finish()             # on dst: (list_of_saddles, list_of_tables) of the LAST step
     """
 
     def __init__(self, n_frames, device, dst=0, group=None, depth=2, always_depth=False, slab_records=SLAB_RECORDS,
-                 force_collective=False, every=1):
+                 force_collective=False, every=1, steps_per_gather=1):
         # force_collective: a world of ONE rank still sends its slabs through the backend's gather (bench.py
         # --collective-world-1: what a one-GPU box can exercise of the nccl = RCCL path)
         self.dst, self.group = dst, group
@@ -84,49 +88,63 @@ class GatherPipeline:
         self.world = dist.get_world_size(group) if self.multi else 1
         self.rank = dist.get_rank(group) if self.multi else 0
         self.every = max(1, int(every))
-        # one rank alone needs a single buffer pair unless several batches are in flight (ChainPipeline)
-        packed = [alloc_packed(n_frames, device, slab_records) for _ in range(depth if (self.multi or always_depth) else 1)]
-        self.flat = [p[0] for p in packed]
-        self.bufs = [(p[1], p[2]) for p in packed]
+        self.k = max(1, int(steps_per_gather)) if self.multi else 1
+        assert self.every == 1 or self.k == 1, "gather every n-th step OR several steps per gather"
+        # one rank alone needs a single buffer unless several batches are in flight (ChainPipeline)
+        n_groups = depth if (self.multi or always_depth) else 1
+        slab = n_frames * 4 + n_frames * slab_records * 5  # floats of one packed slab
+        self.slab = slab
+        # a group = k slabs in one allocation (what one collective moves); bufs = the slabs' views in the order they are used
+        self.group_flat = [torch.zeros(self.k * slab, dtype=torch.float32, device=device) for _ in range(n_groups)]
+        self.flat = [g[j * slab:(j + 1) * slab] for g in self.group_flat for j in range(self.k)]
+        self.bufs = [split_packed(f, n_frames) for f in self.flat]
         self.recv = None
         if self.multi and self.rank == dst:
-            self.recv = [[torch.empty_like(f) for _ in range(self.world)] for f in self.flat]
-        self.works = [None] * len(self.bufs)
+            self.recv = [[torch.empty_like(g) for _ in range(self.world)] for g in self.group_flat]
+        self.works = [None] * n_groups
         self.i = -1
         self.submitted = 0
-        self.gathered_i = None  # buffer index of the last step that went through the gather
+        self.gathered_i = None  # slot index of the last step that went through a gather
 
     def acquire(self):
         self.i = (self.i + 1) % len(self.bufs)
-        w = self.works[self.i]
-        if w is not None:
-            w.wait()  # the current stream waits for the gather that was reading these buffers
-            self.works[self.i] = None
+        if self.i % self.k == 0:  # the first slab of a group: the gather that last read the group must be through
+            g = self.i // self.k
+            w = self.works[g]
+            if w is not None:
+                w.wait()  # the current stream waits for it
+                self.works[g] = None
         return self.bufs[self.i]
 
     def _gather(self):
-        f = self.flat[self.i]
-        self.works[self.i] = dist.gather(f, self.recv[self.i] if self.rank == self.dst else None, dst=self.dst, group=self.group,
-                                         async_op=True)
+        g = self.i // self.k
+        self.works[g] = dist.gather(self.group_flat[g], self.recv[g] if self.rank == self.dst else None, dst=self.dst,
+                                    group=self.group, async_op=True)
         self.gathered_i = self.i
 
     def submit(self):
         self.submitted += 1
-        if self.multi and self.submitted % self.every == 0:
+        if not self.multi:
+            return
+        if self.k > 1:
+            if self.i % self.k == self.k - 1:  # the group is full
+                self._gather()
+        elif self.submitted % self.every == 0:
             self._gather()
 
     def finish(self):
         if self.multi and self.gathered_i != self.i and self.i >= 0:
-            self._gather()  # (every > 1: the last step's results are always delivered)
+            self._gather()  # (a group that is not full yet / every > 1: the last step's results are always delivered)
         for w in self.works:
             if w is not None:
                 w.wait()
-        self.works = [None] * len(self.bufs)
+        self.works = [None] * len(self.works)
         if not self.multi:
             return [self.bufs[self.i][0]], [self.bufs[self.i][1]]
         if self.rank != self.dst:
             return None, None
-        views = [split_packed(f, self.n_frames) for f in self.recv[self.i]]
+        g, j = self.i // self.k, self.i % self.k
+        views = [split_packed(r[j * self.slab:(j + 1) * self.slab], self.n_frames) for r in self.recv[g]]
         return [v[0] for v in views], [v[1] for v in views]
 
 
@@ -144,7 +162,7 @@ class ChainPipeline:
     """
 
     def __init__(self, tag_family, n_frames, device, depth=2, params=None, dst=0, group=None, slab_records=SLAB_RECORDS,
-                 detector_cls=None, force_collective=False, gather_every=1):
+                 detector_cls=None, force_collective=False, gather_every=1, steps_per_gather=1):
         # detector_cls: a stand-in with TagDetector's enqueue interface (the CPU test of bench.py's N > 1 control flow)
         if detector_cls is None:
             from .detector import TagDetector
@@ -160,7 +178,10 @@ class ChainPipeline:
         self.streams = [torch.cuda.Stream(dev) for _ in range(self.depth)] if self.depth > 1 else [None]
         self.gather = GatherPipeline(n_frames, dev, dst=dst, group=group, depth=max(2, self.depth),
                                      always_depth=self.depth > 1, slab_records=slab_records, force_collective=force_collective,
-                                     every=gather_every)
+                                     every=gather_every,
+                                     # (several detectors in flight write their slabs on different streams: a gather of several
+                                     # slabs would have to wait for all of them -- one slab per gather there)
+                                     steps_per_gather=steps_per_gather if self.depth == 1 else 1)
         self.i = -1
         self.last_table = None
 

@@ -94,6 +94,10 @@ def parse_args():
     ap.add_argument("--gather-every", type=int, default=1,
                     help="N > 1: gather the result slabs to rank 0 every n-th step (and the last one) instead of every step; "
                          "the default -- and what the headline is quoted on -- is every step")
+    ap.add_argument("--gather-steps", type=int, default=4,
+                    help="N > 1: the result slabs of this many consecutive steps travel to rank 0 in ONE collective (every step's results "
+                         "are delivered, the fence sends a group that is not full; fewer, larger messages: one rank through nccl pays "
+                         "+18 us per step with 1, +11 with 4, +9 with 8 -- profiles/r5_gather_steps.txt); 1 = a collective per step")
     ap.add_argument("--pmc-traffic", type=float, default=None,
                     help="HBM bytes per K1 launch from a separate rocprofv3 --pmc run (profiles/)")
     return ap.parse_args()
@@ -614,7 +618,8 @@ def main():
     # collective of the path -- so the gather of a step overlaps the chain of the next.
     slab = 8192 if args.noise else sharding.SLAB_RECORDS  # pure noise: ~7100 saddles per 1280x800 frame
     pipe = sharding.ChainPipeline(A.TagFamily.T36H11, F, dev, depth=args.pipeline, dst=0, slab_records=slab,
-                                  detector_cls=rt.detector_cls, force_collective=coll1, gather_every=args.gather_every)
+                                  detector_cls=rt.detector_cls, force_collective=coll1, gather_every=args.gather_every,
+                                  steps_per_gather=args.gather_steps if args.gather_every <= 1 else 1)
 
     def step():
         pipe.submit(frames)
@@ -826,7 +831,7 @@ def main():
                 "frames_per_s": round(F * world * args.steps / dt, 1),
                 "saddles_per_frame": round(saddles_per_frame, 1),
                 "clusters_per_frame": round(clusters_per_frame, 1),
-                "parallelism": "frame-sharded x%d, RCCL gather of result slabs" % world if world > 1 else "1 GPU",
+                "parallelism": "frame-sharded x%d, RCCL gather of result slabs (%d steps per collective)" % (world, pipe.gather.k) if world > 1 else "1 GPU",
                 "batches_in_flight": pipe.depth,
                 "k1_rows_per_segment": rows_per_seg,
             },

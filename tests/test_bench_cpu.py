@@ -87,7 +87,7 @@ def test_bench_eight_rank_control_flow_under_gloo():
     assert out["n_gpus"] == 8 and out["steps"] == 2 and out["scaling"] == "weak" and out["backend"] == "cpu-stub"
     gc = out["gather_check"]
     assert gc["ranks"] == 8 and gc["frames"] == 2048 and gc["oracle_checked_remote_frames"] == 7 and gc["through_collective"] is True
-    assert out["config"]["frames_per_gpu"] == 256 and "x8" in out["config"]["parallelism"]
+    assert out["config"]["frames_per_gpu"] == 256 and "x8" in out["config"]["parallelism"] and "4 steps per collective" in out["config"]["parallelism"]
     # whole-job value: all eight ranks' pixels over the slowest rank's time
     assert abs(out["value"] - 8 * 256 * 192 * 128 * 2 / (out["ms_per_step"] * 2 * 1e-3) / 1e6) < 0.02 * out["value"]
 
@@ -99,3 +99,15 @@ def test_bench_gathers_every_nth_step_and_always_the_last():
                       "--no-extra", "--no-cpu-baseline", "--gather-every", "3"])
     gc = out["gather_check"]
     assert out["n_gpus"] == 3 and gc["ranks"] == 3 and gc["frames"] == 9 and gc["oracle_checked_remote_frames"] == 2
+
+
+def test_bench_one_collective_per_step_or_per_three():
+    """The default sends the slabs of four consecutive steps in one collective (the 2- and 8-rank tests above run it: the group that is
+    not full at a fence is sent by the fence).  Here: --gather-steps 1 (a collective per step) and 3, over 7 timed steps on 3 ranks;
+    rank 0 still finds every rank's LAST step complete and checks it like any other run."""
+    for k in ("1", "3"):
+        out = _launch(3, ["--steps", "7", "--warmup", "1", "--frames", "3", "--width", "192", "--height", "128", "--settle-ms", "0",
+                          "--no-extra", "--no-cpu-baseline", "--gather-steps", k])
+        gc = out["gather_check"]
+        assert out["n_gpus"] == 3 and gc["ranks"] == 3 and gc["frames"] == 9 and gc["oracle_checked_remote_frames"] == 2
+        assert ("%s steps per collective" % k) in out["config"]["parallelism"]

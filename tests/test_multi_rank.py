@@ -55,17 +55,23 @@ def _worker(rank, world, port, q):
     gs, gt = sharding.gather_results(saddles, table, dst=0)
     # the same through the double-buffered asynchronous pipeline bench.py uses: 3 "steps", the
     # buffers of the last one must arrive intact
-    pipe = sharding.GatherPipeline(FRAMES_PER_RANK, "cpu", dst=0)
-    for step in range(3):
-        ps, pt = pipe.acquire()
-        ps.zero_(); pt.zero_()
-        ps.copy_(saddles * (1.0 if step == 2 else 0.5))
-        pt.copy_(table)
-        pipe.submit()
-    ps_all, pt_all = pipe.finish()
-    if rank == 0:
-        for r in range(world):
-            assert torch.equal(pt_all[r], gt[r]) and torch.equal(ps_all[r], gs[r]), "pipeline gather differs"
+    # one slab per gather; several steps per gather with the last group full (k = 3, 6 steps), not full (k = 4: 5 and 9 steps:
+    # the second pass over the buffers), a single step; every n-th step
+    for kw, steps in (({}, 3), ({"steps_per_gather": 3}, 6), ({"steps_per_gather": 4}, 5), ({"steps_per_gather": 4}, 9),
+                      ({"steps_per_gather": 4}, 1), ({"every": 2}, 5)):
+        pipe = sharding.GatherPipeline(FRAMES_PER_RANK, "cpu", dst=0, **kw)
+        for step in range(steps):
+            ps, pt = pipe.acquire()
+            ps.zero_(); pt.zero_()
+            ps.copy_(saddles * (1.0 if step == steps - 1 else 0.5))  # only the LAST step carries the real records
+            pt.copy_(table)
+            pipe.submit()
+        ps_all, pt_all = pipe.finish()
+        if rank == 0:
+            for r in range(world):
+                assert torch.equal(pt_all[r], gt[r]) and torch.equal(ps_all[r], gs[r]), "pipeline gather differs (%s, %d steps)" % (kw, steps)
+        else:
+            assert ps_all is None and pt_all is None
     if rank == 0:
         frames = []
         for r in range(world):
