@@ -5,8 +5,8 @@ A "step" is one pass of the hot path (luma -> blur -> Hessian response -> min/th
 clustering -> rochade_refine -> k/phi filter, kernels K1..K4) over one batch of synthetic
 1280x800 u8 frames that is already resident in HBM.  N = 1 is BASELINE.json configs[1]
 (256 frames on one MI355X); N > 1 is configs[2]: every rank owns 256 frames (weak scaling,
-2048 frames on 8 GPUs) and the only collective is the per-step RCCL gather of the result
-slabs to rank 0.
+2048 frames on 8 GPUs) and the only collective is the RCCL gather of the result slabs to rank 0
+(every step's slab is delivered; --gather-steps consecutive steps share one collective).
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
