@@ -802,6 +802,9 @@ def main():
         roof["chain_frac"] = round(px_per_step_rank * a_design / step_s / 1e9 / HBM_PEAK_GBPS, 4)
         roof["a_min_bytes_per_px"] = a_min
         roof["a_min_frac"] = round(px_per_step_rank * a_min / step_s / 1e9 / HBM_PEAK_GBPS, 4)
+        if pipelined:  # the same over the step with several batches in flight (reported beside, never `value`)
+            pipelined["chain_frac"] = round(px_per_step_rank * a_design / (pipelined["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+            roof["chain_frac_in_flight"] = pipelined["chain_frac"]
         roof["chain_note"] = ("chain_frac = design bytes per GPU / ms_per_step / 8 TB/s (what the whole step achieves); frac = the blur "
                               "kernel alone; a_min_frac = the fused lower bound of SURVEY.md 8(d) over the same step time")
         if not serial:  # batches in flight: the timed launches shared the chip; the serial pass gives the kernel alone
