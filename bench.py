@@ -530,6 +530,25 @@ def detect_end_to_end_leg(torch, A, dev, n_frames, width, height, quick=False):
                     assert rc == 0 and (status == 0).all()
                 res["frames_per_s_" + fmt2] = round(n_frames / statistics.median(ts), 1)
                 del h2
+        if not quick:
+            # DetectorParams::max_num_of_boards = 1 (src/detector.rs:25-41; default 2): one board search per frame instead of two -- on
+            # frames that hold one board the second search (30 seeds that find nothing) is 95 % of the host tail.  Not the reference's
+            # default, so not the headline: what the path delivers when the host tail is cheap (the upload over PCIe then binds)
+            p1 = A.DetectorParams.default_params()
+            p1.max_num_of_boards = 1
+            det1 = A.TagDetector(A.TagFamily.T36H11, p1, device=dev.index)
+            try:
+                det1.detect_batch_raw(host[:64], n_threads=quota, cap=cap, out=out[:64], counts=counts[:64], status=status[:64])
+                ts = []
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    rc, _, _, _ = det1.detect_batch_raw(host, n_threads=quota, cap=cap, out=out, counts=counts, status=status)
+                    ts.append(time.perf_counter() - t0)
+                    assert rc == 0 and (status == 0).all()
+                res["frames_per_s_max_num_of_boards_1"] = round(n_frames / statistics.median(ts), 1)
+                res["tags_per_frame_max_num_of_boards_1"] = round(float(counts.mean()), 1)
+            finally:
+                det1.close()
         res["note"] = ("never `value`: set by the host tail (the reference's exhaustive board search, one frame per thread) and by the CPUs the box "
                        "gives the process (host_cpu_quota of the host_cores it shows: cgroup cpu.max); parallel_efficiency = frames/s over threads x the "
                        "1-thread rate; the chain alone delivers config.frames_per_s")
