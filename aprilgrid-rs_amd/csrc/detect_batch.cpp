@@ -12,6 +12,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <exception>
@@ -24,6 +25,7 @@
 #include "../../include/aprilgrid_amd.h"
 #include "detector_internal.h"
 #include "host_tail.hpp"
+#include "tail_kernels.h"
 
 namespace agx {
 
@@ -258,6 +260,184 @@ extern "C" int agx_detect_batch(agx_detector *det, const void *frames, const voi
     return rc;
 }
 
+// agx_detect_batch with option "device_tail": the board search and the decode run on the device behind the chain
+// (tail_kernels.hip); per chunk one wait, and a few KB of tags come back instead of the saddle lists.  Frames the kernel
+// hands back -- an angle comparison inside its guard band, a list beyond its fixed sizes -- take the host tail on the
+// pool, as every frame does without the option: the results are the host tail's either way.
+static int detect_batch_device_tail(agx_detector *det, const void *frames, const void *d_frames, int n_frames, int width, int height,
+                                    size_t row_stride_bytes, size_t frame_stride_bytes, int format, agx_tag *out,
+                                    uint32_t cap_per_frame, uint32_t *counts, int *frame_status, WorkerPool *pool)
+{
+    const FamilyInfo *fam = static_cast<const FamilyInfo *>(agx_internal_family(det));
+    const int max_boards = agx_internal_max_boards(det);
+    const int device = agx_internal_device(det);
+    constexpr int S = AGX_UPLOAD_STREAMS;
+    // a frame's search is one wave for a millisecond or two, whatever the number of frames beside it: chunks as large
+    // as the staging allows, several per call only so that the next one's upload runs under this one's kernels
+    const int chunk = std::max(1, std::min(n_frames, 256));
+    const int n_chunks = (n_frames + chunk - 1) / chunk;
+    const size_t chunk_bytes = (size_t)chunk * frame_stride_bytes;
+    uint8_t *d_stage = nullptr;
+    hipStream_t up[S] = {nullptr, nullptr, nullptr};
+    if (!d_frames) {
+        d_stage = static_cast<uint8_t *>(agx_internal_stage(det, (size_t)std::min(S, n_chunks) * chunk_bytes));
+        if (!d_stage) return AGX_ERR_HIP;
+        if (agx_internal_upload_streams(det, (void **)up) != 0) return AGX_ERR_HIP;
+    }
+    std::mutex m;
+    std::condition_variable cv;
+    std::vector<int> uploaded;  // per chunk: 0 pending, 1 on the device, -1 failed   (guarded by m)
+    std::atomic<int> first_bad{AGX_OK};
+    std::atomic<bool> nomem{false};
+    std::deque<std::vector<agx_saddle>> handed_back;  // saddle lists of frames for the host tail (alive until the pool is drained)
+    int rc = AGX_OK, n_fallback = 0, n_uncertain = 0;
+    bool pending_batch = false;
+    auto upload_task = [&, device](int ci) {
+        const int c0 = ci * chunk, nf = std::min(chunk, n_frames - c0), slot = ci % S;
+        const bool ok = hipSetDevice(device) == hipSuccess &&
+                        hipMemcpyAsync(d_stage + (size_t)slot * chunk_bytes, (const uint8_t *)frames + (size_t)c0 * frame_stride_bytes,
+                                       (size_t)nf * frame_stride_bytes, hipMemcpyHostToDevice, up[slot]) == hipSuccess &&
+                        hipStreamSynchronize(up[slot]) == hipSuccess;
+        {
+            std::lock_guard<std::mutex> lk(m);
+            uploaded[(size_t)ci] = ok ? 1 : -1;
+        }
+        cv.notify_all();
+    };
+    try {
+    uploaded.assign((size_t)n_chunks, 0);
+    if (!d_frames)
+        for (int ci = 0; ci < std::min(S, n_chunks); ++ci) pool->submit([&upload_task, ci] { upload_task(ci); });
+    std::vector<uint32_t> ns, offs;
+    std::vector<int> fst;
+    for (int ci = 0; ci < n_chunks; ++ci) {
+        const int c0 = ci * chunk, nf = std::min(chunk, n_frames - c0);
+        const uint8_t *h_chunk = (const uint8_t *)frames + (size_t)c0 * frame_stride_bytes;
+        const void *d_chunk;
+        if (!d_frames) {
+            std::unique_lock<std::mutex> lk(m);
+            cv.wait(lk, [&] { return uploaded[(size_t)ci] != 0; });
+            if (uploaded[(size_t)ci] < 0) { rc = AGX_ERR_HIP; break; }
+            d_chunk = d_stage + (size_t)(ci % S) * chunk_bytes;
+        } else {
+            d_chunk = (const uint8_t *)d_frames + (size_t)c0 * frame_stride_bytes;
+        }
+        rc = agx_saddles_batch_enqueue(det, d_chunk, nf, width, height, row_stride_bytes, frame_stride_bytes, format);
+        if (rc) break;
+        pending_batch = true;
+        const uint8_t *d_luma = static_cast<const uint8_t *>(d_chunk);  // detector.rs:507: L8 frames are their own u8 luma
+        size_t luma_row = row_stride_bytes, luma_frame = frame_stride_bytes;
+        if (format != AGX_L8) {
+            rc = agx_internal_chunk_luma8(det, d_chunk, nf, width, height, row_stride_bytes, frame_stride_bytes, format, 0, 1, (size_t)chunk,
+                                          nullptr, &d_luma);
+            if (rc) break;
+            luma_row = (size_t)width;
+            luma_frame = (size_t)width * (size_t)height;
+        }
+        rc = agx_internal_enqueue_tail(det, d_luma, luma_row, luma_frame, std::max(cap_per_frame, 1u));
+        if (rc) break;
+        const agx_tag *tags = nullptr;
+        const uint32_t *table = nullptr;
+        uint32_t tag_cap = 0;
+        rc = agx_internal_fetch_tail(det, &tags, &table, &tag_cap);  // waits for the device
+        if (rc) break;
+        bool any_back = false;
+        if (std::getenv("AGX_TAIL_DEBUG")) {
+            int h[32] = {0};
+            for (int f = 0; f < nf; ++f)
+                for (int b = 0; b < 32; ++b) h[b] += (table[2 * f + 1] >> b) & 1u;
+            for (int b = 0; b < 32; ++b)
+                if (h[b]) std::fprintf(stderr, "tail status bit %d: %d frames\n", b, h[b]);
+        }
+        for (int f = 0; f < nf; ++f) {
+            const int gf = c0 + f;
+            const uint32_t st = table[2 * f + 1], nt = table[2 * f];
+            if (st != TAIL_OK) {
+                any_back = true;
+                continue;
+            }
+            counts[gf] = nt;
+            int stf = AGX_OK;
+            if (nt > cap_per_frame) {  // (cannot happen: the kernel's own capacity is at most the caller's)
+                stf = AGX_ERR_CAPACITY;
+                int exp = AGX_OK;
+                first_bad.compare_exchange_strong(exp, stf);
+            } else if (nt) {
+                std::memcpy(out + (size_t)gf * cap_per_frame, tags + (size_t)f * tag_cap, (size_t)nt * sizeof(agx_tag));
+            }
+            if (frame_status) frame_status[gf] = stf;
+        }
+        if (any_back) {
+            // the saddle lists of the frames handed back (and the status of frames whose chain overflowed)
+            ns.resize((size_t)nf);
+            offs.resize((size_t)nf);
+            fst.resize((size_t)nf);
+            const agx_saddle *records = nullptr;
+            rc = agx_internal_fetch_compact(det, &records, ns.data(), offs.data(), fst.data());
+            pending_batch = false;
+            if (rc) break;
+            for (int f = 0; f < nf; ++f) {
+                if (table[2 * f + 1] == TAIL_OK) continue;
+                const int gf = c0 + f;
+                if (fst[(size_t)f] != AGX_OK) {  // reported, never truncated
+                    counts[gf] = 0;
+                    if (frame_status) frame_status[gf] = fst[(size_t)f];
+                    int exp = AGX_OK;
+                    first_bad.compare_exchange_strong(exp, fst[(size_t)f]);
+                    continue;
+                }
+                ++n_fallback;
+                n_uncertain += (table[2 * f + 1] & TAIL_UNCERTAIN) != 0;
+                handed_back.emplace_back(records + offs[(size_t)f], records + offs[(size_t)f] + ns[(size_t)f]);
+                const std::vector<agx_saddle> *list = &handed_back.back();
+                const uint8_t *img = h_chunk + (size_t)f * frame_stride_bytes;
+                pool->submit([=, &first_bad, &nomem] {
+                    try {
+                        std::vector<uint8_t> grey;  // to_luma8 of an L16 / RGB8 frame, on the host this time
+                        const uint8_t *g = img;
+                        size_t gstride = row_stride_bytes;
+                        if (format != AGX_L8) {
+                            grey.resize((size_t)width * (size_t)height);
+                            (void)luma8(img, width, height, row_stride_bytes, format, grey.data());
+                            g = grey.data();
+                            gstride = (size_t)width;
+                        }
+                        const std::vector<agx_tag> &tg = detect_tail_scratch(*fam, max_boards, list->data(), list->size(), g, width, height, gstride);
+                        int stf = AGX_OK;
+                        counts[gf] = (uint32_t)tg.size();
+                        if (tg.size() > cap_per_frame) {
+                            stf = AGX_ERR_CAPACITY;
+                            int exp = AGX_OK;
+                            first_bad.compare_exchange_strong(exp, stf);
+                        } else if (!tg.empty()) {
+                            std::memcpy(out + (size_t)gf * cap_per_frame, tg.data(), tg.size() * sizeof(agx_tag));
+                        }
+                        if (frame_status) frame_status[gf] = stf;
+                    } catch (...) {
+                        counts[gf] = 0;
+                        if (frame_status) frame_status[gf] = AGX_ERR_NOMEM;
+                        nomem.store(true);
+                    }
+                });
+            }
+        } else {
+            agx_internal_abandon_batch(det);  // (the stream is idle: the batch is done with)
+            pending_batch = false;
+        }
+        // chain, luma and tail have read the staging slot: the chunk S ahead may go up
+        if (!d_frames && ci + S < n_chunks) pool->submit_front([&upload_task, ci] { upload_task(ci + S); });
+    }
+    } catch (...) {
+        rc = AGX_ERR_NOMEM;
+    }
+    (void)pool->wait();
+    if (pending_batch) agx_internal_abandon_batch(det);
+    agx_internal_tail_stats(det, n_frames, n_fallback, n_uncertain);
+    if (rc) return rc;
+    if (nomem.load()) return AGX_ERR_NOMEM;
+    return first_bad.load();
+}
+
 static int detect_batch_impl(agx_detector *det, const void *frames, const void *d_frames, int n_frames, int width,
                              int height, size_t row_stride_bytes, size_t frame_stride_bytes, int format, agx_tag *out,
                              uint32_t cap_per_frame, uint32_t *counts, int *frame_status, int n_threads)
@@ -280,6 +460,9 @@ static int detect_batch_impl(agx_detector *det, const void *frames, const void *
     const int max_boards = agx_internal_max_boards(det);
     if (hipSetDevice(agx_internal_device(det)) != hipSuccess) return AGX_ERR_HIP;
     const int device = agx_internal_device(det);
+    if (agx_internal_device_tail(det))
+        return detect_batch_device_tail(det, frames, d_frames, n_frames, width, height, row_stride_bytes, frame_stride_bytes, format, out,
+                                        cap_per_frame, counts, frame_status, pool);
 
     // Chunks of about one frame per worker (8 .. 64): the chain of a chunk takes 0.1 ms on the device, a frame's board
     // search about a millisecond on a host thread, so small chunks cost nothing and the workers start after the first 8 .. 64 frames
@@ -353,7 +536,7 @@ static int detect_batch_impl(agx_detector *det, const void *frames, const void *
         const uint8_t *h_luma = nullptr;
         if (format != AGX_L8) {
             rc = agx_internal_chunk_luma8(det, d_chunk, nf, width, height, row_stride_bytes, frame_stride_bytes, format, r, R,
-                                          (size_t)chunk, &h_luma);
+                                          (size_t)chunk, &h_luma, nullptr);
             if (rc) break;
         }
         Slot &sl = slots[(size_t)r];

@@ -18,6 +18,7 @@
 #include "chain_kernels.h"
 #include "detector_internal.h"
 #include "host_tail.hpp"
+#include "tail_kernels.h"
 
 using namespace agx;
 
@@ -112,6 +113,16 @@ struct agx_detector {
     void *pool = nullptr;  // agx_detect_batch: worker threads of the host tail
     int pool_threads = 0;
     std::vector<agx_saddle> scratch_saddles;  // host staging of agx_detect / agx_detect_planes (reused)
+
+    // option "device_tail": agx_detect_batch's board search + decode on the device (tail_kernels.hip); frames the kernel
+    // hands back (TAIL_UNCERTAIN / TAIL_CAPACITY) take the host tail
+    int device_tail = 0;
+    uint64_t *d_codes = nullptr;                                     // the family's code list
+    agx_tag *h_tags = nullptr, *h_tags_dev = nullptr;                // mapped pinned [tail_frames][tail_tag_cap]
+    uint32_t *h_tail_table = nullptr, *h_tail_table_dev = nullptr;   // mapped pinned [tail_frames][2]: count, status
+    size_t tail_frames = 0;
+    uint32_t tail_tag_cap = 0;
+    int last_tail_frames = 0, last_tail_fallbacks = 0, last_tail_uncertain = 0;  // of the last agx_detect_batch call
 
     std::string last_error;
 };
@@ -534,7 +545,8 @@ __attribute__((visibility("hidden"))) void *agx_internal_pool(agx_detector *det,
 __attribute__((visibility("hidden"))) int agx_internal_chunk_luma8(agx_detector *det, const void *d_frames, int n_frames,
                                                                    int width, int height, size_t row_stride,
                                                                    size_t frame_stride, int format, int slot, int n_slots,
-                                                                   size_t chunk_capacity_frames, const uint8_t **h_out)
+                                                                   size_t chunk_capacity_frames, const uint8_t **h_out,
+                                                                   const uint8_t **d_out)
 {
     const size_t plane = (size_t)width * (size_t)height, one = plane * chunk_capacity_frames;
     if (slot < 0 || slot >= n_slots) return AGX_ERR_ARG;
@@ -550,6 +562,8 @@ __attribute__((visibility("hidden"))) int agx_internal_chunk_luma8(agx_detector 
     }
     uint8_t *d = det->d_luma + (size_t)slot * one, *h = det->h_luma + (size_t)slot * one;
     if (launch_luma8(d_frames, row_stride, frame_stride, n_frames, format, d, width, height, det->stream) != 0) return AGX_ERR_HIP;
+    if (d_out) *d_out = d;  // (the device tail reads it there; no copy to the host unless asked for)
+    if (!h_out) return AGX_OK;
     if (hipMemcpyAsync(h, d, plane * (size_t)n_frames, hipMemcpyDeviceToHost, det->stream) != hipSuccess) return AGX_ERR_HIP;
     *h_out = h;
     return AGX_OK;
@@ -594,6 +608,72 @@ __attribute__((visibility("hidden"))) int agx_internal_fetch_compact(agx_detecto
     }
     *records = reinterpret_cast<const agx_saddle *>(det->h_out);
     det->last_error.clear();
+    return AGX_OK;
+}
+// agx_detect_batch with option "device_tail": the board search + decode of the batch that was just enqueued, behind it on
+// the detector's stream.  d_luma = the frames' u8 luma in device memory (L8 frames: the frames themselves).  Results go to
+// mapped pinned host memory; agx_internal_fetch_tail waits for them.
+__attribute__((visibility("hidden"))) int agx_internal_device_tail(const agx_detector *det) { return det->device_tail; }
+__attribute__((visibility("hidden"))) void agx_internal_tail_stats(agx_detector *det, int frames, int fallbacks, int uncertain)
+{
+    det->last_tail_frames = frames;
+    det->last_tail_fallbacks = fallbacks;
+    det->last_tail_uncertain = uncertain;
+}
+__attribute__((visibility("hidden"))) int agx_internal_enqueue_tail(agx_detector *det, const void *d_luma, size_t luma_row_stride,
+                                                                    size_t luma_frame_stride, uint32_t tag_cap)
+{
+    if (!det->enqueued || det->external_out) return AGX_ERR_STATE;
+    const ChainArgs &a = det->args;
+    if (tag_cap == 0 || luma_row_stride > 0x7fffffffu) return AGX_ERR_ARG;
+    if (tag_cap > 128u) tag_cap = 128u;  // (the kernel's own list of distinct ids; frames beyond it take the host tail)
+    if (!det->d_codes) {
+        if (hipMalloc((void **)&det->d_codes, (size_t)det->fam.n_codes * sizeof(uint64_t)) != hipSuccess) return AGX_ERR_HIP;
+        if (hipMemcpy(det->d_codes, det->fam.codes, (size_t)det->fam.n_codes * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess) return AGX_ERR_HIP;
+        if (init_tail_kernels() != 0) return AGX_ERR_HIP;
+    }
+    if ((size_t)a.n_frames > det->tail_frames || tag_cap > det->tail_tag_cap) {
+        if (hipStreamSynchronize(det->stream) != hipSuccess) return AGX_ERR_HIP;
+        if (det->h_tags) (void)hipHostFree(det->h_tags);
+        if (det->h_tail_table) (void)hipHostFree(det->h_tail_table);
+        det->h_tags = det->h_tags_dev = nullptr;
+        det->h_tail_table = det->h_tail_table_dev = nullptr;
+        det->tail_frames = 0;
+        const size_t F = std::max((size_t)a.n_frames, det->tail_frames), cap = std::max(tag_cap, det->tail_tag_cap);
+        if (hipHostMalloc((void **)&det->h_tags, F * cap * sizeof(agx_tag), hipHostMallocMapped) != hipSuccess) return AGX_ERR_HIP;
+        if (hipHostMalloc((void **)&det->h_tail_table, F * 2 * sizeof(uint32_t), hipHostMallocMapped) != hipSuccess) return AGX_ERR_HIP;
+        if (hipHostGetDevicePointer((void **)&det->h_tags_dev, det->h_tags, 0) != hipSuccess) return AGX_ERR_HIP;
+        if (hipHostGetDevicePointer((void **)&det->h_tail_table_dev, det->h_tail_table, 0) != hipSuccess) return AGX_ERR_HIP;
+        det->tail_frames = F;
+        det->tail_tag_cap = (uint32_t)cap;
+    }
+    TailArgs t{};
+    t.saddles = a.out;
+    t.ctr = a.ctr;
+    t.n_frames = a.n_frames;
+    t.luma = static_cast<const uint8_t *>(d_luma);
+    t.luma_frame_stride = (long long)luma_frame_stride;
+    t.luma_row_stride = (int)luma_row_stride;
+    t.W = a.W;
+    t.H = a.H;
+    t.edge = det->fam.edge;
+    t.border = det->fam.border;
+    t.hamming = det->fam.hamming;
+    t.n_codes = det->fam.n_codes;
+    t.codes = det->d_codes;
+    t.max_boards = det->params.max_num_of_boards;
+    t.tags = det->h_tags_dev;
+    t.table = det->h_tail_table_dev;
+    t.tag_cap = det->tail_tag_cap;
+    if (launch_board_tail(t, det->stream) != 0) return AGX_ERR_HIP;
+    return AGX_OK;
+}
+__attribute__((visibility("hidden"))) int agx_internal_fetch_tail(agx_detector *det, const agx_tag **tags, const uint32_t **table, uint32_t *tag_cap)
+{
+    if (hipStreamSynchronize(det->stream) != hipSuccess) return AGX_ERR_HIP;
+    *tags = det->h_tags;
+    *table = det->h_tail_table;
+    *tag_cap = det->tail_tag_cap;
     return AGX_OK;
 }
 __attribute__((visibility("hidden"))) void agx_internal_abandon_batch(agx_detector *det)
@@ -744,6 +824,9 @@ void agx_detector_destroy(agx_detector *det)
     if (det->d_luma) (void)hipFree(det->d_luma);
     if (det->h_luma) (void)hipHostFree(det->h_luma);
     if (det->h_table) (void)hipHostFree(det->h_table);
+    if (det->d_codes) (void)hipFree(det->d_codes);
+    if (det->h_tags) (void)hipHostFree(det->h_tags);
+    if (det->h_tail_table) (void)hipHostFree(det->h_tail_table);
     if (det->d_dbg_resp) (void)hipFree(det->d_dbg_resp);
     if (det->d_resp_store) (void)hipFree(det->d_resp_store);
     for (int i = 0; i < AGX_UPLOAD_STREAMS; ++i)
@@ -803,6 +886,19 @@ int agx_detector_set_option(agx_detector *det, const char *name, int value)
     else if (!std::strcmp(name, "store_response")) det->store_resp = value != 0;
     else if (!std::strcmp(name, "profile_stride")) det->prof_stride = value > 1 ? value : 1;
     else if (!std::strcmp(name, "profile_kernel")) det->prof_kernel = value >= 0 && value < K_COUNT ? value : K_BLUR_HESSIAN;
+    else if (!std::strcmp(name, "device_tail")) {
+        // the device evaluates angle_degree's atan2f by glibc's routine (libm_f32.h): offered only where this process's atan2f IS
+        // that routine -- checked once per process on 2^20 operand pairs (10^8 in tests/test_abi_cpu.py's long form)
+        if (value != 0) {
+            static const uint64_t mismatches = libm_atan2f_mismatches(1u << 20, 1);
+            if (mismatches) {
+                det->device_tail = 0;
+                return fail(det, AGX_ERR_STATE, "device_tail: this C library's atan2f is not the routine the device tail restates (" +
+                                                    std::to_string(mismatches) + " of 2^20 inputs differ); the host tail stays in use");
+            }
+        }
+        det->device_tail = value != 0;
+    }
     else if (!std::strcmp(name, "reload_tuning_env")) tuning_env_reload();  // (process-wide: the AGX_* overrides are read again)
     else if (!std::strcmp(name, "tail_threads")) {
         const int n = value < 1 ? 1 : (value > 64 ? 64 : value);
@@ -827,6 +923,10 @@ int agx_detector_get_option(const agx_detector *det, const char *name, int *valu
     else if (!std::strcmp(name, "store_response")) *value = det->store_resp;
     else if (!std::strcmp(name, "debug_ablation")) *value = det->dbg;
     else if (!std::strcmp(name, "tail_threads")) *value = det->tail_threads;
+    else if (!std::strcmp(name, "device_tail")) *value = det->device_tail;
+    else if (!std::strcmp(name, "last_device_tail_frames")) *value = det->last_tail_frames;
+    else if (!std::strcmp(name, "last_device_tail_fallbacks")) *value = det->last_tail_fallbacks;
+    else if (!std::strcmp(name, "last_device_tail_uncertain")) *value = det->last_tail_uncertain;  // (of them: an angle inside its guard band)
     // the blur kernel's tiling of the last enqueued batch (0 before the first one)
     else if (!std::strcmp(name, "k1_rows_per_segment")) *value = a.rows_per_seg;
     else if (!std::strcmp(name, "sparse_path")) *value = det->sparse_path;
@@ -1125,6 +1225,15 @@ int agx_debug_angle_pairs_coarse(const float *vectors, size_t n, float *coarse, 
     return agx_guard(nullptr, [&]() -> int {
     if (!vectors || !coarse || !has_coarse) return AGX_ERR_ARG;
     debug_angle_pairs(vectors, n, nullptr, nullptr, nullptr, coarse, has_coarse);
+    return AGX_OK;
+    });
+}
+
+int agx_debug_libm_atan2f_check(uint64_t n, uint64_t seed, uint64_t *mismatches)
+{
+    return agx_guard(nullptr, [&]() -> int {
+    if (!mismatches) return AGX_ERR_ARG;
+    *mismatches = libm_atan2f_mismatches(n, seed);
     return AGX_OK;
     });
 }

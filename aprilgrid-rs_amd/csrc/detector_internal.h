@@ -23,10 +23,16 @@ int agx_internal_upload_streams(agx_detector *det, void **streams /* [AGX_UPLOAD
 // the staging is a ring of n_slots chunks of chunk_capacity_frames
 int agx_internal_chunk_luma8(agx_detector *det, const void *d_frames, int n_frames, int width, int height, size_t row_stride,
                              size_t frame_stride, int format, int slot, int n_slots, size_t chunk_capacity_frames,
-                             const uint8_t **h_out);
+                             const uint8_t **h_out, const uint8_t **d_out);  // (h_out null: no copy to the host; d_out: where it is on the device)
 // the last batch's compact list in the detector's pinned host mirror (valid until the next enqueue) + per-frame
 // counts / offsets / status; waits for the device
 int agx_internal_fetch_compact(agx_detector *det, const agx_saddle **records, uint32_t *counts, uint32_t *offsets, int *status);
+// option "device_tail": board search + decode of the enqueued batch on the device (tail_kernels.hip); the results in mapped
+// pinned host memory after agx_internal_fetch_tail: tags[f * tag_cap ..], table[2 f] = count, table[2 f + 1] = agx::TAIL_* status
+int agx_internal_device_tail(const agx_detector *det);
+int agx_internal_enqueue_tail(agx_detector *det, const void *d_luma, size_t luma_row_stride, size_t luma_frame_stride, uint32_t tag_cap);
+int agx_internal_fetch_tail(agx_detector *det, const agx_tag **tags, const uint32_t **table, uint32_t *tag_cap);
+void agx_internal_tail_stats(agx_detector *det, int frames, int fallbacks, int uncertain);
 }
 namespace agx {
 void destroy_worker_pool(void *pool);

@@ -4,6 +4,7 @@
 // saddles per frame.  Decisions here depend on f32 comparisons, so the f32 expressions keep
 // the reference's operand order and this file is compiled with -ffp-contract=off.
 #include "host_tail.hpp"
+#include "libm_f32.h"
 
 #ifdef AGX_TAIL_PROFILE
 #include <chrono>
@@ -227,6 +228,54 @@ static inline bool quad_rest(const agx_saddle &s0, const agx_saddle &d0, const a
     if (angles_differ_by_more_than(a1, a3, 10.0f)) return false;
     if (dot2(v01x, v01y, v02x, v02y) < 0.0f || dot2(v03x, v03y, v02x, v02y) < 0.0f) return false;
     return true;
+}
+
+// How many of n pseudo-random operand pairs (all bit patterns, image-sized products, ratios around the reduction's
+// interval ends, the special cases) this process's atan2f and libm_f32.h's restatement of glibc's routine disagree on.
+// The device tail (tail_kernels.hip) evaluates angle_degree with the restatement: it is offered only where this is 0.
+uint64_t libm_atan2f_mismatches(uint64_t n, uint64_t seed)
+{
+    uint64_t state = seed * 0x9E3779B97F4A7C15ull + 0x243F6A8885A308D3ull, bad = 0;
+    auto next = [&]() {  // splitmix64
+        uint64_t z = (state += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    };
+    auto differ = [](float y, float x) {
+        const float a = std::atan2(y, x), b = fdlibm_atan2f(y, x);
+        return f32_bits(a) != f32_bits(b) && !(a != a && b != b);
+    };
+    const float special[] = {0.0f, -0.0f, 1.0f, -1.0f, INFINITY, -INFINITY, NAN, 1e-40f, -1e-40f, 3e38f, 0.4375f, 0.6875f, 1.1875f, 2.4375f};
+    for (float a : special)
+        for (float b : special) bad += differ(a, b);
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint64_t r = next(), q = next();
+        float y, x;
+        switch (i & 3) {
+        case 0: y = f32_from_bits((uint32_t)r); x = f32_from_bits((uint32_t)(r >> 32)); break;  // any two floats
+        case 1:  // cross and dot products of vectors between image points
+        case 2: {
+            const float ax = (float)(int32_t)(r & 0xfff) - 2048.0f + (float)((r >> 12) & 0xffff) / 65536.0f;
+            const float ay = (float)(int32_t)((r >> 28) & 0xfff) - 2048.0f + (float)((r >> 40) & 0xffff) / 65536.0f;
+            const float bx = (float)(int32_t)(q & 0xfff) - 2048.0f + (float)((q >> 12) & 0xffff) / 65536.0f;
+            const float by = (float)(int32_t)((q >> 28) & 0xfff) - 2048.0f + (float)((q >> 40) & 0xffff) / 65536.0f;
+            y = by * ax - bx * ay;
+            x = ax * bx + ay * by;
+            break;
+        }
+        default: {  // ratios near the ends of the reduction intervals
+            const float ends[] = {0.4375f, 0.6875f, 1.1875f, 2.4375f, 1.0f};
+            x = 1.0f + (float)(r & 0xffffff) / 16777216.0f;
+            y = x * ends[(r >> 24) % 5] * (1.0f + ((float)(int32_t)(q & 0xff) - 128.0f) * 5.9604645e-8f);
+            if (q >> 63) y = -y;
+            if ((q >> 62) & 1) x = -x;
+            break;
+        }
+        }
+        bad += differ(y, x);
+    }
+    return bad;
 }
 
 void debug_angle_pairs(const float *v, size_t n, float *exact, float *approx, uint8_t *has_approx, float *coarse, uint8_t *has_coarse)

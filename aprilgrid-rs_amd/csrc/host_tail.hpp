@@ -30,6 +30,9 @@ float angle_degree(float v0x, float v0y, float v1x, float v1y);
 // (coarse / has_coarse, optional: the cheaper first-level approximation and where it is used)
 void debug_angle_pairs(const float *v, size_t n, float *exact, float *approx, uint8_t *has_approx, float *coarse = nullptr,
                        uint8_t *has_coarse = nullptr);
+// this process's atan2f against libm_f32.h's restatement of glibc's routine on n pseudo-random operand pairs + the special
+// cases: the number of disagreements (the device tail is offered only where it is 0)
+uint64_t libm_atan2f_mismatches(uint64_t n, uint64_t seed);
 // saddle.rs:17-67
 bool is_valid_quad(const agx_saddle &s0, const agx_saddle &d0, const agx_saddle &s1, const agx_saddle &d1);
 

@@ -362,6 +362,11 @@ int agx_debug_angle_pairs(const float *vectors, size_t n, float *exact, float *a
 /* The coarser first-level approximation in front of it (a three-term polynomial in float, max error 0.04 degrees, guard band
  * 0.1): most of the search's ~16 000 angle comparisons per frame are decided from it.  Same hook, same check. */
 int agx_debug_angle_pairs_coarse(const float *vectors, size_t n, float *coarse, uint8_t *has_coarse);
+/* Test hook of the device tail (option "device_tail"): the kernel evaluates angle_degree's atan2f by glibc's own
+ * single-precision routine, restated (csrc/libm_f32.h).  *mismatches = on how many of n pseudo-random operand pairs (any two
+ * floats, cross / dot products of image-sized vectors, ratios at the ends of the routine's reduction intervals, plus the
+ * special cases) this process's atan2f disagrees with the restatement; the option is refused unless that is 0. */
+int agx_debug_libm_atan2f_check(uint64_t n, uint64_t seed, uint64_t *mismatches);
 int agx_debug_fetch(agx_detector *det, int frame, int what, void *host_out, size_t cap_bytes,
                     size_t *n_items);
 
