@@ -38,6 +38,7 @@ struct TailArgs {
     agx_tag *tags;
     uint32_t *table;
     uint32_t tag_cap;
+    int debug;  // AGX_TAIL_DEBUG >= 2: frame 0's wave prints where its time went (100 MHz ticks)
 };
 
 // Enqueue the device tail of the batch on `stream`; hipError_t.

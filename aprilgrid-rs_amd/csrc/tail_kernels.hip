@@ -3,9 +3,9 @@
 // What the reference does after refined_saddle_points (src/detector.rs:510-539): up to max_num_of_boards rounds of
 // try_find_best_board (:588-639; init_quads :543-586, board::Board src/board.rs, is_valid_quad src/saddle.rs:17-67) and
 // try_decode_quad (:448-476) over a few hundred saddles per frame.  The chain leaves those saddles in device memory; this
-// kernel runs the same search there, one wave per frame, so that a batch's tags -- a few KB -- are all that crosses PCIe and
-// no host thread spends a millisecond per frame on it (host_tail.cpp is the same algorithm on the host and stays the
-// reference-exact arbiter, below).
+// kernel runs the same search there, one workgroup per frame, so that a batch's tags -- a few KB -- are all that crosses
+// PCIe and no host thread spends a millisecond per frame on it (host_tail.cpp is the same algorithm on the host and stays
+// the reference-exact arbiter, below).
 //
 // Exactness.  Everything the search decides on is binary32 arithmetic in the reference's operand order (this file is
 // compiled with -ffp-contract=off like the chain), integer work, or one of three libm calls: atan2f (angle_degree,
@@ -19,12 +19,19 @@
 // itself).  So do frames beyond the fixed list sizes (TAIL_CAPACITY).  A frame the kernel reports TAIL_OK for has the host
 // tail's tags, bit for bit (tests/test_gpu_device_tail.py).
 //
-// Mapping.  One 64-lane workgroup (one wave) per frame; the frame's saddles, a uniform-grid index for the 3-NN queries
-// of find_closest_potential_saddle_idxs (src/board.rs:177-233), the candidate quads of the current seed and the boards
-// under construction live in LDS (~70 KB: two frames per CU).  The phases of a seed -- 50-NN (bitonic sort of the distance
-// keys), the same / different orientation lists, the candidate quads (lanes over the (d0, d1) combinations, written in the
-// reference's order by ballot + prefix count) -- are wave-parallel; the boards of a seed's candidate quads are built SIXTEEN
-// AT A TIME, one lane each (board.rs's recursion as an explicit stack in the lane's LDS slot), which is where the time goes.
+// Mapping.  One workgroup of four waves per frame; the frame's saddles and a uniform-grid index for the 3-NN queries of
+// find_closest_potential_saddle_idxs (src/board.rs:177-233) are shared in LDS, every wave has its own candidate list and
+// board (~75 KB per frame: two frames per CU).
+//   seeds     the waves take the seeds of try_find_best_board four at a time, one each; what a seed contributes to the
+//             sequential loop (:613-629) is its best score and the first quad that reaches it, so the merge walks the four
+//             results in the reference's order with the reference's rules (strict improvement, stop at >= 36, 30 seeds) --
+//             as host_tail.cpp's find_best_board_parallel does on threads;
+//   init_quads  50-NN by a bitonic sort of the distance keys; the same / different orientation lists and the (d0, d1)
+//             combinations by ballot + prefix count, in the reference's order; is_valid_quad per lane;
+//   a board   is grown by the whole wave: board.rs's recursion is a stack walked in lock step, the four 3-NN queries of a
+//             try_expand_one run on 16 lanes each over the grid cells their radius reaches, its up to 81 candidate
+//             quadruples are tested one per lane and the first valid one in the reference's loop order is taken;
+//   the rest  (try_fix_missing, decode, the tag map, removing the used saddles) on the first wave.
 #include <hip/hip_runtime.h>
 
 #include "libm_f32.h"
@@ -36,7 +43,7 @@ namespace {
 constexpr int TN = TAIL_MAX_SADDLES;
 constexpr int TGC = 1024;    // cells of the k-NN grid
 constexpr int TCAND = 1024;  // candidate quads of one seed
-constexpr int TB = 16;       // boards built side by side
+constexpr int TW = 4;        // waves per frame
 constexpr int BCELLS = 128;  // cells (found or not) of one board
 constexpr int BGR = 12, BGN = 2 * BGR + 1;  // board cells live within +-BGR of the seed's cell
 constexpr int TTAGS = 128;   // distinct tag ids of one frame
@@ -48,27 +55,31 @@ constexpr int SL_FOUND = 1280;   // u8[BCELLS]
 constexpr int SL_GRID = 1408;    // u8[BGN * BGN] cell coordinates -> cell number (0xff none)
 constexpr int SL_ACTIVE = 2048;  // u32[TN / 32]: board.rs active_idxs
 constexpr int SL_STACK = 2112;   // u8[BCELLS][2]: cell, next direction
-constexpr int SL_TMP = 2368;     // u16[12]: the candidate lists of try_expand_one
-constexpr int SL_BYTES = 2396;   // 599 dwords (odd: the slots of neighbouring lanes start in different banks)
+constexpr int SL_BYTES = 2368;
 static_assert(BGN * BGN <= SL_ACTIVE - SL_GRID, "board grid");
 static_assert(TN / 8 <= SL_STACK - SL_ACTIVE, "active mask");
 
-// the wave's LDS (bytes)
+// a wave's own LDS (bytes)
+constexpr int WV_CAND = 0;                      // u64[TCAND]; also u64[TN] distance keys; wave 0: u32[2 * TGC] while the grid is built, decode results
+constexpr int WV_PAIRS = WV_CAND + TCAND * 8;   // u16[1176 + pad]
+constexpr int WV_SMALL = WV_PAIRS + 1184 * 2;   // u16[3][64]: same, diff, the white-block test per s1
+constexpr int WV_SLOT = WV_SMALL + 384;         // the board under construction
+constexpr int WV_BYTES = WV_SLOT + SL_BYTES;
+static_assert(WV_BYTES % 8 == 0, "alignment");
+// the frame's LDS (bytes)
 constexpr int OFF_SX = 0, OFF_SY = OFF_SX + TN * 4, OFF_ST = OFF_SY + TN * 4;
 constexpr int OFF_GX = OFF_ST + TN * 4, OFF_GY = OFF_GX + TN * 4, OFF_GI = OFF_GY + TN * 4;
 constexpr int OFF_GSTART = OFF_GI + TN * 2;                // u16[TGC + 1]
 constexpr int OFF_SEEDS = OFF_GSTART + (TGC + 4) * 2;      // u16[TN]
-constexpr int OFF_CAND = OFF_SEEDS + TN * 2;               // u64[TCAND]; also: u32[2 * TGC] while the grid is built, u64[TN] distance keys,
-                                                           // decode results
-constexpr int OFF_PAIRS = OFF_CAND + TCAND * 8;            // u16[1176 + pad]
-constexpr int OFF_SMALL = OFF_PAIRS + 1184 * 2;            // u16[4][64]: same, diff, s1 that pass part 1, spare
-constexpr int OFF_QUADS = OFF_SMALL + 512;                 // u64[BCELLS]
+constexpr int OFF_QUADS = OFF_SEEDS + TN * 2;              // u64[BCELLS]
 constexpr int OFF_TAGIDS = OFF_QUADS + BCELLS * 8;         // u32[TTAGS]
 constexpr int OFF_USED = OFF_TAGIDS + TTAGS * 4;           // u32[TN / 32]
 constexpr int OFF_HIST = OFF_USED + TN / 8;                // u32[364]
-constexpr int OFF_BOARDS = OFF_HIST + 364 * 4;             // (TB + 1) slots: the last one keeps the best board's cells
-constexpr int LDS_BYTES = OFF_BOARDS + (TB + 1) * SL_BYTES;
-static_assert(OFF_CAND % 8 == 0 && OFF_QUADS % 8 == 0 && OFF_BOARDS % 4 == 0, "alignment");
+constexpr int OFF_SHARED = OFF_HIST + 364 * 4;             // u32[16] + u64[TW]: what the waves tell each other
+constexpr int OFF_BEST = OFF_SHARED + 64 + TW * 8;         // the chosen board
+constexpr int OFF_WAVES = OFF_BEST + SL_BYTES;
+constexpr int LDS_BYTES = OFF_WAVES + TW * WV_BYTES;
+static_assert(OFF_QUADS % 8 == 0 && OFF_SHARED % 8 == 0 && OFF_BEST % 8 == 0 && OFF_WAVES % 8 == 0, "alignment");
 
 constexpr float kPiF = 3.14159274101257324219f;
 // The white-block angle: cosf / sinf within 1 ulp move the direction by < 1.2e-7 rad (7e-6 degrees), the reference's six
@@ -77,6 +88,7 @@ constexpr float kPiF = 3.14159274101257324219f;
 constexpr double kBandAbs = 1e-4;
 constexpr double kDegD = 180.0 / (double)kPiF;
 typedef unsigned long long u64;
+
 
 struct Ctx {
     const float *sx, *sy, *st;
@@ -139,25 +151,6 @@ __device__ __forceinline__ u64 dist_key(float qx, float qy, float px, float py, 
     return (u64)__float_as_uint(d2) << 32 | idx;
 }
 
-// The three nearest saddles of (qx, qy) among those within r2, ascending (distance, index) -- which is what
-// tree.nearest(.., 3, ..) filtered by `dist_sq <= radius_sq` leaves (board.rs:193-212): a saddle within the radius that
-// is among the three nearest of all is among the three nearest of those within the radius, and the other way round.
-// Only the grid cells the radius reaches are looked at.
-__device__ __forceinline__ void nn3_within(const Ctx &c, float qx, float qy, float r2, u64 &k0, u64 &k1, u64 &k2)
-{
-    k0 = k1 = k2 = ~0ull;
-    const float r = sqrtf(r2) * 1.0001f + 1e-3f;
-    if (!(r < 3e38f)) {  // (not on image coordinates) everything
-        for (int t = 0; t < c.n; ++t) top3_insert(dist_key(qx, qy, c.gx[t], c.gy[t], c.gi[t]), k0, k1, k2);
-        return;
-    }
-    const int xa = cell_x(c, qx - r), xb = cell_x(c, qx + r), ya = cell_y(c, qy - r), yb = cell_y(c, qy + r);
-    for (int y = ya; y <= yb; ++y) {
-        const int t0 = c.gstart[y * c.nx + xa], t1 = c.gstart[y * c.nx + xb + 1];
-        for (int t = t0; t < t1; ++t) top3_insert(dist_key(qx, qy, c.gx[t], c.gy[t], c.gi[t]), k0, k1, k2);
-    }
-}
-
 __device__ __forceinline__ float angle_degree(float v0x, float v0y, float v1x, float v1y)  // math_util.rs:31-33
 {
     return fdlibm_atan2f(v1y * v0x - v1x * v0y, v0x * v1x + v0y * v1y) * 180.0f / kPiF;
@@ -208,7 +201,52 @@ __device__ int valid_quad(const Ctx &c, int i0, int i1, int i2, int i3)
     return white_block(c.st[i0], c.sx[i2] - c.sx[i0], c.sy[i2] - c.sy[i0]);
 }
 
-// ---- a board in a lane's LDS slot --------------------------------------------------------------------------------
+
+// ---- wave helpers ---------------------------------------------------------------------------------------------------
+
+// LDS written by some lanes of this wave, read by others: order the accesses (the waves of a frame run apart between the
+// workgroup barriers, so this is not __syncthreads)
+__device__ __forceinline__ void wsync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ float wave_min_f(float v)
+{
+    for (int o = 32; o; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_max_f(float v)
+{
+    for (int o = 32; o; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u(uint32_t v)
+{
+    for (int o = 32; o; o >>= 1) {
+        const uint32_t w = (uint32_t)__shfl_xor((int)v, o);
+        v = w > v ? w : v;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_or_u(uint32_t v)
+{
+    for (int o = 32; o; o >>= 1) v |= (uint32_t)__shfl_xor((int)v, o);
+    return v;
+}
+__device__ __forceinline__ u64 shfl_u64(u64 v, int src)
+{
+    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src), hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), src);
+    return (u64)hi << 32 | lo;
+}
+__device__ __forceinline__ u64 shfl_xor_u64(u64 v, int mask)
+{
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, mask), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), mask);
+    return (u64)hi << 32 | lo;
+}
+
+// ---- a board, grown by the whole wave (its slot in LDS) -----------------------------------------------------------
 
 __device__ __forceinline__ u64 slot_quad(const uint8_t *slot, int cell)
 {
@@ -232,132 +270,160 @@ __device__ __forceinline__ void slot_use(uint8_t *slot, int i)
 __device__ __forceinline__ int q_at(u64 q, int j) { return (int)((q >> (16 * j)) & 0xffffull); }
 __device__ __forceinline__ u64 q_make(int a, int b, int c, int d) { return (u64)a | (u64)b << 16 | (u64)c << 32 | (u64)d << 48; }
 
-// find_closest_potential_saddle_idxs (board.rs:177-233) for the ordered pair (i0, i1): candidates next to i0 into
-// o[0..3), next to i1 into o[3..6) (LDS), counts returned
-__device__ __forceinline__ void closest_pair(const Ctx &c, const uint8_t *slot, int i0, int i1, uint16_t *o, int &n0, int &n1)
+// try_expand_one (board.rs:153-176) for the quad qs (rotated as try_expand passes it), by the wave.  The four queries of
+// find_closest_potential_saddle_idxs (:177-233) -- next to s0 and s1 along s0 -> s1, next to s3 and s2 along s3 -> s2 -- run on
+// 16 lanes each: the three nearest saddles among those within the radius (which is what tree.nearest(.., 3, ..) filtered
+// by `dist_sq <= radius_sq` leaves: a saddle within the radius that is among the three nearest of all is among the three
+// nearest of those within the radius, and the other way round), found in the grid cells the radius reaches.  Then the
+// reference's four nested loops as one combination per lane; the first valid one in loop order is the result.
+__device__ bool expand_one_w(const Ctx &c, const uint8_t *slot, u64 qs, u64 &out, int lane, uint32_t &status)
 {
-    const float s0x = c.sx[i0], s0y = c.sy[i0], s1x = c.sx[i1], s1y = c.sy[i1];
+    const int g = lane >> 4, l = lane & 15;
+    const int ia = g < 2 ? q_at(qs, 0) : q_at(qs, 3), ib = g < 2 ? q_at(qs, 1) : q_at(qs, 2);  // the pair (first, second)
+    const int anchor = (g & 1) ? ib : ia;                                                      // whose neighbour is looked for
+    const float ax = c.sx[ia], ay = c.sy[ia], bx = c.sx[ib], by = c.sy[ib];
     const float ratio0 = 1.0f + 0.3f;
-    const float ex = s0x - s1x, ey = s0y - s1y;
+    const float ex = ax - bx, ey = ay - by;
     const float radius_sq = 0.5f * (ex * ex + ey * ey);
-    const float v10x = s1x - s0x, v10y = s1y - s0y;
-    n0 = n1 = 0;
-    u64 k0, k1, k2;
-    nn3_within(c, s0x + v10x * ratio0, s0y + v10y * ratio0, radius_sq, k0, k1, k2);
-    {
-        const float t0 = c.st[i0];
-        const u64 ks[3] = {k0, k1, k2};
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int idx = (int)(uint32_t)ks[i];
-            if (ks[i] != ~0ull && __uint_as_float((uint32_t)(ks[i] >> 32)) <= radius_sq && slot_active(slot, idx) &&
-                theta_dist(t0, c.st[idx]) < 5.0f)
-                o[n0++] = (uint16_t)idx;
+    const float v10x = bx - ax, v10y = by - ay;
+    const float qx = c.sx[anchor] + v10x * ratio0, qy = c.sy[anchor] + v10y * ratio0;
+    u64 k0 = ~0ull, k1 = ~0ull, k2 = ~0ull;
+    const float r = sqrtf(radius_sq) * 1.0001f + 1e-3f;
+    if (!(r < 3e38f)) {  // (not on image coordinates) everything
+        for (int t = l; t < c.n; t += 16) top3_insert(dist_key(qx, qy, c.gx[t], c.gy[t], c.gi[t]), k0, k1, k2);
+    } else {
+        const int xa = cell_x(c, qx - r), xb = cell_x(c, qx + r), ya = cell_y(c, qy - r), yb = cell_y(c, qy + r);
+        for (int y = ya; y <= yb; ++y) {
+            const int t0 = c.gstart[y * c.nx + xa], t1 = c.gstart[y * c.nx + xb + 1];
+            for (int t = t0 + l; t < t1; t += 16) top3_insert(dist_key(qx, qy, c.gx[t], c.gy[t], c.gi[t]), k0, k1, k2);
         }
     }
-    if (!n0) return;  // (try_expand_one's loops are empty whatever the other list holds)
-    nn3_within(c, s1x + v10x * ratio0, s1y + v10y * ratio0, radius_sq, k0, k1, k2);
-    {
-        const float t1 = c.st[i1];
-        const u64 ks[3] = {k0, k1, k2};
+    // the three smallest keys of the 16 lanes, filtered as :207-221 (radius, still unused by this board, same orientation)
+    u64 list = 0;
+    int cnt = 0;
+    const float at = c.st[anchor];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int idx = (int)(uint32_t)ks[i];
-            if (ks[i] != ~0ull && __uint_as_float((uint32_t)(ks[i] >> 32)) <= radius_sq && slot_active(slot, idx) &&
-                theta_dist(t1, c.st[idx]) < 5.0f)
-                o[3 + n1++] = (uint16_t)idx;
+    for (int rk = 0; rk < 3; ++rk) {
+        u64 m = k0;
+#pragma unroll
+        for (int o = 8; o; o >>= 1) {
+            const u64 v = shfl_xor_u64(m, o);
+            m = v < m ? v : m;
+        }
+        if (k0 == m && m != ~0ull) {
+            k0 = k1;
+            k1 = k2;
+            k2 = ~0ull;
+        }
+        const bool have = m != ~0ull;
+        const int idx = have ? (int)(uint32_t)m : 0;
+        if (have && __uint_as_float((uint32_t)(m >> 32)) <= radius_sq && slot_active(slot, idx) && theta_dist(at, c.st[idx]) < 5.0f) {
+            list |= (u64)idx << (16 * cnt);
+            ++cnt;
         }
     }
-}
-
-// try_expand_one (board.rs:153-176); qs = the quad rotated as try_expand passes it
-__device__ bool expand_one(const Ctx &c, uint8_t *slot, u64 qs, u64 &out, uint32_t &status)
-{
-    uint16_t *tmp = reinterpret_cast<uint16_t *>(slot + SL_TMP);
-    int n0, n1, n2, n3;
-    closest_pair(c, slot, q_at(qs, 0), q_at(qs, 1), tmp, n0, n1);
-    if (n0 == 0 || n1 == 0) return false;
-    closest_pair(c, slot, q_at(qs, 3), q_at(qs, 2), tmp + 6, n3, n2);  // (s3's candidates at tmp[6..9), s2's at tmp[9..12))
-    if (n3 == 0 || n2 == 0) return false;
-    for (int i0 = 0; i0 < n0; ++i0)
-        for (int i1 = 0; i1 < n1; ++i1)
-            for (int i2 = 0; i2 < n2; ++i2)
-                for (int i3 = 0; i3 < n3; ++i3) {
-                    const int a = tmp[i0], b = tmp[3 + i1], cc = tmp[9 + i2], d = tmp[6 + i3];
-                    const int v = valid_quad(c, a, b, cc, d);
-                    if (v == 1) {
-                        out = q_make(a, b, cc, d);
-                        return true;
-                    }
-                    if (v == 2) status |= TAIL_UNCERTAIN | (1u << 8);
-                }
+    list |= (u64)cnt << 48;
+    const u64 l0 = shfl_u64(list, 0), l1 = shfl_u64(list, 16), l3 = shfl_u64(list, 32), l2 = shfl_u64(list, 48);
+    const int n0 = (int)(l0 >> 48), n1 = (int)(l1 >> 48), n2 = (int)(l2 >> 48), n3 = (int)(l3 >> 48);
+    if (n0 == 0 || n1 == 0 || n2 == 0 || n3 == 0) return false;  // (an empty loop)
+    for (int pass = 0; pass < 2; ++pass) {
+        const int L = lane + 64 * pass;  // the combination's number in loop order: ((i0 * 3 + i1) * 3 + i2) * 3 + i3
+        const int j0 = L / 27, j1 = (L / 9) % 3, j2 = (L / 3) % 3, j3 = L % 3;
+        const bool in = L < 81 && j0 < n0 && j1 < n1 && j2 < n2 && j3 < n3;
+        const int a = q_at(l0, j0 < 3 ? j0 : 0), b = q_at(l1, j1), cc = q_at(l2, j2), d = q_at(l3, j3);
+        const int v = in ? valid_quad(c, a, b, cc, d) : 0;
+        const u64 mv = __ballot(v == 1), mu = __ballot(v == 2);
+        const int first = mv ? __ffsll((long long)mv) - 1 : 64;
+        if (mu & (first == 64 ? ~0ull : ((1ull << first) - 1ull))) status |= TAIL_UNCERTAIN;  // an undecided one before it
+        if (mv) {
+            out = shfl_u64(q_make(a, b, cc, d), first);
+            return true;
+        }
+        if (n0 < 3) break;  // (combinations 64 .. 80 have i0 = 2)
+    }
     return false;
 }
 
-// Board::new (board.rs:26-48): the board grown from a seed quad; returns its score, the cells stay in the slot
-__device__ int build_board(const Ctx &c, uint8_t *slot, u64 seed, int &n_cells_out, uint32_t &status)
+// Board::new (board.rs:26-48): the board grown from a seed quad; returns its score, the cells stay in the slot.
+// try_expand's recursion (:114-152) is a stack of (cell, next direction) walked by all lanes alike; lane 0 writes.
+__device__ int build_board_w(const Ctx &c, uint8_t *slot, u64 seed, int lane, int &n_cells_out, uint32_t &status)
 {
     {
-        uint32_t *act = reinterpret_cast<uint32_t *>(slot + SL_ACTIVE);
-        for (int i = 0; i < TN / 32; ++i) act[i] = 0xffffffffu;
         uint32_t *g = reinterpret_cast<uint32_t *>(slot + SL_GRID);
-        for (int i = 0; i < (SL_ACTIVE - SL_GRID) / 4; ++i) g[i] = 0xffffffffu;
+        for (int i = lane; i < (SL_ACTIVE - SL_GRID) / 4; i += 64) g[i] = 0xffffffffu;
+        if (lane < TN / 32) reinterpret_cast<uint32_t *>(slot + SL_ACTIVE)[lane] = 0xffffffffu;
     }
+    wsync();
     uint8_t *grid = slot + SL_GRID, *found = slot + SL_FOUND, *stack = slot + SL_STACK;
     int8_t *xy = reinterpret_cast<int8_t *>(slot + SL_XY);
-    for (int j = 1; j < 4; ++j) slot_use(slot, q_at(seed, j));  // :35-37
-    int n_cells = 1, score = 1;
-    slot_set_quad(slot, 0, seed);
-    xy[0] = 0;
-    xy[1] = 0;
-    found[0] = 1;
-    grid[BGR * BGN + BGR] = 0;
-    stack[0] = 0;
-    stack[1] = 0;
-    int sp = 1;
-    while (sp > 0) {  // try_expand (:114-152), its recursion as a stack of (cell, next direction)
+    if (lane == 0) {
+        for (int j = 1; j < 4; ++j) slot_use(slot, q_at(seed, j));  // :35-37
+        slot_set_quad(slot, 0, seed);
+        xy[0] = 0;
+        xy[1] = 0;
+        found[0] = 1;
+        grid[BGR * BGN + BGR] = 0;
+        stack[0] = 0;
+        stack[1] = 0;
+    }
+    wsync();
+    int n_cells = 1, score = 1, sp = 1;
+    while (sp > 0) {
         const int cell = stack[2 * (sp - 1)], i = stack[2 * (sp - 1) + 1];
         if (i == 4) {
             --sp;
             continue;
         }
-        stack[2 * (sp - 1) + 1] = (uint8_t)(i + 1);
         const int nx = xy[2 * cell] + (i == 0 ? 1 : (i == 2 ? -1 : 0)), ny = xy[2 * cell + 1] + (i == 1 ? -1 : (i == 3 ? 1 : 0));
         if (nx < -BGR || nx > BGR || ny < -BGR || ny > BGR) {
-            status |= TAIL_CAPACITY | (1u << 11);
+            status |= TAIL_CAPACITY;
             break;
         }
         const int gpos = (ny + BGR) * BGN + (nx + BGR);
         const int e = grid[gpos];
-        if (e != 0xff && found[e]) continue;
+        if (e != 0xff && found[e]) {
+            wsync();  // (every lane has read the stack's top)
+            if (lane == 0) stack[2 * (sp - 1) + 1] = (uint8_t)(i + 1);
+            wsync();
+            continue;
+        }
         const u64 quad = slot_quad(slot, cell);
         const u64 qs = i ? (quad >> (16 * i) | quad << (64 - 16 * i)) : quad;  // qs[j] = quad[(j + i) & 3]
-        u64 nq;
-        const bool ok = expand_one(c, slot, qs, nq, status);
+        u64 nq = 0;
+        const bool ok = expand_one_w(c, slot, qs, nq, lane, status);
         int at = e;
         if (at == 0xff) {
             if (n_cells == BCELLS) {
-                status |= TAIL_CAPACITY | (1u << 12);
+                status |= TAIL_CAPACITY;
                 break;
             }
             at = n_cells++;
-            grid[gpos] = (uint8_t)at;
-            xy[2 * at] = (int8_t)nx;
-            xy[2 * at + 1] = (int8_t)ny;
+        }
+        wsync();  // (reads of this step are done)
+        if (lane == 0) {
+            stack[2 * (sp - 1) + 1] = (uint8_t)(i + 1);
+            if (e == 0xff) {
+                grid[gpos] = (uint8_t)at;
+                xy[2 * at] = (int8_t)nx;
+                xy[2 * at + 1] = (int8_t)ny;
+            }
+            if (ok) {
+                const u64 v = i ? (nq << (16 * i) | nq >> (64 - 16 * i)) : nq;  // v[(j + i) & 3] = nq[j]
+                for (int j = 0; j < 4; ++j) slot_use(slot, q_at(v, j));
+                slot_set_quad(slot, at, v);
+                found[at] = 1;
+                stack[2 * sp] = (uint8_t)at;  // (depth <= found cells <= BCELLS)
+                stack[2 * sp + 1] = 0;
+            } else {
+                slot_set_quad(slot, at, 0ull);
+                found[at] = 0;
+            }
         }
         if (ok) {
-            const u64 v = i ? (nq << (16 * i) | nq >> (64 - 16 * i)) : nq;  // v[(j + i) & 3] = nq[j]
-            for (int j = 0; j < 4; ++j) slot_use(slot, q_at(v, j));
             ++score;
-            slot_set_quad(slot, at, v);
-            found[at] = 1;
-            stack[2 * sp] = (uint8_t)at;
-            stack[2 * sp + 1] = 0;
-            ++sp;  // (depth <= found cells <= BCELLS)
-        } else {
-            slot_set_quad(slot, at, 0ull);
-            found[at] = 0;
+            ++sp;
         }
+        wsync();
     }
     n_cells_out = n_cells;
     return score;
@@ -459,89 +525,161 @@ __device__ bool decode_quad(const TailArgs &a, const uint8_t *luma, const float 
     return false;
 }
 
-// ---- wave helpers ---------------------------------------------------------------------------------------------------
 
-__device__ __forceinline__ float wave_min_f(float v)
+// ---- init_quads (detector.rs:543-586) for the seed s0, by one wave: the candidate quads into the wave's list, in the
+// reference's order; returns how many
+__device__ int init_quads_w(const Ctx &c, uint8_t *wv, int s0, int lane, uint32_t &status, unsigned long long *tk)
 {
-    for (int o = 32; o; o >>= 1) v = fminf(v, __shfl_xor(v, o));
-    return v;
-}
-__device__ __forceinline__ float wave_max_f(float v)
-{
-    for (int o = 32; o; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
-}
-__device__ __forceinline__ uint32_t wave_max_u(uint32_t v)
-{
-    for (int o = 32; o; o >>= 1) {
-        const uint32_t w = (uint32_t)__shfl_xor((int)v, o);
-        v = w > v ? w : v;
+    unsigned long long t_last = wall_clock64();
+#define TKS(i) do { const unsigned long long t_now = wall_clock64(); tk[i] += t_now - t_last; t_last = t_now; } while (0)
+    const u64 below = (1ull << lane) - 1ull;
+    u64 *cand = reinterpret_cast<u64 *>(wv + WV_CAND);
+    uint16_t *pairs = reinterpret_cast<uint16_t *>(wv + WV_PAIRS);
+    uint16_t *same = reinterpret_cast<uint16_t *>(wv + WV_SMALL), *diff = same + 64, *s1ok = same + 128;
+    const int n = c.n;
+    const float *sx = c.sx, *sy = c.sy, *st = c.st;
+    const float s0x = sx[s0], s0y = sy[s0], s0t = st[s0];
+    int nc = 0;
+    // 50 nearest: every distance key, sorted
+    int P = 64;
+    while (P < n) P <<= 1;
+    u64 *keys = cand;
+    wsync();  // (the previous seed's candidates are done with)
+    for (int i = lane; i < P; i += 64) keys[i] = i < n ? dist_key(s0x, s0y, sx[i], sy[i], (uint32_t)i) : ~0ull;
+    wsync();
+    for (int k = 2; k <= P; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = lane; i < P; i += 64) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const u64 ka = keys[i], kb = keys[ixj];
+                    if ((ka > kb) == ((i & k) == 0)) {
+                        keys[i] = kb;
+                        keys[ixj] = ka;
+                    }
+                }
+            }
+            wsync();
+        }
+    TKS(2);
+    const int m = n < 50 ? n : 50;
+    int ns = 0, nd = 0;
+    {
+        const int idx = (lane >= 1 && lane < m) ? (int)(uint32_t)keys[lane] : 0;
+        const float td = theta_dist(s0t, st[idx]);
+        const bool is_s = lane >= 1 && lane < m && td < 5.0f;
+        const bool is_d = lane >= 1 && lane < m && !is_s && td > 80.0f;
+        const u64 ms = __ballot(is_s), md = __ballot(is_d);
+        if (is_s) same[__popcll(ms & below)] = (uint16_t)idx;
+        if (is_d) diff[__popcll(md & below)] = (uint16_t)idx;
+        ns = __popcll(ms);
+        nd = __popcll(md);
     }
-    return v;
-}
-__device__ __forceinline__ uint32_t wave_or_u(uint32_t v)
-{
-    for (int o = 32; o; o >>= 1) v |= (uint32_t)__shfl_xor((int)v, o);
-    return v;
+    wsync();  // (the keys are dead from here: cand is written below)
+    int n_pairs = 0;
+    if (ns > 0 && nd >= 2) {
+        // the (d0, d1) combinations in the reference's order (itertools combinations(2)) that pass saddle.rs:18-21
+        for (int p = 0; p < nd; ++p) {
+            const bool ok = lane > p && lane < nd && !(theta_dist(st[diff[p]], st[diff[lane < nd ? lane : 0]]) > 5.0f);
+            const u64 mk = __ballot(ok);
+            if (ok) pairs[n_pairs + __popcll(mk & below)] = (uint16_t)(p | lane << 8);
+            n_pairs += __popcll(mk);
+        }
+        // the white-block test depends on (s0, s1) only: once per s1 (0 fails, 1 passes, 2 undecided here)
+        if (lane < ns) s1ok[lane] = (uint16_t)white_block(s0t, sx[same[lane]] - s0x, sy[same[lane]] - s0y);
+    }
+    wsync();
+    TKS(3);
+    if (n_pairs > 0) {
+        for (int si = 0; si < ns; ++si) {
+            const int wb = s1ok[si];
+            if (wb == 0) continue;
+            const int s1 = same[si];
+            const float v02x = sx[s1] - s0x, v02y = sy[s1] - s0y;
+            for (int base = 0; base < n_pairs; base += 64) {
+                const int p = base + lane;
+                bool ok = false;
+                u64 q = 0;
+                if (p < n_pairs) {
+                    const int pa = pairs[p] & 0xff, pb = pairs[p] >> 8;
+                    const int d0 = diff[pa], d1 = diff[pb];
+                    ok = quad_rest(c, s0, d0, s1, d1);
+                    if (ok && wb == 2) {  // a quad hangs on the undecided test
+                        status |= TAIL_UNCERTAIN;
+                        ok = false;
+                    }
+                    const float c0 = cross2(sx[d0] - s0x, sy[d0] - s0y, v02x, v02y);
+                    q = c0 > 0.0f ? q_make(s0, d0, s1, d1) : q_make(s0, d1, s1, d0);
+                }
+                const u64 mk = __ballot(ok);
+                const int at = nc + __popcll(mk & below);
+                if (ok && at < TCAND) cand[at] = q;
+                nc += __popcll(mk);
+            }
+        }
+        if (nc > TCAND) {
+            status |= TAIL_CAPACITY;
+            nc = TCAND;
+        }
+    }
+    wsync();
+    TKS(4);
+    return nc;
 }
 
-__global__ void __launch_bounds__(64) k_board_tail(TailArgs a)
+__global__ void __launch_bounds__(64 * TW) k_board_tail(TailArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const int f = blockIdx.x, lane = threadIdx.x;
+    const int f = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const u64 below = (1ull << lane) - 1ull;
     float *sx = reinterpret_cast<float *>(lds + OFF_SX), *sy = reinterpret_cast<float *>(lds + OFF_SY), *st = reinterpret_cast<float *>(lds + OFF_ST);
     float *gx = reinterpret_cast<float *>(lds + OFF_GX), *gy = reinterpret_cast<float *>(lds + OFF_GY);
     uint16_t *gi = reinterpret_cast<uint16_t *>(lds + OFF_GI), *gstart = reinterpret_cast<uint16_t *>(lds + OFF_GSTART);
     uint16_t *seeds = reinterpret_cast<uint16_t *>(lds + OFF_SEEDS);
-    u64 *cand = reinterpret_cast<u64 *>(lds + OFF_CAND);
-    uint32_t *tmp32 = reinterpret_cast<uint32_t *>(lds + OFF_CAND);
-    uint16_t *pairs = reinterpret_cast<uint16_t *>(lds + OFF_PAIRS);
-    uint16_t *same = reinterpret_cast<uint16_t *>(lds + OFF_SMALL), *diff = same + 64, *s1ok = same + 128;
     u64 *quads = reinterpret_cast<u64 *>(lds + OFF_QUADS);
     uint32_t *tagids = reinterpret_cast<uint32_t *>(lds + OFF_TAGIDS);
     uint32_t *used = reinterpret_cast<uint32_t *>(lds + OFF_USED);
     uint32_t *hist = reinterpret_cast<uint32_t *>(lds + OFF_HIST);
-    uint8_t *boards = lds + OFF_BOARDS;
-    uint8_t *best_slot = boards + TB * SL_BYTES;
+    uint32_t *sh = reinterpret_cast<uint32_t *>(lds + OFF_SHARED);  // [0] status, [1] n, [2] seeds, [3] saddles removed, [4 .. 4 + TW) candidates per wave, [8 .. 8 + TW) the seeds' best boards, [12] the boards handed out
+    uint8_t *wv = lds + OFF_WAVES + wave * WV_BYTES;  // this wave's own
+    uint32_t *tmp32 = reinterpret_cast<uint32_t *>(wv + WV_CAND);
 
-    uint32_t status = 0;  // per lane; merged at the end
-    int n_tags = 0;
+    uint32_t status = 0;  // per lane; merged through sh[0]
+    int n_tags = 0;       // (wave 0)
+    unsigned long long tk[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = wall_clock64();
+    int n_cands_total = 0, n_seeds_done = 0, n_boards = 0;
+#define TK(i) do { const unsigned long long t_now = wall_clock64(); tk[i] += t_now - t_last; t_last = t_now; } while (0)
     const FrameCounters &fc = a.ctr[f];
     int n = (int)fc.n_out;
     const uint32_t cflags = fc.flags;
-    if (cflags & (FLAG_CAND_OVERFLOW | FLAG_ROOT_OVERFLOW | FLAG_OUT_OVERFLOW)) {
-        if (lane == 0) {
+    if ((cflags & (FLAG_CAND_OVERFLOW | FLAG_ROOT_OVERFLOW | FLAG_OUT_OVERFLOW)) || n > TN) {  // (the whole workgroup alike)
+        if (tid == 0) {
             a.table[2 * f] = 0;
-            a.table[2 * f + 1] = TAIL_CHAIN;
+            a.table[2 * f + 1] = n > TN ? TAIL_CAPACITY : TAIL_CHAIN;
         }
         return;
     }
-    if (n > TN) {
-        if (lane == 0) {
-            a.table[2 * f] = 0;
-            a.table[2 * f + 1] = TAIL_CAPACITY;
-        }
-        return;
-    }
+    if (tid == 0) sh[0] = 0;
     {
         const float *src = a.saddles + (size_t)fc.out_offset * 5;
-        for (int i = lane; i < n; i += 64) {
+        for (int i = tid; i < n; i += 64 * TW) {
             const float x = src[5 * i], y = src[5 * i + 1], t = src[5 * i + 3];
             sx[i] = x;
             sy[i] = y;
             st[i] = t;
             // coordinates of an image and half an atan2 in degrees; anything else (NaN included) is not this kernel's business
-            if (!(fabsf(x) < 1e6f && fabsf(y) < 1e6f && t >= -180.0f && t <= 180.0f)) status |= TAIL_CAPACITY | (1u << 13);
+            if (!(fabsf(x) < 1e6f && fabsf(y) < 1e6f && t >= -180.0f && t <= 180.0f)) status |= TAIL_CAPACITY;
         }
     }
     const uint8_t *luma = a.luma + (size_t)f * (size_t)a.luma_frame_stride;
     const uint32_t tag_cap = a.tag_cap < (uint32_t)TTAGS ? a.tag_cap : (uint32_t)TTAGS;
     __syncthreads();
-    if (wave_or_u(status)) n = 0;  // (uniform) nothing is searched; the status goes out below
+    if (status) atomicOr(&sh[0], status);
+    __syncthreads();
+    if (sh[0]) n = 0;  // nothing is searched; the status goes out below
 
     for (int round = 0; round < a.max_boards && n > 0; ++round) {
-        // ---- the k-NN grid over this round's saddles -----------------------------------------------------------------
+        // ---- the k-NN grid over this round's saddles (every wave derives the geometry, the first one fills the cells) ----
         Ctx c;
         c.sx = sx; c.sy = sy; c.st = st; c.gx = gx; c.gy = gy; c.gi = gi; c.gstart = gstart; c.n = n;
         {
@@ -560,14 +698,15 @@ __global__ void __launch_bounds__(64) k_board_tail(TailArgs a)
                 ny = (int)(h / cell) + 1;
             }
             c.ox = x0; c.oy = y0; c.inv_cell = 1.0f / cell; c.nx = nx; c.ny = ny;
-            const int ncell = nx * ny;
+        }
+        if (wave == 0) {
+            const int nx = c.nx, ncell = c.nx * c.ny;
             uint32_t *cnt = tmp32, *fill = tmp32 + TGC;
             for (int i = lane; i < ncell; i += 64) cnt[i] = 0;
-            __syncthreads();
+            wsync();
             for (int i = lane; i < n; i += 64) atomicAdd(&cnt[cell_y(c, sy[i]) * nx + cell_x(c, sx[i])], 1u);
-            __syncthreads();
-            // exclusive scan: 16 consecutive cells per lane
-            uint32_t local = 0;
+            wsync();
+            uint32_t local = 0;  // exclusive scan: 16 consecutive cells per lane
             for (int k = 0; k < TGC / 64; ++k) {
                 const int ci = lane * (TGC / 64) + k;
                 if (ci < ncell) local += cnt[ci];
@@ -587,23 +726,20 @@ __global__ void __launch_bounds__(64) k_board_tail(TailArgs a)
                 }
             }
             if (lane == 0) gstart[ncell] = (uint16_t)n;
-            __syncthreads();
+            wsync();
             for (int i = lane; i < n; i += 64) {
                 const uint32_t pos = atomicAdd(&fill[cell_y(c, sy[i]) * nx + cell_x(c, sx[i])], 1u);
                 gi[pos] = (uint16_t)i;
                 gx[pos] = sx[i];
                 gy[pos] = sy[i];
             }
-            __syncthreads();
-        }
-
-        // ---- seeds: the most populated round(theta) bin (ties: the smallest angle), in index order -------------------
-        int n_seeds = 0;
-        {
+            wsync();
+            TK(0);
+            // ---- seeds: the most populated round(theta) bin (ties: the smallest angle), in index order ---------------
             for (int i = lane; i < 364; i += 64) hist[i] = 0;
-            __syncthreads();
+            wsync();
             for (int i = lane; i < n; i += 64) atomicAdd(&hist[(int)round_half_away(st[i]) + 180], 1u);
-            __syncthreads();
+            wsync();
             uint32_t bestk = 0;
             for (int i = lane; i < 361; i += 64) {
                 const uint32_t k = hist[i] << 16 | (uint32_t)(0xffff - i);
@@ -611,266 +747,243 @@ __global__ void __launch_bounds__(64) k_board_tail(TailArgs a)
             }
             bestk = wave_max_u(bestk);
             const int best_angle = (int)(0xffff - (bestk & 0xffffu)) - 180;
+            int ns_ = 0;
             for (int base = 0; base < n; base += 64) {
                 const int i = base + lane;
                 const bool is = i < n && (int)round_half_away(st[i]) == best_angle;
                 const u64 m = __ballot(is);
-                if (is) seeds[n_seeds + __popcll(m & below)] = (uint16_t)i;
-                n_seeds += __popcll(m);
+                if (is) seeds[ns_ + __popcll(m & below)] = (uint16_t)i;
+                ns_ += __popcll(m);
             }
+            if (lane == 0) sh[2] = (uint32_t)ns_;
+            TK(1);
+        }
+        __syncthreads();
+        const int n_seeds = (int)sh[2];
+        const int total = n_seeds < 30 ? n_seeds : 30;  // popped from the back, at most 30 (detector.rs:613)
+
+        // ---- try_find_best_board's loop over the seeds (:613-629), TW seeds at a time: every wave lists the candidate quads
+        // of one seed, then the waves take the group's boards one by one from a common counter (the boards of a seed that
+        // finds the real board cost fifty times what the others cost) ----------------------------------------------------
+        uint32_t best_score = 0;
+        u64 best_quad = 0;
+        bool stop = false;
+        for (int base = 0; base < total && !stop; base += TW) {
+            const int k = base + wave;
+            int nc_mine = 0;
+            if (k < total) {
+                nc_mine = init_quads_w(c, wv, seeds[n_seeds - 1 - k], lane, status, tk);
+                n_cands_total += nc_mine;
+                ++n_seeds_done;
+            }
+            if (lane == 0) {
+                sh[4 + wave] = (uint32_t)nc_mine;
+                sh[8 + wave] = 0;
+                if (wave == 0) sh[12] = 0;
+            }
+            __syncthreads();
+            int first_item[TW + 1];
+            first_item[0] = 0;
+#pragma unroll
+            for (int w = 0; w < TW; ++w) first_item[w + 1] = first_item[w] + (int)sh[4 + w];
+            for (;;) {
+                int item = lane == 0 ? (int)atomicAdd(&sh[12], 1u) : 0;
+                item = __shfl(item, 0);
+                if (item >= first_item[TW]) break;
+                int w = 0;
+#pragma unroll
+                for (int t = 1; t < TW; ++t) w += item >= first_item[t];
+                int ci = item;
+#pragma unroll
+                for (int t = 1; t < TW; ++t) ci -= (item >= first_item[t]) ? (int)sh[4 + t - 1] : 0;
+                const u64 q = reinterpret_cast<const u64 *>(lds + OFF_WAVES + w * WV_BYTES + WV_CAND)[ci];
+                int cells;
+                const unsigned long long tb0 = wall_clock64();
+                const uint32_t score = (uint32_t)build_board_w(c, wv + WV_SLOT, q, lane, cells, status);
+                tk[8] += wall_clock64() - tb0;
+                tk[9] += (unsigned long long)cells;
+                ++n_boards;
+                // the seed's best score and the FIRST candidate that reaches it (what the sequential loop is left with, :616-622)
+                if (lane == 0) atomicMax(&sh[8 + w], score << 16 | (uint32_t)(0xffff - ci));
+            }
+            status = wave_or_u(status);
+            if (lane == 0 && status) atomicOr(&sh[0], status);
+            __syncthreads();
+            for (int w = 0; w < TW && base + w < total; ++w) {  // the reference's order
+                const uint32_t key = sh[8 + w];
+                if ((key >> 16) > best_score) {
+                    best_score = key >> 16;
+                    best_quad = reinterpret_cast<const u64 *>(lds + OFF_WAVES + w * WV_BYTES + WV_CAND)[0xffff - (key & 0xffffu)];
+                }
+                if (best_score >= 36) {
+                    stop = true;
+                    break;
+                }
+            }
+            if (sh[0]) stop = true;  // the frame goes to the host anyway
             __syncthreads();
         }
+        TK(5);
+        if (sh[0] || best_score == 0) break;  // (None: the remaining rounds would find nothing either)
 
-        // ---- try_find_best_board's loop over the seeds (detector.rs:613-629) -------------------------------------------
-        int best_score = 0, best_cells = 0;
-        int count = 0;
-        while (n_seeds > 0 && count < 30) {
-            const int s0 = seeds[--n_seeds];
-            const float s0x = sx[s0], s0y = sy[s0], s0t = st[s0];
-            int nc = 0;
-            // init_quads (:543-586).  50 nearest: every distance key, sorted
-            int P = 64;
-            while (P < n) P <<= 1;
-            u64 *keys = cand;
-            for (int i = lane; i < P; i += 64) keys[i] = i < n ? dist_key(s0x, s0y, sx[i], sy[i], (uint32_t)i) : ~0ull;
-            __syncthreads();
-            for (int k = 2; k <= P; k <<= 1)
-                for (int j = k >> 1; j > 0; j >>= 1) {
-                    for (int i = lane; i < P; i += 64) {
-                        const int ixj = i ^ j;
-                        if (ixj > i) {
-                            const u64 ka = keys[i], kb = keys[ixj];
-                            if ((ka > kb) == ((i & k) == 0)) {
-                                keys[i] = kb;
-                                keys[ixj] = ka;
-                            }
-                        }
-                    }
-                    __syncthreads();
-                }
-            const int m = n < 50 ? n : 50;
-            int ns = 0, nd = 0;
-            {
-                const int idx = (lane >= 1 && lane < m) ? (int)(uint32_t)keys[lane] : 0;
-                const float td = theta_dist(s0t, st[idx]);
-                const bool is_s = lane >= 1 && lane < m && td < 5.0f;
-                const bool is_d = lane >= 1 && lane < m && !is_s && td > 80.0f;
-                const u64 ms = __ballot(is_s), md = __ballot(is_d);
-                if (is_s) same[__popcll(ms & below)] = (uint16_t)idx;
-                if (is_d) diff[__popcll(md & below)] = (uint16_t)idx;
-                ns = __popcll(ms);
-                nd = __popcll(md);
-            }
-            __syncthreads();  // (keys are dead from here: cand is written below)
-            int n_pairs = 0, n_s1 = 0;
-            if (ns > 0 && nd >= 2) {
-                // the (d0, d1) combinations in the reference's order (itertools combinations(2)) that pass :18-21
-                for (int p = 0; p < nd; ++p) {
-                    const bool ok = lane > p && lane < nd && !(theta_dist(st[diff[p]], st[diff[lane < nd ? lane : 0]]) > 5.0f);
-                    const u64 mk = __ballot(ok);
-                    if (ok) pairs[n_pairs + __popcll(mk & below)] = (uint16_t)(p | lane << 8);
-                    n_pairs += __popcll(mk);
-                }
-                // the white-block test depends on (s0, s1) only: once per s1 (s1ok: 0 fails, 1 passes, 2 undecided here)
-                if (lane < ns) s1ok[lane] = (uint16_t)white_block(s0t, sx[same[lane]] - s0x, sy[same[lane]] - s0y);
-                n_s1 = ns;
-            }
-            __syncthreads();
-            if (n_pairs > 0) {
-                for (int si = 0; si < n_s1; ++si) {
-                    const int wb = s1ok[si];
-                    if (wb == 0) continue;
-                    const int s1 = same[si];
-                    const float v02x = sx[s1] - s0x, v02y = sy[s1] - s0y;
-                    for (int base = 0; base < n_pairs; base += 64) {
-                        const int p = base + lane;
-                        bool ok = false;
-                        u64 q = 0;
-                        if (p < n_pairs) {
-                            const int pa = pairs[p] & 0xff, pb = pairs[p] >> 8;
-                            const int d0 = diff[pa], d1 = diff[pb];
-                            ok = quad_rest(c, s0, d0, s1, d1);
-                            if (ok && wb == 2) {  // a quad hangs on the undecided test
-                                status |= TAIL_UNCERTAIN | (1u << 9);
-                                ok = false;
-                            }
-                            const float c0 = cross2(sx[d0] - s0x, sy[d0] - s0y, v02x, v02y);
-                            q = c0 > 0.0f ? q_make(s0, d0, s1, d1) : q_make(s0, d1, s1, d0);
-                        }
-                        const u64 mk = __ballot(ok);
-                        const int at = nc + __popcll(mk & below);
-                        if (ok && at < TCAND) cand[at] = q;
-                        nc += __popcll(mk);
+        if (wave == 0) {
+            // the chosen board again (a board is a function of the saddles and its seed quad), then try_fix_missing +
+            // all_tag_indexes (board.rs:49-112), cells in insertion order
+            uint8_t *slot = wv + WV_SLOT;
+            int best_cells = 0;
+            (void)build_board_w(c, slot, best_quad, lane, best_cells, status);
+            int n_quads = 0;
+            if (lane == 0) {
+                const int8_t *xy = reinterpret_cast<const int8_t *>(slot + SL_XY);
+                uint8_t *found = slot + SL_FOUND;
+                auto find = [&](int x, int y) -> int {
+                    if (x < -BGR || x > BGR || y < -BGR || y > BGR) return -1;
+                    const int e = slot[SL_GRID + (y + BGR) * BGN + (x + BGR)];
+                    return e == 0xff ? -1 : e;
+                };
+                uint8_t *fa = slot + SL_STACK, *fb = fa + BCELLS;  // the fix list: the two found neighbours ...
+                uint8_t *fm = reinterpret_cast<uint8_t *>(wv + WV_PAIRS);  // ... and the cell between them
+                int n_fix = 0;
+                for (int i = 0; i < best_cells; ++i) {
+                    if (found[i]) continue;
+                    const int x = xy[2 * i], y = xy[2 * i + 1];
+                    const int c0 = find(x + 1, y), c1 = find(x - 1, y);
+                    if (c0 >= 0 && c1 >= 0) {
+                        if (found[c0] && found[c1]) { fa[n_fix] = (uint8_t)c0; fb[n_fix] = (uint8_t)c1; fm[n_fix] = (uint8_t)i; ++n_fix; }
+                    } else {
+                        const int c2 = find(x, y + 1), c3 = find(x, y - 1);
+                        if (c2 >= 0 && c3 >= 0 && found[c2] && found[c3]) { fa[n_fix] = (uint8_t)c2; fb[n_fix] = (uint8_t)c3; fm[n_fix] = (uint8_t)i; ++n_fix; }
                     }
                 }
-                if (nc > TCAND) {
-                    status |= TAIL_CAPACITY | (1u << 14);
-                    nc = TCAND;
+                for (int k = 0; k < n_fix; ++k) {
+                    const u64 q0 = slot_quad(slot, fa[k]), q1 = slot_quad(slot, fb[k]);
+                    int mid[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int i0 = q_at(q0, i), i1 = q_at(q1, i);
+                        const float x = (sx[i0] + sx[i1]) / 2.0f, y = (sy[i0] + sy[i1]) / 2.0f;
+                        u64 bestk = ~0ull;
+                        for (int t = 0; t < n; ++t) {
+                            const u64 kk = dist_key(x, y, sx[t], sy[t], (uint32_t)t);
+                            bestk = kk < bestk ? kk : bestk;
+                        }
+                        mid[i] = (int)(uint32_t)bestk;
+                    }
+                    const int v = valid_quad(c, mid[0], mid[1], mid[2], mid[3]);
+                    if (v == 2) status |= TAIL_UNCERTAIN;
+                    if (v == 1) {  // the cell between the two is the missing one ((b0 + b1) / 2, :100): it exists, not found
+                        slot_set_quad(slot, fm[k], q_make(mid[0], mid[1], mid[2], mid[3]));
+                        found[fm[k]] = 1;
+                    }
                 }
-            }
-            __syncthreads();
-            // a board per candidate quad, in order; the first one that beats the best so far is kept (:616-622)
-            for (int base = 0; base < nc; base += TB) {
-                int score = 0, cells = 0;
-                if (lane < TB && base + lane < nc) score = build_board(c, boards + lane * SL_BYTES, cand[base + lane], cells, status);
-                const uint32_t key = wave_max_u((uint32_t)score << 8 | (uint32_t)(63 - lane));
-                const int top = (int)(key >> 8), who = 63 - (int)(key & 0xffu);
-                if (top > best_score) {  // (uniform)
-                    best_score = top;
-                    best_cells = __shfl(cells, who);
-                    __syncthreads();
-                    const uint32_t *src = reinterpret_cast<const uint32_t *>(boards + who * SL_BYTES);
-                    uint32_t *dst = reinterpret_cast<uint32_t *>(best_slot);
-                    for (int i = lane; i < SL_GRID / 4; i += 64) dst[i] = src[i];  // quads, coordinates, found flags
-                }
-                __syncthreads();
-            }
-            if (best_score >= 36) break;
-            ++count;
-            if (wave_or_u(status)) break;  // the frame goes to the host anyway
-        }
-        if (wave_or_u(status)) break;
-        if (best_score == 0) break;  // None: the remaining rounds would find nothing either
-
-        // ---- try_fix_missing + all_tag_indexes (board.rs:49-112), cells in insertion order ----------------------------
-        int n_quads = 0;
-        if (lane == 0) {
-            const int8_t *xy = reinterpret_cast<const int8_t *>(best_slot + SL_XY);
-            uint8_t *found = best_slot + SL_FOUND;
-            auto find = [&](int x, int y) -> int {
                 for (int i = 0; i < best_cells; ++i)
-                    if (xy[2 * i] == x && xy[2 * i + 1] == y) return i;
-                return -1;
-            };
-            uint8_t *fa = best_slot + SL_STACK, *fb = fa + BCELLS;  // the fix list: cell numbers of the two found neighbours, and of the cell
-            uint8_t *fc_ = best_slot + SL_GRID;
-            int n_fix = 0;
-            for (int i = 0; i < best_cells; ++i) {
-                if (found[i]) continue;
-                const int x = xy[2 * i], y = xy[2 * i + 1];
-                const int c0 = find(x + 1, y), c1 = find(x - 1, y);
-                if (c0 >= 0 && c1 >= 0) {
-                    if (found[c0] && found[c1]) { fa[n_fix] = (uint8_t)c0; fb[n_fix] = (uint8_t)c1; fc_[n_fix] = (uint8_t)i; ++n_fix; }
-                } else {
-                    const int c2 = find(x, y + 1), c3 = find(x, y - 1);
-                    if (c2 >= 0 && c3 >= 0 && found[c2] && found[c3]) { fa[n_fix] = (uint8_t)c2; fb[n_fix] = (uint8_t)c3; fc_[n_fix] = (uint8_t)i; ++n_fix; }
-                }
+                    if (found[i]) quads[n_quads++] = slot_quad(slot, i);
             }
-            for (int k = 0; k < n_fix; ++k) {
-                const u64 q0 = slot_quad(best_slot, fa[k]), q1 = slot_quad(best_slot, fb[k]);
-                int mid[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int i0 = q_at(q0, i), i1 = q_at(q1, i);
-                    const float x = (sx[i0] + sx[i1]) / 2.0f, y = (sy[i0] + sy[i1]) / 2.0f;
-                    u64 bestk = ~0ull;
-                    for (int t = 0; t < n; ++t) {
-                        const u64 kk = dist_key(x, y, sx[t], sy[t], (uint32_t)t);
-                        bestk = kk < bestk ? kk : bestk;
-                    }
-                    mid[i] = (int)(uint32_t)bestk;
-                }
-                const int v = valid_quad(c, mid[0], mid[1], mid[2], mid[3]);
-                if (v == 2) status |= TAIL_UNCERTAIN | (1u << 10);
-                if (v == 1) {  // the cell between the two is the missing one ((b0 + b1) / 2, :100): it exists, not found
-                    slot_set_quad(best_slot, fc_[k], q_make(mid[0], mid[1], mid[2], mid[3]));
-                    found[fc_[k]] = 1;
-                }
-            }
-            for (int i = 0; i < best_cells; ++i)
-                if (found[i]) quads[n_quads++] = slot_quad(best_slot, i);
-        }
-        n_quads = __shfl(n_quads, 0);
-        __syncthreads();
-        if (wave_or_u(status)) break;
+            n_quads = __shfl(n_quads, 0);
+            wsync();
+            TK(6);
 
-        // ---- decode the board's quads (detector.rs:514-527); results in the candidates' space -------------------------
-        float *dec_xy = reinterpret_cast<float *>(lds + OFF_CAND);          // [BCELLS][8]
-        int *dec_id = reinterpret_cast<int *>(lds + OFF_CAND + BCELLS * 32);  // [BCELLS]: tag id or -1
-        for (int base = 0; base < n_quads; base += 64) {
-            const int qi = base + lane;
-            if (qi < n_quads) {
-                const u64 q = quads[qi];
-                float qxy[8];
+            // ---- decode the board's quads (detector.rs:514-527); results in the candidates' space ---------------------
+            float *dec_xy = reinterpret_cast<float *>(wv + WV_CAND);           // [BCELLS][8]
+            int *dec_id = reinterpret_cast<int *>(wv + WV_CAND + BCELLS * 32);  // [BCELLS]: tag id or -1
+            for (int base = 0; base < n_quads; base += 64) {
+                const int qi = base + lane;
+                if (qi < n_quads) {
+                    const u64 q = quads[qi];
+                    float qxy[8];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    qxy[2 * i] = sx[q_at(q, i)];
-                    qxy[2 * i + 1] = sy[q_at(q, i)];
-                }
-                int id = -1, rot = 0;
-                if (!decode_quad(a, luma, qxy, id, rot)) id = -1;
-                dec_id[qi] = id;
-                if (id >= 0) {
+                    for (int i = 0; i < 4; ++i) {
+                        qxy[2 * i] = sx[q_at(q, i)];
+                        qxy[2 * i + 1] = sy[q_at(q, i)];
+                    }
+                    int id = -1, rot = 0;
+                    if (!decode_quad(a, luma, qxy, id, rot)) id = -1;
+                    dec_id[qi] = id;
+                    if (id >= 0) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {  // rotate_left(rot) then reverse, :468-469
-                        const int src = ((3 - i) + rot) & 3;
-                        float vx = qxy[0], vy = qxy[1];
-                        if (src == 1) { vx = qxy[2]; vy = qxy[3]; }
-                        if (src == 2) { vx = qxy[4]; vy = qxy[5]; }
-                        if (src == 3) { vx = qxy[6]; vy = qxy[7]; }
-                        dec_xy[8 * qi + 2 * i] = vx;
-                        dec_xy[8 * qi + 2 * i + 1] = vy;
+                        for (int i = 0; i < 4; ++i) {  // rotate_left(rot) then reverse, :468-469
+                            const int src = ((3 - i) + rot) & 3;
+                            float vx = qxy[0], vy = qxy[1];
+                            if (src == 1) { vx = qxy[2]; vy = qxy[3]; }
+                            if (src == 2) { vx = qxy[4]; vy = qxy[5]; }
+                            if (src == 3) { vx = qxy[6]; vy = qxy[7]; }
+                            dec_xy[8 * qi + 2 * i] = vx;
+                            dec_xy[8 * qi + 2 * i + 1] = vy;
+                        }
                     }
                 }
             }
-        }
-        for (int i = lane; i < TN / 32; i += 64) used[i] = 0;
-        __syncthreads();
-        int n_used = 0;
-        if (lane == 0) {
-            for (int qi = 0; qi < n_quads; ++qi) {
-                const int id = dec_id[qi];
-                if (id < 0) continue;
-                int at = -1;
-                for (int t = 0; t < n_tags; ++t)
-                    if (tagids[t] == (uint32_t)id) at = t;
-                if (at < 0) {
-                    if ((uint32_t)n_tags >= tag_cap) {
-                        status |= TAIL_CAPACITY | (1u << 15);
-                        break;
+            for (int i = lane; i < TN / 32; i += 64) used[i] = 0;
+            wsync();
+            int n_used = 0;
+            if (lane == 0) {
+                for (int qi = 0; qi < n_quads; ++qi) {
+                    const int id = dec_id[qi];
+                    if (id < 0) continue;
+                    int at = -1;
+                    for (int t = 0; t < n_tags; ++t)
+                        if (tagids[t] == (uint32_t)id) at = t;
+                    if (at < 0) {
+                        if ((uint32_t)n_tags >= tag_cap) {
+                            status |= TAIL_CAPACITY;
+                            break;
+                        }
+                        at = n_tags++;
+                        tagids[at] = (uint32_t)id;
                     }
-                    at = n_tags++;
-                    tagids[at] = (uint32_t)id;
-                }
-                agx_tag *o = a.tags + (size_t)f * a.tag_cap + at;
-                o->id = (uint32_t)id;
-                for (int i = 0; i < 8; ++i) o->xy[i] = dec_xy[8 * qi + i];
-                const u64 q = quads[qi];
-                for (int i = 0; i < 4; ++i) {
-                    const int s = q_at(q, i);
-                    if (!((used[s >> 5] >> (s & 31)) & 1u)) ++n_used;
-                    used[s >> 5] |= 1u << (s & 31);
+                    agx_tag *o = a.tags + (size_t)f * a.tag_cap + at;
+                    o->id = (uint32_t)id;
+                    for (int i = 0; i < 8; ++i) o->xy[i] = dec_xy[8 * qi + i];
+                    const u64 q = quads[qi];
+                    for (int i = 0; i < 4; ++i) {
+                        const int s = q_at(q, i);
+                        if (!((used[s >> 5] >> (s & 31)) & 1u)) ++n_used;
+                        used[s >> 5] |= 1u << (s & 31);
+                    }
                 }
             }
+            n_tags = __shfl(n_tags, 0);
+            n_used = __shfl(n_used, 0);
+            wsync();
+            TK(7);
+            // the saddles of decoded quads leave the list (:528-538), order kept
+            int kept = 0;
+            for (int base = 0; base < n; base += 64) {
+                const int i = base + lane;
+                const bool keep = i < n && !((used[i >> 5] >> (i & 31)) & 1u);
+                const float x = i < n ? sx[i] : 0.0f, y = i < n ? sy[i] : 0.0f, t = i < n ? st[i] : 0.0f;
+                const u64 mk = __ballot(keep);
+                wsync();
+                if (keep) {
+                    const int at = kept + __popcll(mk & below);
+                    sx[at] = x;
+                    sy[at] = y;
+                    st[at] = t;
+                }
+                kept += __popcll(mk);
+                wsync();
+            }
+            status = wave_or_u(status);
+            if (lane == 0) {
+                sh[1] = (uint32_t)kept;
+                sh[3] = (uint32_t)n_used;
+                if (status) atomicOr(&sh[0], status);
+            }
         }
-        n_tags = __shfl(n_tags, 0);
-        n_used = __shfl(n_used, 0);
         __syncthreads();
-        if (wave_or_u(status)) break;
-        if (n_used == 0) break;  // nothing removed: the next round would repeat this one
-        // the saddles of decoded quads leave the list (:528-538), order kept
-        int kept = 0;
-        for (int base = 0; base < n; base += 64) {
-            const int i = base + lane;
-            const bool keep = i < n && !((used[i >> 5] >> (i & 31)) & 1u);
-            const float x = i < n ? sx[i] : 0.0f, y = i < n ? sy[i] : 0.0f, t = i < n ? st[i] : 0.0f;
-            const u64 mk = __ballot(keep);
-            __syncthreads();
-            if (keep) {
-                const int at = kept + __popcll(mk & below);
-                sx[at] = x;
-                sy[at] = y;
-                st[at] = t;
-            }
-            kept += __popcll(mk);
-            __syncthreads();
-        }
-        n = kept;
+        if (sh[0]) break;
+        if (sh[3] == 0) break;  // nothing removed: the next round would repeat this one
+        n = (int)sh[1];
+        __syncthreads();  // (before wave 0 writes the shared words of the next round)
     }
-    status = wave_or_u(status);
-    if (lane == 0) {
-        a.table[2 * f] = status ? 0u : (uint32_t)n_tags;
-        a.table[2 * f + 1] = status;
+    __syncthreads();
+    const uint32_t st_all = sh[0];
+    if (a.debug >= 2 && f == 0 && tid == 0)
+        printf("tail frame 0 (wave 0): ticks grid %llu seeds %llu seed loop %llu (sort50 %llu lists %llu cands %llu boards %llu) fix %llu decode %llu; seeds %d cands %d; boards built by this wave %d, their cells %llu\n", tk[0], tk[1], tk[5],
+               tk[2], tk[3], tk[4], tk[8], tk[6], tk[7], n_seeds_done, n_cands_total, n_boards, tk[9]);
+    if (tid == 0) {
+        a.table[2 * f] = st_all ? 0u : (uint32_t)n_tags;
+        a.table[2 * f + 1] = st_all;
     }
 }
 
@@ -884,7 +997,7 @@ int init_tail_kernels()
 int launch_board_tail(const TailArgs &t, void *stream)
 {
     if (t.n_frames <= 0) return (int)hipSuccess;
-    hipLaunchKernelGGL(k_board_tail, dim3((unsigned)t.n_frames), dim3(64), LDS_BYTES, (hipStream_t)stream, t);
+    hipLaunchKernelGGL(k_board_tail, dim3((unsigned)t.n_frames), dim3(64 * TW), LDS_BYTES, (hipStream_t)stream, t);
     return (int)hipGetLastError();
 }
 
