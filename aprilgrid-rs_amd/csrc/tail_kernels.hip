@@ -43,7 +43,7 @@ namespace {
 constexpr int TN = TAIL_MAX_SADDLES;
 constexpr int TGC = 1024;    // cells of the k-NN grid
 constexpr int TCAND = 1024;  // candidate quads of one seed
-constexpr int TW = 4;        // waves per frame
+constexpr int TW = 8;        // waves per frame
 constexpr int BCELLS = 128;  // cells (found or not) of one board
 constexpr int BGR = 12, BGN = 2 * BGR + 1;  // board cells live within +-BGR of the seed's cell
 constexpr int TTAGS = 128;   // distinct tag ids of one frame
@@ -75,11 +75,10 @@ constexpr int OFF_QUADS = OFF_SEEDS + TN * 2;              // u64[BCELLS]
 constexpr int OFF_TAGIDS = OFF_QUADS + BCELLS * 8;         // u32[TTAGS]
 constexpr int OFF_USED = OFF_TAGIDS + TTAGS * 4;           // u32[TN / 32]
 constexpr int OFF_HIST = OFF_USED + TN / 8;                // u32[364]
-constexpr int OFF_SHARED = OFF_HIST + 364 * 4;             // u32[16] + u64[TW]: what the waves tell each other
-constexpr int OFF_BEST = OFF_SHARED + 64 + TW * 8;         // the chosen board
-constexpr int OFF_WAVES = OFF_BEST + SL_BYTES;
+constexpr int OFF_SHARED = OFF_HIST + 364 * 4;             // u32[8 + 2 * TW]: what the waves tell each other
+constexpr int OFF_WAVES = OFF_SHARED + (8 + 2 * TW) * 4;
 constexpr int LDS_BYTES = OFF_WAVES + TW * WV_BYTES;
-static_assert(OFF_QUADS % 8 == 0 && OFF_SHARED % 8 == 0 && OFF_BEST % 8 == 0 && OFF_WAVES % 8 == 0, "alignment");
+static_assert(OFF_QUADS % 8 == 0 && OFF_SHARED % 8 == 0 && OFF_WAVES % 8 == 0, "alignment");
 
 constexpr float kPiF = 3.14159274101257324219f;
 // The white-block angle: cosf / sinf within 1 ulp move the direction by < 1.2e-7 rad (7e-6 degrees), the reference's six
@@ -156,16 +155,27 @@ __device__ __forceinline__ float angle_degree(float v0x, float v0y, float v1x, f
     return fdlibm_atan2f(v1y * v0x - v1x * v0y, v0x * v1x + v0y * v1y) * 180.0f / kPiF;
 }
 
-// saddle.rs:26-38 "filter white block" for (s0, s1): 1 passes, 0 fails, 2 too close to a threshold to say here
+// saddle.rs:26-38 "filter white block" for (s0, s1): 1 passes, 0 fails, 2 too close to a threshold to say here.
+// Nearly every angle is degrees away from 60 and 120: those are decided from the reference's expression evaluated with
+// this device's sincosf (<= 4 ulp, the OpenCL bound: the angle within 2e-4 degrees of the reference's -- the argument of
+// kBandAbs with a 4-ulp direction on one side); only within 1e-3 degrees of a threshold is the binary64 evaluation made.
 __device__ __forceinline__ int white_block(float s0_theta, float v02x, float v02y)
 {
-    const float th = s0_theta / 180.0f * kPiF;
-    double sd, cd;
-    sincos((double)th, &sd, &cd);
-    const double y = sd * (double)v02x - cd * (double)v02y, x = (double)v02x * cd + (double)v02y * sd;
     // s1 == s0 (try_expand_one pairs the same saddle with itself when the candidate lists overlap): both atan2f operands are
     // zeros whatever cosf / sinf return, the angle is 0 or 180
     if (v02x == 0.0f && v02y == 0.0f) return 0;
+    const float th = s0_theta / 180.0f * kPiF;
+    {
+        float sf, cf;
+        sincosf(th, &sf, &cf);
+        const float yf = sf * v02x - cf * v02y, xf = v02x * cf + v02y * sf;
+        const float af = fabsf(fdlibm_atan2f(yf, xf) * 180.0f / kPiF);
+        if (af < 60.0f - 1e-3f || af > 120.0f + 1e-3f) return 0;
+        if (af > 60.0f + 1e-3f && af < 120.0f - 1e-3f) return 1;
+    }
+    double sd, cd;
+    sincos((double)th, &sd, &cd);
+    const double y = sd * (double)v02x - cd * (double)v02y, x = (double)v02x * cd + (double)v02y * sd;
     const double m = fabs(y) + fabs(x);
     if (!(m > 0.0) || !(m < 1e300)) return 2;
     const double a = fabs(atan2(y, x)) * kDegD;
@@ -235,6 +245,23 @@ __device__ __forceinline__ uint32_t wave_or_u(uint32_t v)
     for (int o = 32; o; o >>= 1) v |= (uint32_t)__shfl_xor((int)v, o);
     return v;
 }
+// minimum over the lane's row of 16, in every lane of the row (DPP: no LDS crossbar)
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint32_t row_min_u(uint32_t v)
+{
+    uint32_t t = dpp_u<0xB1>(v);  // quad_perm [1, 0, 3, 2]
+    v = t < v ? t : v;
+    t = dpp_u<0x4E>(v);           // quad_perm [2, 3, 0, 1]
+    v = t < v ? t : v;
+    t = dpp_u<0x141>(v);          // row_half_mirror
+    v = t < v ? t : v;
+    t = dpp_u<0x140>(v);          // row_mirror
+    return t < v ? t : v;
+}
 __device__ __forceinline__ u64 shfl_u64(u64 v, int src)
 {
     const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src), hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), src);
@@ -276,8 +303,10 @@ __device__ __forceinline__ u64 q_make(int a, int b, int c, int d) { return (u64)
 // by `dist_sq <= radius_sq` leaves: a saddle within the radius that is among the three nearest of all is among the three
 // nearest of those within the radius, and the other way round), found in the grid cells the radius reaches.  Then the
 // reference's four nested loops as one combination per lane; the first valid one in loop order is the result.
-__device__ bool expand_one_w(const Ctx &c, const uint8_t *slot, u64 qs, u64 &out, int lane, uint32_t &status)
+__device__ bool expand_one_w(const Ctx &c, const uint8_t *slot, u64 qs, u64 &out, int lane, uint32_t &status, unsigned long long *ek)
 {
+    unsigned long long e_last = wall_clock64();
+#define EK(i) do { const unsigned long long t_now = wall_clock64(); ek[i] += t_now - e_last; e_last = t_now; } while (0)
     const int g = lane >> 4, l = lane & 15;
     const int ia = g < 2 ? q_at(qs, 0) : q_at(qs, 3), ib = g < 2 ? q_at(qs, 1) : q_at(qs, 2);  // the pair (first, second)
     const int anchor = (g & 1) ? ib : ia;                                                      // whose neighbour is looked for
@@ -298,18 +327,16 @@ __device__ bool expand_one_w(const Ctx &c, const uint8_t *slot, u64 qs, u64 &out
             for (int t = t0 + l; t < t1; t += 16) top3_insert(dist_key(qx, qy, c.gx[t], c.gy[t], c.gi[t]), k0, k1, k2);
         }
     }
+    EK(0);
     // the three smallest keys of the 16 lanes, filtered as :207-221 (radius, still unused by this board, same orientation)
     u64 list = 0;
     int cnt = 0;
     const float at = c.st[anchor];
 #pragma unroll
     for (int rk = 0; rk < 3; ++rk) {
-        u64 m = k0;
-#pragma unroll
-        for (int o = 8; o; o >>= 1) {
-            const u64 v = shfl_xor_u64(m, o);
-            m = v < m ? v : m;
-        }
+        const uint32_t hi0 = (uint32_t)(k0 >> 32), mh = row_min_u(hi0);  // (distance, index): the distance first ...
+        const uint32_t ml = row_min_u(hi0 == mh ? (uint32_t)k0 : 0xffffffffu);  // ... then the index among the nearest
+        const u64 m = (u64)mh << 32 | ml;
         if (k0 == m && m != ~0ull) {
             k0 = k1;
             k1 = k2;
@@ -323,9 +350,13 @@ __device__ bool expand_one_w(const Ctx &c, const uint8_t *slot, u64 qs, u64 &out
         }
     }
     list |= (u64)cnt << 48;
+    EK(1);
     const u64 l0 = shfl_u64(list, 0), l1 = shfl_u64(list, 16), l3 = shfl_u64(list, 32), l2 = shfl_u64(list, 48);
     const int n0 = (int)(l0 >> 48), n1 = (int)(l1 >> 48), n2 = (int)(l2 >> 48), n3 = (int)(l3 >> 48);
+    EK(2);
+    ek[5] += 1;
     if (n0 == 0 || n1 == 0 || n2 == 0 || n3 == 0) return false;  // (an empty loop)
+    ek[6] += 1;
     for (int pass = 0; pass < 2; ++pass) {
         const int L = lane + 64 * pass;  // the combination's number in loop order: ((i0 * 3 + i1) * 3 + i2) * 3 + i3
         const int j0 = L / 27, j1 = (L / 9) % 3, j2 = (L / 3) % 3, j3 = L % 3;
@@ -337,16 +368,18 @@ __device__ bool expand_one_w(const Ctx &c, const uint8_t *slot, u64 qs, u64 &out
         if (mu & (first == 64 ? ~0ull : ((1ull << first) - 1ull))) status |= TAIL_UNCERTAIN;  // an undecided one before it
         if (mv) {
             out = shfl_u64(q_make(a, b, cc, d), first);
+            EK(3);
             return true;
         }
         if (n0 < 3) break;  // (combinations 64 .. 80 have i0 = 2)
     }
+    EK(3);
     return false;
 }
 
 // Board::new (board.rs:26-48): the board grown from a seed quad; returns its score, the cells stay in the slot.
 // try_expand's recursion (:114-152) is a stack of (cell, next direction) walked by all lanes alike; lane 0 writes.
-__device__ int build_board_w(const Ctx &c, uint8_t *slot, u64 seed, int lane, int &n_cells_out, uint32_t &status)
+__device__ int build_board_w(const Ctx &c, uint8_t *slot, u64 seed, int lane, int &n_cells_out, uint32_t &status, unsigned long long *ek)
 {
     {
         uint32_t *g = reinterpret_cast<uint32_t *>(slot + SL_GRID);
@@ -390,7 +423,7 @@ __device__ int build_board_w(const Ctx &c, uint8_t *slot, u64 seed, int lane, in
         const u64 quad = slot_quad(slot, cell);
         const u64 qs = i ? (quad >> (16 * i) | quad << (64 - 16 * i)) : quad;  // qs[j] = quad[(j + i) & 3]
         u64 nq = 0;
-        const bool ok = expand_one_w(c, slot, qs, nq, lane, status);
+        const bool ok = expand_one_w(c, slot, qs, nq, lane, status, ek);
         int at = e;
         if (at == 0xff) {
             if (n_cells == BCELLS) {
@@ -640,7 +673,7 @@ __global__ void __launch_bounds__(64 * TW) k_board_tail(TailArgs a)
     uint32_t *tagids = reinterpret_cast<uint32_t *>(lds + OFF_TAGIDS);
     uint32_t *used = reinterpret_cast<uint32_t *>(lds + OFF_USED);
     uint32_t *hist = reinterpret_cast<uint32_t *>(lds + OFF_HIST);
-    uint32_t *sh = reinterpret_cast<uint32_t *>(lds + OFF_SHARED);  // [0] status, [1] n, [2] seeds, [3] saddles removed, [4 .. 4 + TW) candidates per wave, [8 .. 8 + TW) the seeds' best boards, [12] the boards handed out
+    uint32_t *sh = reinterpret_cast<uint32_t *>(lds + OFF_SHARED);  // [0] status, [1] n, [2] seeds, [3] saddles removed, [4] the boards handed out, [8 .. 8 + TW) candidates per wave, [8 + TW ..) the seeds' best boards
     uint8_t *wv = lds + OFF_WAVES + wave * WV_BYTES;  // this wave's own
     uint32_t *tmp32 = reinterpret_cast<uint32_t *>(wv + WV_CAND);
 
@@ -648,6 +681,7 @@ __global__ void __launch_bounds__(64 * TW) k_board_tail(TailArgs a)
     int n_tags = 0;       // (wave 0)
     unsigned long long tk[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = wall_clock64();
     int n_cands_total = 0, n_seeds_done = 0, n_boards = 0;
+    unsigned long long ek[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define TK(i) do { const unsigned long long t_now = wall_clock64(); tk[i] += t_now - t_last; t_last = t_now; } while (0)
     const FrameCounters &fc = a.ctr[f];
     int n = (int)fc.n_out;
@@ -768,26 +802,27 @@ __global__ void __launch_bounds__(64 * TW) k_board_tail(TailArgs a)
         uint32_t best_score = 0;
         u64 best_quad = 0;
         bool stop = false;
-        for (int base = 0; base < total && !stop; base += TW) {
+        // (the first seed alone: it usually finds the board and ends the loop -- its neighbours in the list would find it again)
+        for (int base = 0, gw = 1; base < total && !stop; base += gw, gw = TW) {
             const int k = base + wave;
             int nc_mine = 0;
-            if (k < total) {
+            if (wave < gw && k < total) {
                 nc_mine = init_quads_w(c, wv, seeds[n_seeds - 1 - k], lane, status, tk);
                 n_cands_total += nc_mine;
                 ++n_seeds_done;
             }
             if (lane == 0) {
-                sh[4 + wave] = (uint32_t)nc_mine;
-                sh[8 + wave] = 0;
-                if (wave == 0) sh[12] = 0;
+                sh[8 + wave] = (uint32_t)nc_mine;
+                sh[8 + TW + wave] = 0;
+                if (wave == 0) sh[4] = 0;
             }
             __syncthreads();
             int first_item[TW + 1];
             first_item[0] = 0;
 #pragma unroll
-            for (int w = 0; w < TW; ++w) first_item[w + 1] = first_item[w] + (int)sh[4 + w];
+            for (int w = 0; w < TW; ++w) first_item[w + 1] = first_item[w] + (int)sh[8 + w];
             for (;;) {
-                int item = lane == 0 ? (int)atomicAdd(&sh[12], 1u) : 0;
+                int item = lane == 0 ? (int)atomicAdd(&sh[4], 1u) : 0;
                 item = __shfl(item, 0);
                 if (item >= first_item[TW]) break;
                 int w = 0;
@@ -795,22 +830,22 @@ __global__ void __launch_bounds__(64 * TW) k_board_tail(TailArgs a)
                 for (int t = 1; t < TW; ++t) w += item >= first_item[t];
                 int ci = item;
 #pragma unroll
-                for (int t = 1; t < TW; ++t) ci -= (item >= first_item[t]) ? (int)sh[4 + t - 1] : 0;
+                for (int t = 1; t < TW; ++t) ci -= (item >= first_item[t]) ? (int)sh[8 + t - 1] : 0;
                 const u64 q = reinterpret_cast<const u64 *>(lds + OFF_WAVES + w * WV_BYTES + WV_CAND)[ci];
                 int cells;
                 const unsigned long long tb0 = wall_clock64();
-                const uint32_t score = (uint32_t)build_board_w(c, wv + WV_SLOT, q, lane, cells, status);
+                const uint32_t score = (uint32_t)build_board_w(c, wv + WV_SLOT, q, lane, cells, status, ek);
                 tk[8] += wall_clock64() - tb0;
                 tk[9] += (unsigned long long)cells;
                 ++n_boards;
                 // the seed's best score and the FIRST candidate that reaches it (what the sequential loop is left with, :616-622)
-                if (lane == 0) atomicMax(&sh[8 + w], score << 16 | (uint32_t)(0xffff - ci));
+                if (lane == 0) atomicMax(&sh[8 + TW + w], score << 16 | (uint32_t)(0xffff - ci));
             }
             status = wave_or_u(status);
             if (lane == 0 && status) atomicOr(&sh[0], status);
             __syncthreads();
-            for (int w = 0; w < TW && base + w < total; ++w) {  // the reference's order
-                const uint32_t key = sh[8 + w];
+            for (int w = 0; w < gw && base + w < total; ++w) {  // the reference's order
+                const uint32_t key = sh[8 + TW + w];
                 if ((key >> 16) > best_score) {
                     best_score = key >> 16;
                     best_quad = reinterpret_cast<const u64 *>(lds + OFF_WAVES + w * WV_BYTES + WV_CAND)[0xffff - (key & 0xffffu)];
@@ -831,7 +866,7 @@ __global__ void __launch_bounds__(64 * TW) k_board_tail(TailArgs a)
             // all_tag_indexes (board.rs:49-112), cells in insertion order
             uint8_t *slot = wv + WV_SLOT;
             int best_cells = 0;
-            (void)build_board_w(c, slot, best_quad, lane, best_cells, status);
+            (void)build_board_w(c, slot, best_quad, lane, best_cells, status, ek);
             int n_quads = 0;
             if (lane == 0) {
                 const int8_t *xy = reinterpret_cast<const int8_t *>(slot + SL_XY);
@@ -981,6 +1016,8 @@ __global__ void __launch_bounds__(64 * TW) k_board_tail(TailArgs a)
     if (a.debug >= 2 && f == 0 && tid == 0)
         printf("tail frame 0 (wave 0): ticks grid %llu seeds %llu seed loop %llu (sort50 %llu lists %llu cands %llu boards %llu) fix %llu decode %llu; seeds %d cands %d; boards built by this wave %d, their cells %llu\n", tk[0], tk[1], tk[5],
                tk[2], tk[3], tk[4], tk[8], tk[6], tk[7], n_seeds_done, n_cands_total, n_boards, tk[9]);
+    if (a.debug >= 2 && f == 0 && tid == 0)
+        printf("  expand_one: scan %llu reduce+filter %llu broadcast %llu combos %llu; calls %llu, with all four lists %llu\n", ek[0], ek[1], ek[2], ek[3], ek[5], ek[6]);
     if (tid == 0) {
         a.table[2 * f] = st_all ? 0u : (uint32_t)n_tags;
         a.table[2 * f + 1] = st_all;

@@ -1,0 +1,161 @@
+"""Option "device_tail": agx_detect_batch's board search + decode as a HIP kernel (csrc/tail_kernels.hip) behind the chain.
+
+The kernel must return exactly what the host tail returns for every frame it keeps (ids, corners bit for bit, insertion
+order, per-frame status), and hand every other frame back to the host tail -- so the option never changes a result.  The
+host tail itself is pinned against the oracle and the reference's tag counts in tests/test_gpu_parity.py; here the two
+tails are compared with each other on the same saddles, and with the oracle where the frames are small."""
+import numpy as np
+import pytest
+
+from util import ALL_IMAGES, REFERENCE_TAG_COUNTS, bits_equal, load_image, synth_module
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import oracle as O
+    O.lib()
+    return O
+
+
+@pytest.fixture(scope="module")
+def pair():
+    import aprilgrid_rs_amd as A
+    host = A.TagDetector("t36h11", None, device=0)
+    dev = A.TagDetector("t36h11", None, device=0)
+    dev.set_option("device_tail", 1)
+    assert dev.get_option("device_tail") == 1 and host.get_option("device_tail") == 0
+    yield host, dev
+    host.close()
+    dev.close()
+
+
+def same_results(host, dev, frames, cap=128, device_frames=None, threads=4):
+    """Both detectors over the same batch -> (tags per frame, frames the kernel handed back)."""
+    rc_h, out_h, cnt_h, st_h = host.detect_batch_raw(frames, n_threads=threads, cap=cap, device_frames=device_frames)
+    rc_d, out_d, cnt_d, st_d = dev.detect_batch_raw(frames, n_threads=threads, cap=cap, device_frames=device_frames)
+    assert rc_h == rc_d, (rc_h, rc_d)
+    assert np.array_equal(st_h, st_d), (st_h, st_d)
+    assert np.array_equal(cnt_h, cnt_d), np.nonzero(cnt_h != cnt_d)
+    for f in range(len(frames)):
+        if st_h[f] == 0:
+            assert out_h[f, : cnt_h[f]].tobytes() == out_d[f, : cnt_d[f]].tobytes(), "frame %d" % f
+    assert dev.get_option("last_device_tail_frames") == len(frames)
+    return cnt_h, dev.get_option("last_device_tail_fallbacks")
+
+
+def test_the_benchmarks_frames_keep_their_tags(pair):
+    """configs[1]'s 256 frames (1280 x 800, one board each): the device tail's tags are the host tail's, and the kernel keeps
+    nearly every frame (a frame goes back only for an angle within 1e-4 degrees of 60 / 120 in a quad that otherwise passes)."""
+    host, dev = pair
+    synth = synth_module()
+    fr, _ = synth.render_batch(0, 256, 1280, 800, device="cuda")
+    frames = fr.cpu().numpy()
+    counts, back = same_results(host, dev, frames, threads=0)
+    assert counts.mean() > 30
+    assert back <= 8, back
+    # configs[2]'s last shard, from a device copy as well
+    fr, _ = synth.render_batch(1792, 64, 1280, 800, device="cuda")
+    counts, back = same_results(host, dev, fr.cpu().numpy(), device_frames=fr, threads=0)
+    assert counts.mean() > 30 and back <= 4
+
+
+@pytest.mark.parametrize("fmt", ["L8", "L16", "RGB8"])
+def test_formats_and_the_oracle(pair, oracle, fmt):
+    """Small frames in the three formats (the decode reads the device's own to_luma8 for L16 / RGB8): equal to the host tail
+    and, frame by frame, to the oracle's detect."""
+    host, dev = pair
+    synth = synth_module()
+    n = 70
+    fr, _ = synth.render_batch(300, n, 320, 240, device="cuda", fmt=fmt)
+    frames = fr.cpu().numpy()
+    if fmt == "L16":
+        frames = frames.view(np.uint16)
+    same_results(host, dev, frames)
+    got = dev.detect_batch(frames, n_threads=4)
+    n_tags = 0
+    for i in range(0, n, 3):
+        ref = oracle.detect(frames[i])
+        assert sorted(got[i]) == sorted(ref), i
+        for t in ref:
+            assert bits_equal(got[i][t], ref[t])
+        n_tags += len(ref)
+    assert n_tags > 20 * (n // 3)
+
+
+@pytest.mark.parametrize("name", ALL_IMAGES)
+def test_fixture_images(pair, name):
+    """The reference's images (two boards, 66 tags, 16-bit, RGB): a batch of one through the device tail gives detect()'s map
+    -- and the reference's own tag counts (tests/test_detector.rs:26-32)."""
+    host, dev = pair
+    img = load_image(name)
+    counts, _ = same_results(host, dev, img[None], cap=128)
+    one = host.detect(img)
+    got = dev.detect_batch(img[None], n_threads=2)[0]
+    assert list(got) == list(one)
+    for t in one:
+        assert bits_equal(got[t], one[t])
+    expected = dict(REFERENCE_TAG_COUNTS).get(name)
+    if expected is not None:
+        assert counts[0] == expected
+
+
+@pytest.mark.parametrize("family", ["T16H5", "T25H7", "T25H9", "T36H11B1"])
+def test_other_families(oracle, family):
+    import aprilgrid_rs_amd as A
+    synth = synth_module()
+    d = A.TagDetector(family, None, device=0)
+    d.set_option("device_tail", 1)
+    imgs = np.stack([synth.render_frame(21 + i, 800, 600, spec=synth.BoardSpec(rows=5, cols=5), family=family)[0].numpy() for i in range(4)])
+    got = d.detect_batch(imgs, n_threads=2)
+    assert d.get_option("last_device_tail_fallbacks") <= 1
+    for i in range(4):
+        ref = oracle.detect(imgs[i], family=family)
+        assert sorted(got[i]) == sorted(ref) and len(ref) >= 20
+        for t in ref:
+            assert bits_equal(got[i][t], ref[t])
+    d.close()
+
+
+@pytest.mark.parametrize("boards", [1, 3])
+def test_max_num_of_boards(boards):
+    import aprilgrid_rs_amd as A
+    p = A.DetectorParams.default_params()
+    p.max_num_of_boards = boards
+    host = A.TagDetector("t36h11", p, device=0)
+    dev = A.TagDetector("t36h11", p, device=0)
+    dev.set_option("device_tail", 1)
+    two = load_image("two_boards.png")
+    counts, _ = same_results(host, dev, two[None])
+    assert counts[0] == (36 if boards == 1 else 72)
+    synth = synth_module()
+    fr, _ = synth.render_batch(40, 24, 640, 480, device="cuda")
+    same_results(host, dev, fr.cpu().numpy())
+    host.close()
+    dev.close()
+
+
+def test_frames_the_kernel_cannot_take(pair):
+    """More saddles than the kernel's lists hold (pure noise), no saddles at all, and more tags than the caller's capacity:
+    the first go to the host tail, the second need nothing, the third report AGX_ERR_CAPACITY -- as without the option."""
+    host, dev = pair
+    synth = synth_module()
+    noise, _ = synth.render_batch(3, 3, 640, 480, device="cuda", pure_noise=True)
+    flat = np.full((2, 480, 640), 128, np.uint8)
+    board, _ = synth.render_batch(300, 3, 640, 480, device="cuda")
+    frames = np.concatenate([noise.cpu().numpy(), flat, board.cpu().numpy()])
+    counts, back = same_results(host, dev, frames)
+    assert back == 3 and list(counts[:5]) == [0] * 5 and counts[5:].min() > 10
+    cap = int(counts[5:].max()) - 1
+    rc_h, _, cnt_h, st_h = host.detect_batch_raw(frames, n_threads=2, cap=cap)
+    rc_d, _, cnt_d, st_d = dev.detect_batch_raw(frames, n_threads=2, cap=cap)
+    assert rc_h == rc_d != 0 and np.array_equal(st_h, st_d) and np.array_equal(cnt_h, cnt_d) and (st_d != 0).any()
+
+
+def test_the_option_is_refused_where_libm_differs():
+    """The kernel evaluates atan2f by glibc's routine; the option checks the host's atan2f against it first (here: equal)."""
+    import ctypes as C
+    import aprilgrid_rs_amd as A
+    bad = C.c_uint64(1)
+    assert A._ffi.lib().agx_debug_libm_atan2f_check(1 << 22, 7, C.byref(bad)) == 0 and bad.value == 0
