@@ -345,13 +345,27 @@ static int detect_batch_device_tail(agx_detector *det, const void *frames, const
         if (std::getenv("AGX_TAIL_DEBUG")) {
             int h[32] = {0};
             for (int f = 0; f < nf; ++f)
-                for (int b = 0; b < 32; ++b) h[b] += (table[2 * f + 1] >> b) & 1u;
+                for (int b = 0; b < 32; ++b) h[b] += (table[4 * f + 1] >> b) & 1u;
             for (int b = 0; b < 32; ++b)
                 if (h[b]) std::fprintf(stderr, "tail status bit %d: %d frames\n", b, h[b]);
+            std::vector<std::pair<uint32_t, int>> tk;
+            double sum = 0;
+            for (int f = 0; f < nf; ++f) {
+                tk.push_back({table[4 * f + 2], f});
+                sum += table[4 * f + 2];
+            }
+            std::sort(tk.begin(), tk.end());
+            std::fprintf(stderr, "tail ticks per frame (100 MHz): mean %.0f median %u p90 %u max %u; slowest:", sum / nf, tk[(size_t)nf / 2].first,
+                         tk[(size_t)nf * 9 / 10].first, tk.back().first);
+            for (int i = 0; i < 5 && i < nf; ++i) {
+                const int f = tk[(size_t)(nf - 1 - i)].second;
+                std::fprintf(stderr, " [frame %d: %u ticks, %u saddles, %u seeds, %u tags]", c0 + f, table[4 * f + 2], table[4 * f + 3] & 0xffff, table[4 * f + 3] >> 16, table[4 * f]);
+            }
+            std::fprintf(stderr, "\n");
         }
         for (int f = 0; f < nf; ++f) {
             const int gf = c0 + f;
-            const uint32_t st = table[2 * f + 1], nt = table[2 * f];
+            const uint32_t st = table[4 * f + 1], nt = table[4 * f];
             if (st != TAIL_OK) {
                 any_back = true;
                 continue;
@@ -377,7 +391,7 @@ static int detect_batch_device_tail(agx_detector *det, const void *frames, const
             pending_batch = false;
             if (rc) break;
             for (int f = 0; f < nf; ++f) {
-                if (table[2 * f + 1] == TAIL_OK) continue;
+                if (table[4 * f + 1] == TAIL_OK) continue;
                 const int gf = c0 + f;
                 if (fst[(size_t)f] != AGX_OK) {  // reported, never truncated
                     counts[gf] = 0;
@@ -387,7 +401,7 @@ static int detect_batch_device_tail(agx_detector *det, const void *frames, const
                     continue;
                 }
                 ++n_fallback;
-                n_uncertain += (table[2 * f + 1] & TAIL_UNCERTAIN) != 0;
+                n_uncertain += (table[4 * f + 1] & TAIL_UNCERTAIN) != 0;
                 handed_back.emplace_back(records + offs[(size_t)f], records + offs[(size_t)f] + ns[(size_t)f]);
                 const std::vector<agx_saddle> *list = &handed_back.back();
                 const uint8_t *img = h_chunk + (size_t)f * frame_stride_bytes;

@@ -119,7 +119,7 @@ struct agx_detector {
     int device_tail = 0;
     uint64_t *d_codes = nullptr;                                     // the family's code list
     agx_tag *h_tags = nullptr, *h_tags_dev = nullptr;                // mapped pinned [tail_frames][tail_tag_cap]
-    uint32_t *h_tail_table = nullptr, *h_tail_table_dev = nullptr;   // mapped pinned [tail_frames][2]: count, status
+    uint32_t *h_tail_table = nullptr, *h_tail_table_dev = nullptr;   // mapped pinned [tail_frames][4]: count, status, ticks, saddles | seeds << 16
     size_t tail_frames = 0;
     uint32_t tail_tag_cap = 0;
     int last_tail_frames = 0, last_tail_fallbacks = 0, last_tail_uncertain = 0;  // of the last agx_detect_batch call
@@ -641,7 +641,7 @@ __attribute__((visibility("hidden"))) int agx_internal_enqueue_tail(agx_detector
         det->tail_frames = 0;
         const size_t F = std::max((size_t)a.n_frames, det->tail_frames), cap = std::max(tag_cap, det->tail_tag_cap);
         if (hipHostMalloc((void **)&det->h_tags, F * cap * sizeof(agx_tag), hipHostMallocMapped) != hipSuccess) return AGX_ERR_HIP;
-        if (hipHostMalloc((void **)&det->h_tail_table, F * 2 * sizeof(uint32_t), hipHostMallocMapped) != hipSuccess) return AGX_ERR_HIP;
+        if (hipHostMalloc((void **)&det->h_tail_table, F * 4 * sizeof(uint32_t), hipHostMallocMapped) != hipSuccess) return AGX_ERR_HIP;
         if (hipHostGetDevicePointer((void **)&det->h_tags_dev, det->h_tags, 0) != hipSuccess) return AGX_ERR_HIP;
         if (hipHostGetDevicePointer((void **)&det->h_tail_table_dev, det->h_tail_table, 0) != hipSuccess) return AGX_ERR_HIP;
         det->tail_frames = F;

@@ -34,7 +34,7 @@ struct TailArgs {
     int edge, border, hamming, n_codes;
     const uint64_t *codes;  // device copy of the family's code list
     int max_boards;
-    // results: tags[f][tag_cap], table[f] = {count, status}
+    // results: tags[f][tag_cap], table[f] = {count, status, ticks (100 MHz) the frame took, saddles | seeds << 16}
     agx_tag *tags;
     uint32_t *table;
     uint32_t tag_cap;

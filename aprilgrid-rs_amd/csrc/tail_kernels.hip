@@ -42,7 +42,8 @@ namespace {
 
 constexpr int TN = TAIL_MAX_SADDLES;
 constexpr int TGC = 1024;    // cells of the k-NN grid
-constexpr int TCAND = 1024;  // candidate quads of one seed
+constexpr int TCAND = 512;   // candidate quads of one seed
+constexpr int TA3 = 1024;    // (d0, d1) pairs of a seed whose angle a3 is kept in a table
 constexpr int TW = 8;        // waves per frame
 constexpr int BCELLS = 128;  // cells (found or not) of one board
 constexpr int BGR = 12, BGN = 2 * BGR + 1;  // board cells live within +-BGR of the seed's cell
@@ -60,10 +61,12 @@ static_assert(BGN * BGN <= SL_ACTIVE - SL_GRID, "board grid");
 static_assert(TN / 8 <= SL_STACK - SL_ACTIVE, "active mask");
 
 // a wave's own LDS (bytes)
-constexpr int WV_CAND = 0;                      // u64[TCAND]; also u64[TN] distance keys; wave 0: u32[2 * TGC] while the grid is built, decode results
-constexpr int WV_PAIRS = WV_CAND + TCAND * 8;   // u16[1176 + pad]
-constexpr int WV_SMALL = WV_PAIRS + 1184 * 2;   // u16[3][64]: same, diff, the white-block test per s1
-constexpr int WV_SLOT = WV_SMALL + 384;         // the board under construction
+constexpr int WV_CAND = 0;                      // u64[TCAND]; also u64[TN] distance keys; wave 0: u32[2 * TGC] while the grid is built (with
+                                                // the table behind it), decode results
+constexpr int WV_A3 = WV_CAND + TCAND * 8;      // f32[TA3]: angle(v30, v01) of the seed's (d0, d1) pairs
+constexpr int WV_PAIRS = WV_A3 + TA3 * 4;       // u16[1176 + pad]
+constexpr int WV_SMALL = WV_PAIRS + 1184 * 2;   // u16[3][64]: same, diff, the white-block test per s1; f32[2][64]: a0, a2 of the current s1
+constexpr int WV_SLOT = WV_SMALL + 1024;        // the board under construction
 constexpr int WV_BYTES = WV_SLOT + SL_BYTES;
 static_assert(WV_BYTES % 8 == 0, "alignment");
 // the frame's LDS (bytes)
@@ -267,11 +270,6 @@ __device__ __forceinline__ u64 shfl_u64(u64 v, int src)
     const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src), hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), src);
     return (u64)hi << 32 | lo;
 }
-__device__ __forceinline__ u64 shfl_xor_u64(u64 v, int mask)
-{
-    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, mask), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), mask);
-    return (u64)hi << 32 | lo;
-}
 
 // ---- a board, grown by the whole wave (its slot in LDS) -----------------------------------------------------------
 
@@ -321,32 +319,59 @@ __device__ bool expand_one_w(const Ctx &c, const uint8_t *slot, u64 qs, u64 &out
     if (!(r < 3e38f)) {  // (not on image coordinates) everything
         for (int t = l; t < c.n; t += 16) top3_insert(dist_key(qx, qy, c.gx[t], c.gy[t], c.gi[t]), k0, k1, k2);
     } else {
+        // the cell rows the radius reaches, four at a time: four lanes per row, each takes every fourth saddle of the row's
+        // run (a run holds a handful) -- the rows' bounds in one LDS round trip, their saddles in one or two more
         const int xa = cell_x(c, qx - r), xb = cell_x(c, qx + r), ya = cell_y(c, qy - r), yb = cell_y(c, qy + r);
-        for (int y = ya; y <= yb; ++y) {
-            const int t0 = c.gstart[y * c.nx + xa], t1 = c.gstart[y * c.nx + xb + 1];
-            for (int t = t0 + l; t < t1; t += 16) top3_insert(dist_key(qx, qy, c.gx[t], c.gy[t], c.gi[t]), k0, k1, k2);
+        for (int y0 = ya; y0 <= yb; y0 += 4) {
+            const int y = y0 + (l >> 2);
+            if (y <= yb) {
+                const int t0 = c.gstart[y * c.nx + xa], t1 = c.gstart[y * c.nx + xb + 1];
+                for (int t = t0 + (l & 3); t < t1; t += 4) top3_insert(dist_key(qx, qy, c.gx[t], c.gy[t], c.gi[t]), k0, k1, k2);
+            }
         }
     }
     EK(0);
-    // the three smallest keys of the 16 lanes, filtered as :207-221 (radius, still unused by this board, same orientation)
+    // the three smallest keys of the 16 lanes ...
+    u64 top0, top1, top2;
+    {
+        uint32_t hi0 = (uint32_t)(k0 >> 32), mh = row_min_u(hi0);             // (distance, index): the distance first ...
+        uint32_t ml = row_min_u(hi0 == mh ? (uint32_t)k0 : 0xffffffffu);      // ... then the index among the nearest
+        top0 = (u64)mh << 32 | ml;
+        // a query with nothing within its radius leaves an empty list, and try_expand_one's loops are empty with it (keys
+        // ascend by distance: the nearest decides)
+        const bool none = top0 == ~0ull || !(__uint_as_float(mh) <= radius_sq);
+        if (__ballot(none)) {
+            EK(1);
+            ek[5] += 1;
+            return false;
+        }
+        if (k0 == top0) { k0 = k1; k1 = k2; k2 = ~0ull; }
+        hi0 = (uint32_t)(k0 >> 32); mh = row_min_u(hi0);
+        ml = row_min_u(hi0 == mh ? (uint32_t)k0 : 0xffffffffu);
+        top1 = (u64)mh << 32 | ml;
+        if (k0 == top1 && top1 != ~0ull) { k0 = k1; k1 = k2; k2 = ~0ull; }
+        hi0 = (uint32_t)(k0 >> 32); mh = row_min_u(hi0);
+        ml = row_min_u(hi0 == mh ? (uint32_t)k0 : 0xffffffffu);
+        top2 = (u64)mh << 32 | ml;
+    }
+    // ... filtered as :207-221 (radius, still unused by this board, same orientation): lanes 0 .. 2 of the group take one each
     u64 list = 0;
     int cnt = 0;
-    const float at = c.st[anchor];
-#pragma unroll
-    for (int rk = 0; rk < 3; ++rk) {
-        const uint32_t hi0 = (uint32_t)(k0 >> 32), mh = row_min_u(hi0);  // (distance, index): the distance first ...
-        const uint32_t ml = row_min_u(hi0 == mh ? (uint32_t)k0 : 0xffffffffu);  // ... then the index among the nearest
-        const u64 m = (u64)mh << 32 | ml;
-        if (k0 == m && m != ~0ull) {
-            k0 = k1;
-            k1 = k2;
-            k2 = ~0ull;
-        }
-        const bool have = m != ~0ull;
-        const int idx = have ? (int)(uint32_t)m : 0;
-        if (have && __uint_as_float((uint32_t)(m >> 32)) <= radius_sq && slot_active(slot, idx) && theta_dist(at, c.st[idx]) < 5.0f) {
-            list |= (u64)idx << (16 * cnt);
-            ++cnt;
+    {
+        const u64 mine = l == 0 ? top0 : (l == 1 ? top1 : top2);
+        const bool have = l < 3 && mine != ~0ull;
+        const int idx = have ? (int)(uint32_t)mine : 0;
+        const bool ok = have && __uint_as_float((uint32_t)(mine >> 32)) <= radius_sq && slot_active(slot, idx) &&
+                        theta_dist(c.st[anchor], c.st[idx]) < 5.0f;
+        const uint32_t m3 = (uint32_t)(__ballot(ok) >> (16 * g)) & 7u;  // this group's three
+        const int i0 = (int)(uint32_t)top0, i1 = (int)(uint32_t)top1, i2 = (int)(uint32_t)top2;
+        if (m3 & 1u) { list |= (u64)i0 << (16 * cnt); ++cnt; }
+        if (m3 & 2u) { list |= (u64)(i1 & 0xffff) << (16 * cnt); ++cnt; }
+        if (m3 & 4u) { list |= (u64)(i2 & 0xffff) << (16 * cnt); ++cnt; }
+        if (__ballot(cnt == 0)) {  // an empty list
+            EK(1);
+            ek[5] += 1;
+            return false;
         }
     }
     list |= (u64)cnt << 48;
@@ -464,16 +489,8 @@ __device__ int build_board_w(const Ctx &c, uint8_t *slot, u64 seed, int lane, in
 
 // ---- decode (detector.rs:42-169, 448-476; image_util.rs:39-70) -----------------------------------------------------
 
-__device__ u64 rotate_bits(u64 bits, int edge_bits)
-{
-    u64 out = 0;
-    int count = 0;
-    for (int r = edge_bits - 1; r >= 0; --r)
-        for (int cc = 0; cc < edge_bits; ++cc, ++count) out |= ((bits >> (r + cc * edge_bits)) & 1ull) << count;
-    return out;
-}
-
-__device__ bool decode_quad(const TailArgs &a, const uint8_t *luma, const float q[8], int &tag_id, int &rot_out)
+// decode_positions + bit_code (detector.rs:42-122) of one quad: false = None
+__device__ bool quad_bits(const TailArgs &a, const uint8_t *luma, const float q[8], u64 &bits_out)
 {
     const uint32_t w = (uint32_t)a.W, h = (uint32_t)a.H;
     for (int i = 0; i < 4; ++i) {
@@ -537,27 +554,37 @@ __device__ bool decode_quad(const TailArgs &a, const uint8_t *luma, const float 
             }
     }
     if (invalid > 3) return false;
-    for (int rotated = 0; rotated < 4; ++rotated) {  // best_tag :142-169
-        int best = 0;
-        unsigned best_score = (unsigned)__popcll(a.codes[0] ^ bits);
-        for (int i = 1; i < a.n_codes; ++i) {
-            const unsigned s = (unsigned)__popcll(a.codes[i] ^ bits);
-            if (s < best_score) {
-                best_score = s;
-                best = i;
-            }
+    bits_out = bits;
+    return true;
+}
+
+// best_tag (detector.rs:142-169) by the wave: every lane takes every 64th code; the first code with the smallest distance is
+// the smallest (distance, index) pair
+__device__ bool best_tag_w(const TailArgs &a, u64 bits, int lane, int &idx, int &rot)
+{
+    const int nb = a.edge * a.edge;
+    for (int rotated = 0; rotated < 4; ++rotated) {
+        uint32_t best = 0xffffffffu;
+        for (int i = lane; i < a.n_codes; i += 64) {
+            const uint32_t key = (uint32_t)__popcll(a.codes[i] ^ bits) << 16 | (uint32_t)i;
+            best = key < best ? key : best;
         }
-        if (best_score < (unsigned)a.hamming) {
-            tag_id = best;
-            rot_out = rotated;
+        for (int o = 32; o; o >>= 1) {
+            const uint32_t v = (uint32_t)__shfl_xor((int)best, o);
+            best = v < best ? v : best;
+        }
+        if ((best >> 16) < (uint32_t)a.hamming) {
+            idx = (int)(best & 0xffffu);
+            rot = rotated;
             return true;
         }
         if (rotated == 3) break;
-        bits = rotate_bits(bits, a.edge);
+        // rotate_bits (:124-140): output bit `count` is input bit r + c * edge with count = (edge - 1 - r) * edge + c -- a bit per lane
+        const int r = a.edge - 1 - lane / a.edge, cc = lane % a.edge;
+        bits = __ballot(lane < nb && ((bits >> (r + cc * a.edge)) & 1ull));
     }
     return false;
 }
-
 
 // ---- init_quads (detector.rs:543-586) for the seed s0, by one wave: the candidate quads into the wave's list, in the
 // reference's order; returns how many
@@ -569,6 +596,7 @@ __device__ int init_quads_w(const Ctx &c, uint8_t *wv, int s0, int lane, uint32_
     u64 *cand = reinterpret_cast<u64 *>(wv + WV_CAND);
     uint16_t *pairs = reinterpret_cast<uint16_t *>(wv + WV_PAIRS);
     uint16_t *same = reinterpret_cast<uint16_t *>(wv + WV_SMALL), *diff = same + 64, *s1ok = same + 128;
+    float *a0s = reinterpret_cast<float *>(wv + WV_SMALL + 384), *a2s = a0s + 64, *a3tab = reinterpret_cast<float *>(wv + WV_A3);
     const int n = c.n;
     const float *sx = c.sx, *sy = c.sy, *st = c.st;
     const float s0x = sx[s0], s0y = sy[s0], s0t = st[s0];
@@ -620,6 +648,12 @@ __device__ int init_quads_w(const Ctx &c, uint8_t *wv, int s0, int lane, uint32_
         }
         // the white-block test depends on (s0, s1) only: once per s1 (0 fails, 1 passes, 2 undecided here)
         if (lane < ns) s1ok[lane] = (uint16_t)white_block(s0t, sx[same[lane]] - s0x, sy[same[lane]] - s0y);
+        wsync();
+        // a3 = angle(v30, v01) (saddle.rs:59) depends on (d0, d1) only: once per pair
+        for (int p = lane; p < n_pairs && p < TA3; p += 64) {
+            const int d0 = diff[pairs[p] & 0xff], d1 = diff[pairs[p] >> 8];
+            a3tab[p] = angle_degree(s0x - sx[d1], s0y - sy[d1], sx[d0] - s0x, sy[d0] - s0y);
+        }
     }
     wsync();
     TKS(3);
@@ -628,7 +662,16 @@ __device__ int init_quads_w(const Ctx &c, uint8_t *wv, int s0, int lane, uint32_
             const int wb = s1ok[si];
             if (wb == 0) continue;
             const int s1 = same[si];
-            const float v02x = sx[s1] - s0x, v02y = sy[s1] - s0y;
+            const float s1x = sx[s1], s1y = sy[s1];
+            const float v02x = s1x - s0x, v02y = s1y - s0y;
+            // a0 = angle(v01, v12) depends on (s1, d0), a2 = angle(v23, v30) on (s1, d1) (saddle.rs:56-58): once per d
+            wsync();
+            if (lane < nd) {
+                const float dx = sx[diff[lane]], dy = sy[diff[lane]];
+                a0s[lane] = angle_degree(dx - s0x, dy - s0y, s1x - dx, s1y - dy);
+                a2s[lane] = angle_degree(dx - s1x, dy - s1y, s0x - dx, s0y - dy);
+            }
+            wsync();
             for (int base = 0; base < n_pairs; base += 64) {
                 const int p = base + lane;
                 bool ok = false;
@@ -636,7 +679,21 @@ __device__ int init_quads_w(const Ctx &c, uint8_t *wv, int s0, int lane, uint32_
                 if (p < n_pairs) {
                     const int pa = pairs[p] & 0xff, pb = pairs[p] >> 8;
                     const int d0 = diff[pa], d1 = diff[pb];
-                    ok = quad_rest(c, s0, d0, s1, d1);
+                    // is_valid_quad(s0, d0, s1, d1) without the white-block test and :18-21 (the pair list), from the tables
+                    {
+                        const float d0x = sx[d0], d0y = sy[d0], d1x = sx[d1], d1y = sy[d1];
+                        const float v01x = d0x - s0x, v01y = d0y - s0y, v03x = d1x - s0x, v03y = d1y - s0y;
+                        const float v12x = s1x - d0x, v12y = s1y - d0y, v23x = d1x - s1x, v23y = d1y - s1y;
+                        ok = !(cross2(v01x, v01y, v02x, v02y) * cross2(v02x, v02y, v03x, v03y) < 0.0f) &&
+                             !(cross2(v01x, v01y, v12x, v12y) * cross2(v12x, v12y, v23x, v23y) < 0.0f) &&
+                             !(dot2(v01x, v01y, v02x, v02y) < 0.0f || dot2(v03x, v03y, v02x, v02y) < 0.0f) &&
+                             !(fabsf(a0s[pa] - a2s[pb]) > 10.0f);
+                        if (ok) {
+                            const float a1 = angle_degree(v12x, v12y, v23x, v23y);
+                            const float a3 = p < TA3 ? a3tab[p] : angle_degree(s0x - d1x, s0y - d1y, v01x, v01y);
+                            ok = !(fabsf(a1 - a3) > 10.0f);
+                        }
+                    }
                     if (ok && wb == 2) {  // a quad hangs on the undecided test
                         status |= TAIL_UNCERTAIN;
                         ok = false;
@@ -680,16 +737,20 @@ __global__ void __launch_bounds__(64 * TW) k_board_tail(TailArgs a)
     uint32_t status = 0;  // per lane; merged through sh[0]
     int n_tags = 0;       // (wave 0)
     unsigned long long tk[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = wall_clock64();
+    const unsigned long long t_start = t_last;
     int n_cands_total = 0, n_seeds_done = 0, n_boards = 0;
     unsigned long long ek[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define TK(i) do { const unsigned long long t_now = wall_clock64(); tk[i] += t_now - t_last; t_last = t_now; } while (0)
     const FrameCounters &fc = a.ctr[f];
     int n = (int)fc.n_out;
+    const int n_first = n;
     const uint32_t cflags = fc.flags;
     if ((cflags & (FLAG_CAND_OVERFLOW | FLAG_ROOT_OVERFLOW | FLAG_OUT_OVERFLOW)) || n > TN) {  // (the whole workgroup alike)
         if (tid == 0) {
-            a.table[2 * f] = 0;
-            a.table[2 * f + 1] = n > TN ? TAIL_CAPACITY : TAIL_CHAIN;
+            a.table[4 * f] = 0;
+            a.table[4 * f + 1] = n > TN ? TAIL_CAPACITY : TAIL_CHAIN;
+            a.table[4 * f + 2] = 0;
+            a.table[4 * f + 3] = 0;
         }
         return;
     }
@@ -921,7 +982,8 @@ __global__ void __launch_bounds__(64 * TW) k_board_tail(TailArgs a)
             // ---- decode the board's quads (detector.rs:514-527); results in the candidates' space ---------------------
             float *dec_xy = reinterpret_cast<float *>(wv + WV_CAND);           // [BCELLS][8]
             int *dec_id = reinterpret_cast<int *>(wv + WV_CAND + BCELLS * 32);  // [BCELLS]: tag id or -1
-            for (int base = 0; base < n_quads; base += 64) {
+            u64 *dec_bits = reinterpret_cast<u64 *>(wv + WV_PAIRS);  // [BCELLS] (the pair list is dead)
+            for (int base = 0; base < n_quads; base += 64) {  // the sample bits: a quad per lane
                 const int qi = base + lane;
                 if (qi < n_quads) {
                     const u64 q = quads[qi];
@@ -931,19 +993,25 @@ __global__ void __launch_bounds__(64 * TW) k_board_tail(TailArgs a)
                         qxy[2 * i] = sx[q_at(q, i)];
                         qxy[2 * i + 1] = sy[q_at(q, i)];
                     }
-                    int id = -1, rot = 0;
-                    if (!decode_quad(a, luma, qxy, id, rot)) id = -1;
-                    dec_id[qi] = id;
-                    if (id >= 0) {
-#pragma unroll
+                    u64 bits = 0;
+                    dec_id[qi] = quad_bits(a, luma, qxy, bits) ? -2 : -1;
+                    dec_bits[qi] = bits;
+                }
+            }
+            wsync();
+            for (int qi = 0; qi < n_quads; ++qi) {  // the family's codes: the wave per quad
+                if (dec_id[qi] != -2) continue;
+                int id = -1, rot = 0;
+                const bool hit = best_tag_w(a, dec_bits[qi], lane, id, rot);
+                wsync();
+                if (lane == 0) {
+                    dec_id[qi] = hit ? id : -1;
+                    if (hit) {
+                        const u64 q = quads[qi];
                         for (int i = 0; i < 4; ++i) {  // rotate_left(rot) then reverse, :468-469
-                            const int src = ((3 - i) + rot) & 3;
-                            float vx = qxy[0], vy = qxy[1];
-                            if (src == 1) { vx = qxy[2]; vy = qxy[3]; }
-                            if (src == 2) { vx = qxy[4]; vy = qxy[5]; }
-                            if (src == 3) { vx = qxy[6]; vy = qxy[7]; }
-                            dec_xy[8 * qi + 2 * i] = vx;
-                            dec_xy[8 * qi + 2 * i + 1] = vy;
+                            const int src = q_at(q, ((3 - i) + rot) & 3);
+                            dec_xy[8 * qi + 2 * i] = sx[src];
+                            dec_xy[8 * qi + 2 * i + 1] = sy[src];
                         }
                     }
                 }
@@ -1019,8 +1087,10 @@ __global__ void __launch_bounds__(64 * TW) k_board_tail(TailArgs a)
     if (a.debug >= 2 && f == 0 && tid == 0)
         printf("  expand_one: scan %llu reduce+filter %llu broadcast %llu combos %llu; calls %llu, with all four lists %llu\n", ek[0], ek[1], ek[2], ek[3], ek[5], ek[6]);
     if (tid == 0) {
-        a.table[2 * f] = st_all ? 0u : (uint32_t)n_tags;
-        a.table[2 * f + 1] = st_all;
+        a.table[4 * f] = st_all ? 0u : (uint32_t)n_tags;
+        a.table[4 * f + 1] = st_all;
+        a.table[4 * f + 2] = (uint32_t)(wall_clock64() - t_start);  // 100 MHz ticks this frame took
+        a.table[4 * f + 3] = (uint32_t)n_first | (uint32_t)n_seeds_done << 16;  // saddles; seeds wave 0 listed quads for
     }
 }
 
