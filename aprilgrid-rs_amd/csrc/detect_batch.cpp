@@ -272,9 +272,11 @@ static int detect_batch_device_tail(agx_detector *det, const void *frames, const
     const int max_boards = agx_internal_max_boards(det);
     const int device = agx_internal_device(det);
     constexpr int S = AGX_UPLOAD_STREAMS;
-    // a frame's search is one wave for a millisecond or two, whatever the number of frames beside it: chunks as large
-    // as the staging allows, several per call only so that the next one's upload runs under this one's kernels
-    const int chunk = std::max(1, std::min(n_frames, 256));
+    // A frame's search occupies a workgroup of eight waves for two to five milliseconds (frames whose first seed does not
+    // find the whole board cost twice the others), one workgroup per CU: a launch takes what its slowest frame takes, and
+    // only launches of several times the CU count average that out.  So: chunks of up to 1024 frames; several per call only
+    // so that the next one's upload runs under this one's kernels.
+    const int chunk = std::max(1, std::min(n_frames, 1024));
     const int n_chunks = (n_frames + chunk - 1) / chunk;
     const size_t chunk_bytes = (size_t)chunk * frame_stride_bytes;
     uint8_t *d_stage = nullptr;
@@ -292,8 +294,11 @@ static int detect_batch_device_tail(agx_detector *det, const void *frames, const
     std::deque<std::vector<agx_saddle>> handed_back;  // saddle lists of frames for the host tail (alive until the pool is drained)
     int rc = AGX_OK, n_fallback = 0, n_uncertain = 0;
     bool pending_batch = false;
+    std::mutex one_upload;  // the chunks go up one after the other: three large copies side by side share the link, and the first
+                            // chunk -- the one the device waits for -- would arrive with the third
     auto upload_task = [&, device](int ci) {
         const int c0 = ci * chunk, nf = std::min(chunk, n_frames - c0), slot = ci % S;
+        std::lock_guard<std::mutex> one(one_upload);
         const bool ok = hipSetDevice(device) == hipSuccess &&
                         hipMemcpyAsync(d_stage + (size_t)slot * chunk_bytes, (const uint8_t *)frames + (size_t)c0 * frame_stride_bytes,
                                        (size_t)nf * frame_stride_bytes, hipMemcpyHostToDevice, up[slot]) == hipSuccess &&

@@ -116,7 +116,7 @@ struct agx_detector {
 
     // option "device_tail": agx_detect_batch's board search + decode on the device (tail_kernels.hip); frames the kernel
     // hands back (TAIL_UNCERTAIN / TAIL_CAPACITY) take the host tail
-    int device_tail = 0;
+    int device_tail = -1;  // -1: where this process's atan2f is the routine the kernel restates (decided at the first batch), 0 off, 1 on
     uint64_t *d_codes = nullptr;                                     // the family's code list
     agx_tag *h_tags = nullptr, *h_tags_dev = nullptr;                // mapped pinned [tail_frames][tail_tag_cap]
     uint32_t *h_tail_table = nullptr, *h_tail_table_dev = nullptr;   // mapped pinned [tail_frames][4]: count, status, ticks, saddles | seeds << 16
@@ -613,7 +613,18 @@ __attribute__((visibility("hidden"))) int agx_internal_fetch_compact(agx_detecto
 // agx_detect_batch with option "device_tail": the board search + decode of the batch that was just enqueued, behind it on
 // the detector's stream.  d_luma = the frames' u8 luma in device memory (L8 frames: the frames themselves).  Results go to
 // mapped pinned host memory; agx_internal_fetch_tail waits for them.
-__attribute__((visibility("hidden"))) int agx_internal_device_tail(const agx_detector *det) { return det->device_tail; }
+// the device evaluates angle_degree's atan2f by glibc's routine (libm_f32.h): offered only where this process's atan2f IS that
+// routine -- checked once per process on 2^20 operand pairs (more in tests/test_abi_cpu.py)
+static uint64_t libm_check_once()
+{
+    static const uint64_t mismatches = libm_atan2f_mismatches(1u << 20, 1);
+    return mismatches;
+}
+__attribute__((visibility("hidden"))) int agx_internal_device_tail(agx_detector *det)
+{
+    if (det->device_tail < 0) det->device_tail = libm_check_once() == 0 ? 1 : 0;
+    return det->device_tail;
+}
 __attribute__((visibility("hidden"))) void agx_internal_tail_stats(agx_detector *det, int frames, int fallbacks, int uncertain)
 {
     det->last_tail_frames = frames;
@@ -887,18 +898,16 @@ int agx_detector_set_option(agx_detector *det, const char *name, int value)
     else if (!std::strcmp(name, "store_response")) det->store_resp = value != 0;
     else if (!std::strcmp(name, "profile_stride")) det->prof_stride = value > 1 ? value : 1;
     else if (!std::strcmp(name, "profile_kernel")) det->prof_kernel = value >= 0 && value < K_COUNT ? value : K_BLUR_HESSIAN;
-    else if (!std::strcmp(name, "device_tail")) {
-        // the device evaluates angle_degree's atan2f by glibc's routine (libm_f32.h): offered only where this process's atan2f IS
-        // that routine -- checked once per process on 2^20 operand pairs (10^8 in tests/test_abi_cpu.py's long form)
-        if (value != 0) {
-            static const uint64_t mismatches = libm_atan2f_mismatches(1u << 20, 1);
+    else if (!std::strcmp(name, "device_tail")) {  // 1 on (refused where libm differs), 0 off, -1 back to the default (on where possible)
+        if (value > 0) {
+            const uint64_t mismatches = libm_check_once();
             if (mismatches) {
                 det->device_tail = 0;
                 return fail(det, AGX_ERR_STATE, "device_tail: this C library's atan2f is not the routine the device tail restates (" +
                                                     std::to_string(mismatches) + " of 2^20 inputs differ); the host tail stays in use");
             }
         }
-        det->device_tail = value != 0;
+        det->device_tail = value > 0 ? 1 : (value < 0 ? -1 : 0);
     }
     else if (!std::strcmp(name, "reload_tuning_env")) tuning_env_reload();  // (process-wide: the AGX_* overrides are read again)
     else if (!std::strcmp(name, "tail_threads")) {
@@ -924,7 +933,7 @@ int agx_detector_get_option(const agx_detector *det, const char *name, int *valu
     else if (!std::strcmp(name, "store_response")) *value = det->store_resp;
     else if (!std::strcmp(name, "debug_ablation")) *value = det->dbg;
     else if (!std::strcmp(name, "tail_threads")) *value = det->tail_threads;
-    else if (!std::strcmp(name, "device_tail")) *value = det->device_tail;
+    else if (!std::strcmp(name, "device_tail")) *value = det->device_tail;  // (-1: not decided yet)
     else if (!std::strcmp(name, "last_device_tail_frames")) *value = det->last_tail_frames;
     else if (!std::strcmp(name, "last_device_tail_fallbacks")) *value = det->last_tail_fallbacks;
     else if (!std::strcmp(name, "last_device_tail_uncertain")) *value = det->last_tail_uncertain;  // (of them: an angle inside its guard band)

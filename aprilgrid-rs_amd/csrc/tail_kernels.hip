@@ -42,8 +42,9 @@ namespace {
 
 constexpr int TN = TAIL_MAX_SADDLES;
 constexpr int TGC = 1024;    // cells of the k-NN grid
-constexpr int TCAND = 512;   // candidate quads of one seed
-constexpr int TA3 = 1024;    // (d0, d1) pairs of a seed whose angle a3 is kept in a table
+constexpr int TCAND = 256;   // candidate quads of one seed
+constexpr int TA3 = 512;     // (d0, d1) pairs of a seed whose angle a3 is kept in a table
+constexpr int TMEMO = 2048;  // entries of each of the two memo tables (direct mapped)
 constexpr int TW = 8;        // waves per frame
 constexpr int BCELLS = 128;  // cells (found or not) of one board
 constexpr int BGR = 12, BGN = 2 * BGR + 1;  // board cells live within +-BGR of the seed's cell
@@ -61,14 +62,13 @@ static_assert(BGN * BGN <= SL_ACTIVE - SL_GRID, "board grid");
 static_assert(TN / 8 <= SL_STACK - SL_ACTIVE, "active mask");
 
 // a wave's own LDS (bytes)
-constexpr int WV_CAND = 0;                      // u64[TCAND]; also u64[TN] distance keys; wave 0: u32[2 * TGC] while the grid is built (with
-                                                // the table behind it), decode results
+constexpr int WV_CAND = 0;                      // u64[TCAND]; with the table behind it also u64[TN] distance keys and, on wave 0, the decode's corners
 constexpr int WV_A3 = WV_CAND + TCAND * 8;      // f32[TA3]: angle(v30, v01) of the seed's (d0, d1) pairs
-constexpr int WV_PAIRS = WV_A3 + TA3 * 4;       // u16[1176 + pad]
+constexpr int WV_PAIRS = WV_A3 + TA3 * 4;       // u16[1176 + pad]; wave 0: the decode's bits and ids
 constexpr int WV_SMALL = WV_PAIRS + 1184 * 2;   // u16[3][64]: same, diff, the white-block test per s1; f32[2][64]: a0, a2 of the current s1
 constexpr int WV_SLOT = WV_SMALL + 1024;        // the board under construction
 constexpr int WV_BYTES = WV_SLOT + SL_BYTES;
-static_assert(WV_BYTES % 8 == 0, "alignment");
+static_assert(WV_BYTES % 8 == 0 && WV_A3 - WV_CAND + TA3 * 4 >= TN * 8, "alignment / the keys' space");
 // the frame's LDS (bytes)
 constexpr int OFF_SX = 0, OFF_SY = OFF_SX + TN * 4, OFF_ST = OFF_SY + TN * 4;
 constexpr int OFF_GX = OFF_ST + TN * 4, OFF_GY = OFF_GX + TN * 4, OFF_GI = OFF_GY + TN * 4;
@@ -79,9 +79,17 @@ constexpr int OFF_TAGIDS = OFF_QUADS + BCELLS * 8;         // u32[TTAGS]
 constexpr int OFF_USED = OFF_TAGIDS + TTAGS * 4;           // u32[TN / 32]
 constexpr int OFF_HIST = OFF_USED + TN / 8;                // u32[364]
 constexpr int OFF_SHARED = OFF_HIST + 364 * 4;             // u32[8 + 2 * TW]: what the waves tell each other
-constexpr int OFF_WAVES = OFF_SHARED + (8 + 2 * TW) * 4;
+// Boards grown from different seed quads ask the same questions again: what find_closest_potential_saddle_idxs finds for an
+// ordered pair of saddles before the board's own "still unused" test (a function of the pair), and is_valid_quad of four
+// saddles (a function of the four).  Both are kept per round in direct-mapped tables shared by the frame's waves -- an
+// entry is one aligned 64-bit word carrying its whole key, read and written atomically; a collision just overwrites.
+constexpr int OFF_MEMO_P = OFF_SHARED + (8 + 2 * TW) * 4;  // u64[TMEMO]: key (i0, i1, side) -> up to three candidates
+constexpr int OFF_MEMO_Q = OFF_MEMO_P + TMEMO * 8;         // u64[TMEMO]: key (four indices) -> is_valid_quad's 0 / 1 / 2
+constexpr int OFF_WAVES = OFF_MEMO_Q + TMEMO * 8;
 constexpr int LDS_BYTES = OFF_WAVES + TW * WV_BYTES;
-static_assert(OFF_QUADS % 8 == 0 && OFF_SHARED % 8 == 0 && OFF_WAVES % 8 == 0, "alignment");
+static_assert(LDS_BYTES <= 160 * 1024, "LDS of a CU");
+static_assert(2 * TGC * 4 <= TMEMO * 8, "the grid is built in the first memo table's space");
+static_assert(OFF_QUADS % 8 == 0 && OFF_SHARED % 8 == 0 && OFF_MEMO_P % 8 == 0 && OFF_WAVES % 8 == 0, "alignment");
 
 constexpr float kPiF = 3.14159274101257324219f;
 // The white-block angle: cosf / sinf within 1 ulp move the direction by < 1.2e-7 rad (7e-6 degrees), the reference's six
@@ -98,6 +106,7 @@ struct Ctx {
     const uint16_t *gi, *gstart;
     float ox, oy, inv_cell;
     int nx, ny, n;
+    u64 *memo_p, *memo_q;
 };
 
 __device__ __forceinline__ float theta_dist(float t0, float t1)  // math_util.rs:15-23
@@ -314,38 +323,35 @@ __device__ bool expand_one_w(const Ctx &c, const uint8_t *slot, u64 qs, u64 &out
     const float radius_sq = 0.5f * (ex * ex + ey * ey);
     const float v10x = bx - ax, v10y = by - ay;
     const float qx = c.sx[anchor] + v10x * ratio0, qy = c.sy[anchor] + v10y * ratio0;
-    u64 k0 = ~0ull, k1 = ~0ull, k2 = ~0ull;
-    const float r = sqrtf(radius_sq) * 1.0001f + 1e-3f;
-    if (!(r < 3e38f)) {  // (not on image coordinates) everything
-        for (int t = l; t < c.n; t += 16) top3_insert(dist_key(qx, qy, c.gx[t], c.gy[t], c.gi[t]), k0, k1, k2);
-    } else {
-        // the cell rows the radius reaches, four at a time: four lanes per row, each takes every fourth saddle of the row's
-        // run (a run holds a handful) -- the rows' bounds in one LDS round trip, their saddles in one or two more
-        const int xa = cell_x(c, qx - r), xb = cell_x(c, qx + r), ya = cell_y(c, qy - r), yb = cell_y(c, qy + r);
-        for (int y0 = ya; y0 <= yb; y0 += 4) {
-            const int y = y0 + (l >> 2);
-            if (y <= yb) {
-                const int t0 = c.gstart[y * c.nx + xa], t1 = c.gstart[y * c.nx + xb + 1];
-                for (int t = t0 + (l & 3); t < t1; t += 4) top3_insert(dist_key(qx, qy, c.gx[t], c.gy[t], c.gi[t]), k0, k1, k2);
+    // what the query finds before the board's own test (radius and orientation, :207-216), from the memo or by the search:
+    // raw = idx0 | idx1 << 9 | idx2 << 18 | count << 27
+    const uint32_t pkey = 0x80000000u | (uint32_t)ia << 10 | (uint32_t)ib << 1 | (uint32_t)(g & 1);
+    u64 *pslot = c.memo_p + ((pkey * 2654435761u) >> 21);
+    const u64 pe = __hip_atomic_load(pslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    uint32_t raw = (uint32_t)pe;
+    if ((uint32_t)(pe >> 32) != pkey) {  // (the 16 lanes of a query alike)
+        u64 k0 = ~0ull, k1 = ~0ull, k2 = ~0ull;
+        const float r = sqrtf(radius_sq) * 1.0001f + 1e-3f;
+        if (!(r < 3e38f)) {  // (not on image coordinates) everything
+            for (int t = l; t < c.n; t += 16) top3_insert(dist_key(qx, qy, c.gx[t], c.gy[t], c.gi[t]), k0, k1, k2);
+        } else {
+            // the cell rows the radius reaches, four at a time: four lanes per row, each takes every fourth saddle of the row's
+            // run (a run holds a handful) -- the rows' bounds in one LDS round trip, their saddles in one or two more
+            const int xa = cell_x(c, qx - r), xb = cell_x(c, qx + r), ya = cell_y(c, qy - r), yb = cell_y(c, qy + r);
+            for (int y0 = ya; y0 <= yb; y0 += 4) {
+                const int y = y0 + (l >> 2);
+                if (y <= yb) {
+                    const int t0 = c.gstart[y * c.nx + xa], t1 = c.gstart[y * c.nx + xb + 1];
+                    for (int t = t0 + (l & 3); t < t1; t += 4) top3_insert(dist_key(qx, qy, c.gx[t], c.gy[t], c.gi[t]), k0, k1, k2);
+                }
             }
         }
-    }
-    EK(0);
-    // the three smallest keys of the 16 lanes ...
-    u64 top0, top1, top2;
-    {
-        uint32_t hi0 = (uint32_t)(k0 >> 32), mh = row_min_u(hi0);             // (distance, index): the distance first ...
-        uint32_t ml = row_min_u(hi0 == mh ? (uint32_t)k0 : 0xffffffffu);      // ... then the index among the nearest
+        // the three smallest keys of the 16 lanes ((distance, index): the distance first, then the index among the nearest) ...
+        u64 top0, top1, top2;
+        uint32_t hi0 = (uint32_t)(k0 >> 32), mh = row_min_u(hi0);
+        uint32_t ml = row_min_u(hi0 == mh ? (uint32_t)k0 : 0xffffffffu);
         top0 = (u64)mh << 32 | ml;
-        // a query with nothing within its radius leaves an empty list, and try_expand_one's loops are empty with it (keys
-        // ascend by distance: the nearest decides)
-        const bool none = top0 == ~0ull || !(__uint_as_float(mh) <= radius_sq);
-        if (__ballot(none)) {
-            EK(1);
-            ek[5] += 1;
-            return false;
-        }
-        if (k0 == top0) { k0 = k1; k1 = k2; k2 = ~0ull; }
+        if (k0 == top0 && top0 != ~0ull) { k0 = k1; k1 = k2; k2 = ~0ull; }
         hi0 = (uint32_t)(k0 >> 32); mh = row_min_u(hi0);
         ml = row_min_u(hi0 == mh ? (uint32_t)k0 : 0xffffffffu);
         top1 = (u64)mh << 32 | ml;
@@ -353,22 +359,39 @@ __device__ bool expand_one_w(const Ctx &c, const uint8_t *slot, u64 qs, u64 &out
         hi0 = (uint32_t)(k0 >> 32); mh = row_min_u(hi0);
         ml = row_min_u(hi0 == mh ? (uint32_t)k0 : 0xffffffffu);
         top2 = (u64)mh << 32 | ml;
-    }
-    // ... filtered as :207-221 (radius, still unused by this board, same orientation): lanes 0 .. 2 of the group take one each
-    u64 list = 0;
-    int cnt = 0;
-    {
+        // ... within the radius and of the anchor's orientation: lanes 0 .. 2 of the query take one each
         const u64 mine = l == 0 ? top0 : (l == 1 ? top1 : top2);
         const bool have = l < 3 && mine != ~0ull;
         const int idx = have ? (int)(uint32_t)mine : 0;
-        const bool ok = have && __uint_as_float((uint32_t)(mine >> 32)) <= radius_sq && slot_active(slot, idx) &&
-                        theta_dist(c.st[anchor], c.st[idx]) < 5.0f;
-        const uint32_t m3 = (uint32_t)(__ballot(ok) >> (16 * g)) & 7u;  // this group's three
-        const int i0 = (int)(uint32_t)top0, i1 = (int)(uint32_t)top1, i2 = (int)(uint32_t)top2;
-        if (m3 & 1u) { list |= (u64)i0 << (16 * cnt); ++cnt; }
-        if (m3 & 2u) { list |= (u64)(i1 & 0xffff) << (16 * cnt); ++cnt; }
-        if (m3 & 4u) { list |= (u64)(i2 & 0xffff) << (16 * cnt); ++cnt; }
-        if (__ballot(cnt == 0)) {  // an empty list
+        const bool ok = have && __uint_as_float((uint32_t)(mine >> 32)) <= radius_sq && theta_dist(c.st[anchor], c.st[idx]) < 5.0f;
+        const uint32_t m3 = (uint32_t)(__ballot(ok) >> (16 * g)) & 7u;  // this query's three
+        uint32_t rcnt = 0;
+        raw = 0;
+        if (m3 & 1u) { raw |= ((uint32_t)top0 & 0x1ffu) << (9 * rcnt); ++rcnt; }
+        if (m3 & 2u) { raw |= ((uint32_t)top1 & 0x1ffu) << (9 * rcnt); ++rcnt; }
+        if (m3 & 4u) { raw |= ((uint32_t)top2 & 0x1ffu) << (9 * rcnt); ++rcnt; }
+        raw |= rcnt << 27;
+        if (l == 0) __hip_atomic_store(pslot, (u64)pkey << 32 | raw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    EK(0);
+    if (__ballot((raw >> 27) == 0)) {  // a query that finds nothing leaves an empty list, and try_expand_one's loops are empty with it
+        ek[5] += 1;
+        return false;
+    }
+    // the board's own test (:207 active_idxs)
+    u64 list = 0;
+    int cnt = 0;
+    {
+        const int rn = (int)(raw >> 27);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int idx = (int)((raw >> (9 * i)) & 0x1ffu);
+            if (i < rn && slot_active(slot, idx)) {
+                list |= (u64)idx << (16 * cnt);
+                ++cnt;
+            }
+        }
+        if (__ballot(cnt == 0)) {
             EK(1);
             ek[5] += 1;
             return false;
@@ -387,7 +410,18 @@ __device__ bool expand_one_w(const Ctx &c, const uint8_t *slot, u64 qs, u64 &out
         const int j0 = L / 27, j1 = (L / 9) % 3, j2 = (L / 3) % 3, j3 = L % 3;
         const bool in = L < 81 && j0 < n0 && j1 < n1 && j2 < n2 && j3 < n3;
         const int a = q_at(l0, j0 < 3 ? j0 : 0), b = q_at(l1, j1), cc = q_at(l2, j2), d = q_at(l3, j3);
-        const int v = in ? valid_quad(c, a, b, cc, d) : 0;
+        int v = 0;
+        if (in) {  // is_valid_quad of these four: from the memo, or evaluated and kept
+            const u64 qkey = 1ull << 63 | (u64)a | (u64)b << 9 | (u64)cc << 18 | (u64)d << 27;
+            u64 *qslot = c.memo_q + (((uint32_t)qkey * 2654435761u ^ (uint32_t)(qkey >> 20) * 40503u) >> 21);
+            const u64 qe = __hip_atomic_load(qslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if ((qe & ~(3ull << 36)) == qkey) {
+                v = (int)((qe >> 36) & 3ull);
+            } else {
+                v = valid_quad(c, a, b, cc, d);
+                __hip_atomic_store(qslot, qkey | (u64)v << 36, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
         const u64 mv = __ballot(v == 1), mu = __ballot(v == 2);
         const int first = mv ? __ffsll((long long)mv) - 1 : 64;
         if (mu & (first == 64 ? ~0ull : ((1ull << first) - 1ull))) status |= TAIL_UNCERTAIN;  // an undecided one before it
@@ -732,7 +766,6 @@ __global__ void __launch_bounds__(64 * TW) k_board_tail(TailArgs a)
     uint32_t *hist = reinterpret_cast<uint32_t *>(lds + OFF_HIST);
     uint32_t *sh = reinterpret_cast<uint32_t *>(lds + OFF_SHARED);  // [0] status, [1] n, [2] seeds, [3] saddles removed, [4] the boards handed out, [8 .. 8 + TW) candidates per wave, [8 + TW ..) the seeds' best boards
     uint8_t *wv = lds + OFF_WAVES + wave * WV_BYTES;  // this wave's own
-    uint32_t *tmp32 = reinterpret_cast<uint32_t *>(wv + WV_CAND);
 
     uint32_t status = 0;  // per lane; merged through sh[0]
     int n_tags = 0;       // (wave 0)
@@ -777,6 +810,8 @@ __global__ void __launch_bounds__(64 * TW) k_board_tail(TailArgs a)
         // ---- the k-NN grid over this round's saddles (every wave derives the geometry, the first one fills the cells) ----
         Ctx c;
         c.sx = sx; c.sy = sy; c.st = st; c.gx = gx; c.gy = gy; c.gi = gi; c.gstart = gstart; c.n = n;
+        c.memo_p = reinterpret_cast<u64 *>(lds + OFF_MEMO_P);
+        c.memo_q = reinterpret_cast<u64 *>(lds + OFF_MEMO_Q);
         {
             float x0 = 3e38f, x1 = -3e38f, y0 = 3e38f, y1 = -3e38f;
             for (int i = lane; i < n; i += 64) {
@@ -796,7 +831,7 @@ __global__ void __launch_bounds__(64 * TW) k_board_tail(TailArgs a)
         }
         if (wave == 0) {
             const int nx = c.nx, ncell = c.nx * c.ny;
-            uint32_t *cnt = tmp32, *fill = tmp32 + TGC;
+            uint32_t *cnt = reinterpret_cast<uint32_t *>(lds + OFF_MEMO_P), *fill = cnt + TGC;  // (the memo tables are cleared below)
             for (int i = lane; i < ncell; i += 64) cnt[i] = 0;
             wsync();
             for (int i = lane; i < n; i += 64) atomicAdd(&cnt[cell_y(c, sy[i]) * nx + cell_x(c, sx[i])], 1u);
@@ -853,6 +888,8 @@ __global__ void __launch_bounds__(64 * TW) k_board_tail(TailArgs a)
             if (lane == 0) sh[2] = (uint32_t)ns_;
             TK(1);
         }
+        __syncthreads();
+        for (int i = tid; i < 2 * TMEMO; i += 64 * TW) c.memo_p[i] = 0ull;  // both memo tables: this round's saddle numbers
         __syncthreads();
         const int n_seeds = (int)sh[2];
         const int total = n_seeds < 30 ? n_seeds : 30;  // popped from the back, at most 30 (detector.rs:613)
@@ -981,7 +1018,7 @@ __global__ void __launch_bounds__(64 * TW) k_board_tail(TailArgs a)
 
             // ---- decode the board's quads (detector.rs:514-527); results in the candidates' space ---------------------
             float *dec_xy = reinterpret_cast<float *>(wv + WV_CAND);           // [BCELLS][8]
-            int *dec_id = reinterpret_cast<int *>(wv + WV_CAND + BCELLS * 32);  // [BCELLS]: tag id or -1
+            int *dec_id = reinterpret_cast<int *>(wv + WV_PAIRS + BCELLS * 8);    // [BCELLS]: tag id or -1
             u64 *dec_bits = reinterpret_cast<u64 *>(wv + WV_PAIRS);  // [BCELLS] (the pair list is dead)
             for (int base = 0; base < n_quads; base += 64) {  // the sample bits: a quad per lane
                 const int qi = base + lane;

@@ -24,6 +24,8 @@ def pair():
     import aprilgrid_rs_amd as A
     host = A.TagDetector("t36h11", None, device=0)
     dev = A.TagDetector("t36h11", None, device=0)
+    assert dev.get_option("device_tail") == -1  # the default: on where this process's atan2f is glibc's routine, decided at the first batch
+    host.set_option("device_tail", 0)
     dev.set_option("device_tail", 1)
     assert dev.get_option("device_tail") == 1 and host.get_option("device_tail") == 0
     yield host, dev
@@ -125,6 +127,7 @@ def test_max_num_of_boards(boards):
     p.max_num_of_boards = boards
     host = A.TagDetector("t36h11", p, device=0)
     dev = A.TagDetector("t36h11", p, device=0)
+    host.set_option("device_tail", 0)
     dev.set_option("device_tail", 1)
     two = load_image("two_boards.png")
     counts, _ = same_results(host, dev, two[None])

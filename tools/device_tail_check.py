@@ -25,6 +25,7 @@ elif fmt == "L16":
     frames = (frames.astype(np.uint16) * 257)
 det_h = A.TagDetector("t36h11")
 det_d = A.TagDetector("t36h11")
+det_h.set_option("device_tail", 0)
 det_d.set_option("device_tail", 1)
 cap = 64
 
