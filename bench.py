@@ -424,137 +424,149 @@ def host_boundary_leg(torch, A, dev, n_frames, width, height, steps):
 def detect_end_to_end_leg(torch, A, dev, n_frames, width, height, quick=False):
     """TagDetector::detect over the batch, end to end (SURVEY.md 8(d) "what is NOT in t_chain ... reported separately as
     end-to-end frames/s with the host-thread count stated"; reference shape benches/bench_detection.rs:24-36): configs[1]'s
-    frames in ordinary (pageable) HOST memory -> agx_detect_batch -> tag ids + corners in host arrays.  Upload, chain, fetch,
-    board search and decode are all inside; the host tail is the reference's exhaustive search (~1.5 ms per frame and
-    thread), so this rate is set by the host threads, never by the chain -- never `value`.  Timed: the C call alone
-    (caller-owned output arrays, as a C / Rust caller has them), by thread count up to what the process may keep busy
-    (agx_host_parallelism(): affinity mask or cgroup CPU quota, whichever is smaller)."""
+    frames in ordinary (pageable) HOST memory -> agx_detect_batch -> tag ids + corners in host arrays.  Upload, chain, board
+    search, decode and the tags' way back are all inside; never `value`.  Timed: the C call alone (caller-owned output arrays,
+    as a C / Rust caller has them).  Two tails, the same tags (checked here, and frame by frame in tests/test_gpu_device_tail.py):
+      device  (the default where the process's atan2f is glibc's routine) board search + decode as a HIP kernel behind the
+              chain, csrc/tail_kernels.hip: the call is then set by the upload over PCIe and the kernel's slowest frame;
+      host    the reference's exhaustive search on a pool of host threads (~0.8 ms per frame and thread): set by the CPUs the
+              box gives the process (agx_host_parallelism(): affinity mask or cgroup CPU quota, whichever is smaller) -- by
+              thread count."""
     import numpy as np
     from aprilgrid_rs_amd import _ffi
     frames, _ = make_workload(0, n_frames, width, height, "L8", 0, False, dev)
     host = frames.cpu().numpy()
     del frames
-    det = A.TagDetector(A.TagFamily.T36H11, None, device=dev.index)
     quota = int(_ffi.lib().agx_host_parallelism())
     affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cap = 64
+    out = np.zeros((n_frames, cap), A.TagDetector.TAG_DTYPE)
+    counts = np.zeros(n_frames, np.uint32)
+    status = np.zeros(n_frames, np.int32)
+
+    def run(det, frames_h, thr, n, reps):
+        det.detect_batch_raw(frames_h[: min(n, 4 * thr)], n_threads=thr, cap=cap, out=out[: min(n, 4 * thr)], counts=counts[: min(n, 4 * thr)],
+                             status=status[: min(n, 4 * thr)])  # pool start-up, staging, per-thread scratch: outside the clock
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            rc, _, _, _ = det.detect_batch_raw(frames_h[:n], n_threads=thr, cap=cap, out=out[:n], counts=counts[:n], status=status[:n])
+            ts.append(time.perf_counter() - t0)
+            assert rc == 0 and (status[:n] == 0).all(), (rc, status[:n])
+        return statistics.median(ts)
+
+    def formats_and_stream(det, res, big):
+        """What both tails are timed on beyond the 256-frame call: a long stream, pinned input, RGB8 / L16 batches."""
+        if big is not None:
+            o2 = np.zeros((len(big), cap), det.TAG_DTYPE)
+            c2 = np.zeros(len(big), np.uint32)
+            s2 = np.zeros(len(big), np.int32)
+            det.detect_batch_raw(big[:1024], n_threads=quota, cap=cap, out=o2[:1024], counts=c2[:1024], status=s2[:1024])  # (staging of the stream's chunk size)
+            t0 = time.perf_counter()
+            rc, _, _, _ = det.detect_batch_raw(big, n_threads=quota, cap=cap, out=o2, counts=c2, status=s2)
+            dt = time.perf_counter() - t0
+            assert rc == 0 and np.array_equal(c2[:n_frames], c2[-n_frames:]) and (s2 == 0).all()
+            res["frames_per_s_%d_frames" % len(big)] = round(len(big) / dt, 1)
+            del o2, c2, s2
+        # the same frames in PINNED host memory (hipHostMalloc / torch pin_memory): the runtime's pageable path already runs at
+        # the PCIe rate (profiles/r5_ubench_h2d_pageable.txt), so little changes
+        pinned_t = torch.empty((n_frames, height, width), dtype=torch.uint8, pin_memory=True)
+        pinned_t.copy_(torch.from_numpy(host))
+        res["frames_per_s_pinned_input"] = round(n_frames / run(det, pinned_t.numpy(), quota, n_frames, 3), 1)
+        del pinned_t
+        for fmt2 in ("RGB8", "L16"):  # the u8 luma the decode needs is computed on the device behind the chain
+            fr2, _ = make_workload(0, n_frames, width, height, fmt2, 64, False, dev)
+            h2 = host_view(fr2, fmt2)
+            del fr2
+            res["frames_per_s_" + fmt2] = round(n_frames / run(det, h2, quota, n_frames, 3), 1)
+            del h2
+
+    det = A.TagDetector(A.TagFamily.T36H11, None, device=dev.index)
+    det.set_option("device_tail", 0)
+    det_d = A.TagDetector(A.TagFamily.T36H11, None, device=dev.index)
     try:
         # per-frame detect of a sample: what the batch call must reproduce bit for bit
         sample = list(range(0, n_frames, max(1, n_frames // 8)))
         ref = {i: det.detect(host[i]) for i in sample}
-        counts_t = [t for t in (1, 2, 4, 8, 16, 32, 64, 128, 256) if t < quota] + [quota]
-        if quick:
-            counts_t = sorted(set([1, quota]))
-        rows = {}
-        out = np.zeros((n_frames, cap), det.TAG_DTYPE)
-        counts = np.zeros(n_frames, np.uint32)
-        status = np.zeros(n_frames, np.int32)
 
-        def run(thr, n, reps):
-            det.detect_batch_raw(host[: min(n, 4 * thr)], n_threads=thr, cap=cap, out=out[: min(n, 4 * thr)], counts=counts[: min(n, 4 * thr)],
-                                 status=status[: min(n, 4 * thr)])  # pool start-up, staging, per-thread scratch: outside the clock
-            ts = []
-            for _ in range(reps):
-                t0 = time.perf_counter()
-                rc, _, _, _ = det.detect_batch_raw(host[:n], n_threads=thr, cap=cap, out=out[:n], counts=counts[:n], status=status[:n])
-                ts.append(time.perf_counter() - t0)
-                assert rc == 0 and (status[:n] == 0).all(), (rc, status[:n])
-            return statistics.median(ts)
+        def check_sample(what):
+            for i in sample:
+                got = {int(t["id"]): t["xy"].reshape(4, 2) for t in out[i, : counts[i]]}
+                assert sorted(got) == sorted(ref[i]) and all(np.array_equal(got[k], ref[i][k]) for k in got), "%s: detect_batch differs from detect (frame %d)" % (what, i)
 
-        for thr in counts_t:
-            n = n_frames if thr >= 4 else max(16, min(n_frames, 32 * thr))
-            dt = run(thr, n, 3 if thr >= 4 else 1)
-            rows["threads_%d" % thr] = {"frames": n, "frames_per_s": round(n / dt, 1), "ms_per_frame_per_thread": round(1e3 * dt * thr / n, 3),
-                                        "tags_per_frame": round(float(counts[:n].mean()), 1)}
-            if thr == quota:  # the call just made covered every frame: compare the sample with per-frame detect
-                for i in sample:
-                    got = {int(t["id"]): t["xy"].reshape(4, 2) for t in out[i, : counts[i]]}
-                    assert sorted(got) == sorted(ref[i]) and all(np.array_equal(got[k], ref[i][k]) for k in got), "detect_batch differs from detect (frame %d)" % i
-        base = rows["threads_1"]["frames_per_s"]
-        for k, r in rows.items():
-            r["parallel_efficiency"] = round(r["frames_per_s"] / (base * int(k.split("_")[1])), 3)
-        best = rows["threads_%d" % quota]
-        res = {"workload": "configs[1]'s %d frames %dx%d L8 in pageable host memory -> tag ids + corners in host arrays (agx_detect_batch, the C call alone)" % (n_frames, width, height),
-               "frames_per_s": best["frames_per_s"], "threads": quota, "host_cores": affinity, "host_cpu_quota": quota,
-               "ms_per_frame_per_thread": best["ms_per_frame_per_thread"], "parallel_efficiency": best["parallel_efficiency"],
-               "by_threads": rows, "sample_equals_per_frame_detect": len(sample)}
+        big = None
         if not quick:
-            # a longer stream of frames (the same 256 thirty-two times over: 8 GB of host memory, ~0.5 s): start-up and drain
-            # amortised, and long enough (several 100 ms scheduler periods) that a CPU quota binds -- the sustained rate
+            # a longer stream of frames (the same 256 thirty-two times over: 8 GB of host memory): start-up and drain amortised, and
+            # long enough (several 100 ms scheduler periods) that a CPU quota binds -- the sustained rate
             try:
                 big = np.concatenate([host] * max(1, 8192 // n_frames))
             except MemoryError:  # (a host with a tight memory limit: a shorter stream)
                 big = np.concatenate([host] * max(1, 2048 // n_frames))
-            o2 = np.zeros((len(big), cap), det.TAG_DTYPE)
-            c2 = np.zeros(len(big), np.uint32)
-            s2 = np.zeros(len(big), np.int32)
-            t0 = time.perf_counter()
-            rc, _, _, _ = det.detect_batch_raw(big, n_threads=quota, cap=cap, out=o2, counts=c2, status=s2)
-            dt = time.perf_counter() - t0
-            assert rc == 0 and np.array_equal(c2[:n_frames], counts)
-            res["frames_per_s_%d_frames" % len(big)] = round(len(big) / dt, 1)
-            # the same frames in PINNED host memory (hipHostMalloc / torch pin_memory), for comparison: the runtime's pageable path
-            # already runs at the PCIe rate (profiles/r5_ubench_h2d_pageable.txt), so little changes
-            pinned_t = torch.empty((n_frames, height, width), dtype=torch.uint8, pin_memory=True)
-            pinned_t.copy_(torch.from_numpy(host))
-            pinned = pinned_t.numpy()
-            host_saved, host = host, pinned
-            try:
-                dt = run(quota, n_frames, 3)
-            finally:
-                host = host_saved
-            res["frames_per_s_pinned_input"] = round(n_frames / dt, 1)
-            del pinned, pinned_t
+        # ---- the host tail, by thread count --------------------------------------------------------------------------------
+        counts_t = [t for t in (1, 2, 4, 8, 16, 32, 64, 128, 256) if t < quota] + [quota]
+        if quick:
+            counts_t = sorted(set([1, quota]))
+        rows = {}
+        for thr in counts_t:
+            n = n_frames if thr >= 4 else max(16, min(n_frames, 32 * thr))
+            dt = run(det, host, thr, n, 3 if thr >= 4 else 1)
+            rows["threads_%d" % thr] = {"frames": n, "frames_per_s": round(n / dt, 1), "ms_per_frame_per_thread": round(1e3 * dt * thr / n, 3),
+                                        "tags_per_frame": round(float(counts[:n].mean()), 1)}
+            if thr == quota:  # the call just made covered every frame
+                check_sample("host tail")
+        base = rows["threads_1"]["frames_per_s"]
+        for k, r in rows.items():
+            r["parallel_efficiency"] = round(r["frames_per_s"] / (base * int(k.split("_")[1])), 3)
+        best = rows["threads_%d" % quota]
+        host_res = {"frames_per_s": best["frames_per_s"], "threads": quota, "ms_per_frame_per_thread": best["ms_per_frame_per_thread"],
+                    "parallel_efficiency": best["parallel_efficiency"], "by_threads": rows}
+        if not quick:
+            formats_and_stream(det, host_res, big)
             if quota < affinity:  # what threads beyond the quota cost (the reason the default stops at it)
                 thr = min(affinity, 4 * quota)
-                dt = run(thr, n_frames, 3)
-                res["beyond_quota"] = {"threads": thr, "frames_per_s": round(n_frames / dt, 1),
-                                       "note": "a %d-frame call is a burst of a few milliseconds that can fit inside one quota period; the stream below cannot" % n_frames}
-                det.detect_batch_raw(big[:256], n_threads=thr, cap=cap, out=o2[:256], counts=c2[:256], status=s2[:256])
-                t0 = time.perf_counter()
-                rc, _, _, _ = det.detect_batch_raw(big, n_threads=thr, cap=cap, out=o2, counts=c2, status=s2)
-                res["beyond_quota"]["frames_per_s_%d_frames" % len(big)] = round(len(big) / (time.perf_counter() - t0), 1)
-            del big, o2, c2, s2
-        if not quick:
-            # L16 / RGB8 batches: the u8 luma the decode needs is computed on the device behind the chain and comes back with the saddles
-            for fmt2 in ("RGB8", "L16"):
-                fr2, _ = make_workload(0, n_frames, width, height, fmt2, 64, False, dev)
-                h2 = host_view(fr2, fmt2)
-                del fr2
-                det.detect_batch_raw(h2[:64], n_threads=quota, cap=cap, out=out[:64], counts=counts[:64], status=status[:64])
-                ts = []
-                for _ in range(3):
-                    t0 = time.perf_counter()
-                    rc, _, _, _ = det.detect_batch_raw(h2, n_threads=quota, cap=cap, out=out, counts=counts, status=status)
-                    ts.append(time.perf_counter() - t0)
-                    assert rc == 0 and (status == 0).all()
-                res["frames_per_s_" + fmt2] = round(n_frames / statistics.median(ts), 1)
-                del h2
-        if not quick:
+                host_res["beyond_quota"] = {"threads": thr, "frames_per_s": round(n_frames / run(det, host, thr, n_frames, 3), 1),
+                                            "note": "a %d-frame call is a burst of a few milliseconds that can fit inside one quota period; a stream cannot" % n_frames}
             # DetectorParams::max_num_of_boards = 1 (src/detector.rs:25-41; default 2): one board search per frame instead of two -- on
-            # frames that hold one board the second search (30 seeds that find nothing) is 95 % of the host tail.  Not the reference's
-            # default, so not the headline: what the path delivers when the host tail is cheap (the upload over PCIe then binds)
+            # frames that hold one board the second search (30 seeds that find nothing) is 95 % of the host tail.  Not the
+            # reference's default, so not the headline
             p1 = A.DetectorParams.default_params()
             p1.max_num_of_boards = 1
             det1 = A.TagDetector(A.TagFamily.T36H11, p1, device=dev.index)
+            det1.set_option("device_tail", 0)
             try:
-                det1.detect_batch_raw(host[:64], n_threads=quota, cap=cap, out=out[:64], counts=counts[:64], status=status[:64])
-                ts = []
-                for _ in range(3):
-                    t0 = time.perf_counter()
-                    rc, _, _, _ = det1.detect_batch_raw(host, n_threads=quota, cap=cap, out=out, counts=counts, status=status)
-                    ts.append(time.perf_counter() - t0)
-                    assert rc == 0 and (status == 0).all()
-                res["frames_per_s_max_num_of_boards_1"] = round(n_frames / statistics.median(ts), 1)
-                res["tags_per_frame_max_num_of_boards_1"] = round(float(counts.mean()), 1)
+                host_res["frames_per_s_max_num_of_boards_1"] = round(n_frames / run(det1, host, quota, n_frames, 3), 1)
+                host_res["tags_per_frame_max_num_of_boards_1"] = round(float(counts.mean()), 1)
             finally:
                 det1.close()
-        res["note"] = ("never `value`: set by the host tail (the reference's exhaustive board search, one frame per thread) and by the CPUs the box "
-                       "gives the process (host_cpu_quota of the host_cores it shows: cgroup cpu.max); parallel_efficiency = frames/s over threads x the "
-                       "1-thread rate; the chain alone delivers config.frames_per_s")
+        host_res["note"] = ("set by the host tail (the reference's exhaustive board search, one frame per thread) and by the CPUs the box gives the process "
+                            "(host_cpu_quota of the host_cores it shows: cgroup cpu.max); parallel_efficiency = frames/s over threads x the 1-thread rate")
+        # ---- the device tail (the default) -----------------------------------------------------------------------------------
+        dev_res = None
+        dt = run(det_d, host, quota, n_frames, 5)
+        if det_d.get_option("device_tail") == 1:
+            check_sample("device tail")
+            dev_res = {"frames_per_s": round(n_frames / dt, 1), "ms_per_call": round(1e3 * dt, 2), "tags_per_frame": round(float(counts.mean()), 1),
+                       "frames_handed_back_to_the_host_tail": det_d.get_option("last_device_tail_fallbacks"),
+                       "threads": quota}
+            if not quick:
+                formats_and_stream(det_d, dev_res, big)
+            dev_res["note"] = ("board search + decode on the device behind the chain (csrc/tail_kernels.hip: a workgroup per frame, ~2.5 ms per frame, 5 ms for "
+                               "the slowest of 256); the call = upload over PCIe (4.8 ms per 256 frames) + chain + the kernel's slowest frame; a stream of "
+                               "1024-frame chunks runs at the upload's rate.  The host threads only move the frames and take the frames the kernel hands back")
+        del big
+        top = dev_res if dev_res is not None else host_res
+        res = {"workload": "configs[1]'s %d frames %dx%d L8 in pageable host memory -> tag ids + corners in host arrays (agx_detect_batch, the C call alone)" % (n_frames, width, height),
+               "frames_per_s": top["frames_per_s"], "tail": "device" if dev_res is not None else "host", "threads": quota, "host_cores": affinity,
+               "host_cpu_quota": quota, "ms_per_frame_per_thread": host_res["ms_per_frame_per_thread"],
+               "sample_equals_per_frame_detect": len(sample), "device_tail": dev_res, "host_tail": host_res,
+               "note": "never `value` (the chain alone delivers config.frames_per_s).  frames_per_s: the default path; ms_per_frame_per_thread: the host tail's"}
+        for k in top:
+            if k.startswith("frames_per_s_"):
+                res[k] = top[k]
         return res
     finally:
         det.close()
+        det_d.close()
         torch.cuda.empty_cache()
 
 
