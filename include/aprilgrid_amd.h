@@ -137,6 +137,14 @@ int agx_detector_set_limits(agx_detector *det, uint32_t max_candidates, uint32_t
  *                          detector.rs:611-625, in waves of n, merged in the reference's order: same result;
  *                          latency of a single detect, at the price of host cores).  Default 1, like the
  *                          reference; agx_detect_batch parallelises over frames instead
+ *   "device_tail"          agx_detect_batch's board search + decode (detector.rs:510-539) on the device, behind the chain
+ *                          (csrc/tail_kernels.hip), instead of on the pool of host threads.  -1 (default): on where this process's
+ *                          atan2f is glibc's own routine -- the kernel evaluates angle_degree (math_util.rs:31-33) by that routine,
+ *                          restated; decided at the first batch --, else off; 1: on, AGX_ERR_STATE where libm differs; 0: off.
+ *                          The tags are the host tail's bit for bit either way: a frame the kernel cannot decide (an angle
+ *                          within 1e-4 degrees of the white-block thresholds, saddle.rs:26-38) or hold (more than 512 saddles,
+ *                          128 board cells ...) is handed to the host tail.  Read back: "last_device_tail_frames",
+ *                          "last_device_tail_fallbacks", "last_device_tail_uncertain" of the last agx_detect_batch call
  *   "debug_ablation"       measurement switches of the kernels (tools/): bits 1 .. 1024 remove parts of the blur kernel's
  *                          work -- timing experiments, results are INVALID; bits 128 / 2048 / 8192 / 16384 collect
  *                          statistics and phase times (AGX_DBG_VERIFY_STATS), 4096 the start and end of every wave of
@@ -245,10 +253,12 @@ int agx_host_parallelism(void);
 int agx_debug_cgroup_cpu_quota(const char *cgroup_root, const char *proc_self_cgroup);
 
 /* TagDetector::detect (src/detector.rs:505-540) over a batch of equally sized frames in HOST memory
- * (frame i at frames + i*frame_stride_bytes; formats AGX_L8 / AGX_L16 / AGX_RGB8).  The saddle
- * chain of a chunk of frames (about one frame per thread, 8 .. 64) runs on the device while n_threads
- * host threads (0 = agx_host_parallelism(); the pool lives as long as the detector) upload the next
- * chunks and run the board search + decode of the previous ones; no barrier between chunks.
+ * (frame i at frames + i*frame_stride_bytes; formats AGX_L8 / AGX_L16 / AGX_RGB8).  With the device tail (option
+ * "device_tail", the default where available) the saddle chain and the board search + decode of a chunk of up to 1024
+ * frames run on the device while n_threads host threads (0 = agx_host_parallelism(); the pool lives as long as the
+ * detector) upload the next chunk and take the frames the kernel hands back.  With the host tail the saddle
+ * chain of a chunk of frames (about one frame per thread, 8 .. 64) runs on the device while the threads upload the next
+ * chunks and run the board search + decode of the previous ones; no barrier between chunks.  Same tags either way.
  * d_frames: optional device copy of the same frames (skips the upload), else
  * NULL.  out: n_frames * cap_per_frame tags, frame i at out + i*cap_per_frame; counts[i] = tags of
  * frame i; frame_status[i] (may be NULL) = AGX_OK or AGX_ERR_CAPACITY.  Returns the first non-OK

@@ -481,3 +481,18 @@ def test_host_tail_survives_non_finite_saddles():
             s["x"][bad] = -np.inf
             s["theta"][bad] = 1e30
         A.TagDetector.detect_tail("t36h11", s, g)
+
+
+def test_this_libm_atan2f_is_the_routine_the_device_tail_restates():
+    """csrc/libm_f32.h restates glibc's single-precision atan2f (the fdlibm routine, all binary32 operations) so that the device
+    tail can evaluate the reference's angle_degree (math_util.rs:31-33) with the bits the host's libm gives.  The library refuses
+    the device tail where the two differ; in this image they must not: any two floats, cross / dot products of image-sized
+    vectors, ratios at the routine's interval ends, the special cases -- 2^24 pairs per seed."""
+    import ctypes as C
+    from aprilgrid_rs_amd import _ffi
+    lib = _ffi.lib()
+    for seed in (1, 2, 3):
+        bad = C.c_uint64(12345)
+        assert lib.agx_debug_libm_atan2f_check(1 << 24, seed, C.byref(bad)) == 0
+        assert bad.value == 0, (seed, bad.value)
+    assert lib.agx_debug_libm_atan2f_check(16, 1, None) != 0  # (null output: an argument error, not a crash)
