@@ -32,8 +32,10 @@ N = 1 additionally reports, in the same line:
   host_boundary  the PCIe-inclusive rate: the same batch handed over in pinned HOST memory, saddle
                  lists back in host memory, batch after batch -- never `value`;
   detect_end_to_end  TagDetector::detect over the batch (agx_detect_batch: pageable host frames in, tag ids +
-                 corners out; upload, chain, board search and decode inside), frames/s by host-thread count up
-                 to the CPUs the process is granted (cgroup quota stated) -- set by the host tail, never `value`;
+                 corners out; upload, chain, board search and decode inside) -- never `value`.  Two tails, the same tags:
+                 `device_tail` (the default: board search + decode as a kernel behind the chain, set by PCIe and the
+                 kernel's slowest frame) and `host_tail` (a pool of host threads: frames/s by thread count up to the
+                 CPUs the process is granted, cgroup quota stated);
   extra_configs["configs[0]_single_frame"], reference_bench_detection
                  BASELINE.json configs[0] (one frame through detect: the reference's
                  data/1520525725372653511.png and one synthetic 1280x800 frame) and the reference's own
