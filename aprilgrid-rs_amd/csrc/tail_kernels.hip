@@ -85,7 +85,9 @@ constexpr int OFF_SHARED = OFF_HIST + 364 * 4;             // u32[8 + 2 * TW]: w
 // entry is one aligned 64-bit word carrying its whole key, read and written atomically; a collision just overwrites.
 constexpr int OFF_MEMO_P = OFF_SHARED + (8 + 2 * TW) * 4;  // u64[TMEMO]: key (i0, i1, side) -> up to three candidates
 constexpr int OFF_MEMO_Q = OFF_MEMO_P + TMEMO * 8;         // u64[TMEMO]: key (four indices) -> is_valid_quad's 0 / 1 / 2
-constexpr int OFF_WAVES = OFF_MEMO_Q + TMEMO * 8;
+constexpr int OFF_CODES = OFF_MEMO_Q + TMEMO * 8;          // u64[TCODES]: the family's code list (best_tag reads all of it per quad and rotation)
+constexpr int TCODES = 640;
+constexpr int OFF_WAVES = OFF_CODES + TCODES * 8;
 constexpr int LDS_BYTES = OFF_WAVES + TW * WV_BYTES;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS of a CU");
 static_assert(2 * TGC * 4 <= TMEMO * 8, "the grid is built in the first memo table's space");
@@ -98,6 +100,15 @@ constexpr float kPiF = 3.14159274101257324219f;
 constexpr double kBandAbs = 1e-4;
 constexpr double kDegD = 180.0 / (double)kPiF;
 typedef unsigned long long u64;
+
+// Phase timers of the kernel (100 MHz wall clock, frame 0's first wave prints them with AGX_TAIL_DEBUG=2): compiled in only
+// with -DAGX_TAIL_TIMERS (make EXTRA=-DAGX_TAIL_TIMERS): a clock read costs about what a dozen instructions cost, and
+// try_expand_one would read it four times
+#ifdef AGX_TAIL_TIMERS
+#define AGX_TT(...) __VA_ARGS__
+#else
+#define AGX_TT(...)
+#endif
 
 
 struct Ctx {
@@ -312,24 +323,25 @@ __device__ __forceinline__ u64 q_make(int a, int b, int c, int d) { return (u64)
 // reference's four nested loops as one combination per lane; the first valid one in loop order is the result.
 __device__ bool expand_one_w(const Ctx &c, const uint8_t *slot, u64 qs, u64 &out, int lane, uint32_t &status, unsigned long long *ek)
 {
-    unsigned long long e_last = wall_clock64();
-#define EK(i) do { const unsigned long long t_now = wall_clock64(); ek[i] += t_now - e_last; e_last = t_now; } while (0)
+    AGX_TT(unsigned long long e_last = wall_clock64();)
+#define EK(i) AGX_TT(do { const unsigned long long t_now = wall_clock64(); ek[i] += t_now - e_last; e_last = t_now; } while (0))
     const int g = lane >> 4, l = lane & 15;
     const int ia = g < 2 ? q_at(qs, 0) : q_at(qs, 3), ib = g < 2 ? q_at(qs, 1) : q_at(qs, 2);  // the pair (first, second)
     const int anchor = (g & 1) ? ib : ia;                                                      // whose neighbour is looked for
-    const float ax = c.sx[ia], ay = c.sy[ia], bx = c.sx[ib], by = c.sy[ib];
-    const float ratio0 = 1.0f + 0.3f;
-    const float ex = ax - bx, ey = ay - by;
-    const float radius_sq = 0.5f * (ex * ex + ey * ey);
-    const float v10x = bx - ax, v10y = by - ay;
-    const float qx = c.sx[anchor] + v10x * ratio0, qy = c.sy[anchor] + v10y * ratio0;
     // what the query finds before the board's own test (radius and orientation, :207-216), from the memo or by the search:
     // raw = idx0 | idx1 << 9 | idx2 << 18 | count << 27
     const uint32_t pkey = 0x80000000u | (uint32_t)ia << 10 | (uint32_t)ib << 1 | (uint32_t)(g & 1);
     u64 *pslot = c.memo_p + ((pkey * 2654435761u) >> 21);
     const u64 pe = __hip_atomic_load(pslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     uint32_t raw = (uint32_t)pe;
+    AGX_TT(ek[7] += (unsigned long long)__popcll(__ballot((uint32_t)(pe >> 32) != pkey)) / 16;)  // (queries of this call that miss the memo)
     if ((uint32_t)(pe >> 32) != pkey) {  // (the 16 lanes of a query alike)
+        const float ax = c.sx[ia], ay = c.sy[ia], bx = c.sx[ib], by = c.sy[ib];
+        const float ratio0 = 1.0f + 0.3f;
+        const float ex = ax - bx, ey = ay - by;
+        const float radius_sq = 0.5f * (ex * ex + ey * ey);
+        const float v10x = bx - ax, v10y = by - ay;
+        const float qx = c.sx[anchor] + v10x * ratio0, qy = c.sy[anchor] + v10y * ratio0;
         u64 k0 = ~0ull, k1 = ~0ull, k2 = ~0ull;
         const float r = sqrtf(radius_sq) * 1.0001f + 1e-3f;
         if (!(r < 3e38f)) {  // (not on image coordinates) everything
@@ -375,7 +387,7 @@ __device__ bool expand_one_w(const Ctx &c, const uint8_t *slot, u64 qs, u64 &out
     }
     EK(0);
     if (__ballot((raw >> 27) == 0)) {  // a query that finds nothing leaves an empty list, and try_expand_one's loops are empty with it
-        ek[5] += 1;
+        AGX_TT(ek[5] += 1;)
         return false;
     }
     // the board's own test (:207 active_idxs)
@@ -393,7 +405,7 @@ __device__ bool expand_one_w(const Ctx &c, const uint8_t *slot, u64 qs, u64 &out
         }
         if (__ballot(cnt == 0)) {
             EK(1);
-            ek[5] += 1;
+            AGX_TT(ek[5] += 1;)
             return false;
         }
     }
@@ -402,9 +414,9 @@ __device__ bool expand_one_w(const Ctx &c, const uint8_t *slot, u64 qs, u64 &out
     const u64 l0 = shfl_u64(list, 0), l1 = shfl_u64(list, 16), l3 = shfl_u64(list, 32), l2 = shfl_u64(list, 48);
     const int n0 = (int)(l0 >> 48), n1 = (int)(l1 >> 48), n2 = (int)(l2 >> 48), n3 = (int)(l3 >> 48);
     EK(2);
-    ek[5] += 1;
+    AGX_TT(ek[5] += 1;)
     if (n0 == 0 || n1 == 0 || n2 == 0 || n3 == 0) return false;  // (an empty loop)
-    ek[6] += 1;
+    AGX_TT(ek[6] += 1;)
     for (int pass = 0; pass < 2; ++pass) {
         const int L = lane + 64 * pass;  // the combination's number in loop order: ((i0 * 3 + i1) * 3 + i2) * 3 + i3
         const int j0 = L / 27, j1 = (L / 9) % 3, j2 = (L / 3) % 3, j3 = L % 3;
@@ -437,7 +449,8 @@ __device__ bool expand_one_w(const Ctx &c, const uint8_t *slot, u64 qs, u64 &out
 }
 
 // Board::new (board.rs:26-48): the board grown from a seed quad; returns its score, the cells stay in the slot.
-// try_expand's recursion (:114-152) is a stack of (cell, next direction) walked by all lanes alike; lane 0 writes.
+// try_expand's recursion (:114-152) is a stack of (cell, next direction) walked by all lanes alike: the top of the stack lives
+// in registers, lane 0 writes the slot, one wave-level ordering point per step.  A grid byte = the cell's number, bit 7 = found.
 __device__ int build_board_w(const Ctx &c, uint8_t *slot, u64 seed, int lane, int &n_cells_out, uint32_t &status, unsigned long long *ek)
 {
     {
@@ -454,66 +467,65 @@ __device__ int build_board_w(const Ctx &c, uint8_t *slot, u64 seed, int lane, in
         xy[0] = 0;
         xy[1] = 0;
         found[0] = 1;
-        grid[BGR * BGN + BGR] = 0;
-        stack[0] = 0;
-        stack[1] = 0;
+        grid[BGR * BGN + BGR] = 0x80;
     }
     wsync();
     int n_cells = 1, score = 1, sp = 1;
-    while (sp > 0) {
-        const int cell = stack[2 * (sp - 1)], i = stack[2 * (sp - 1) + 1];
-        if (i == 4) {
-            --sp;
+    int cur = 0, cur_i = 0, cur_x = 0, cur_y = 0;  // the top of the stack: cell, next direction, the cell's coordinates and quad
+    u64 cur_quad = seed;
+    for (;;) {
+        if (cur_i == 4) {  // this cell is done: back to the one it was reached from
+            if (--sp == 0) break;
+            cur = stack[2 * (sp - 1)];
+            cur_i = stack[2 * (sp - 1) + 1];
+            cur_x = xy[2 * cur];
+            cur_y = xy[2 * cur + 1];
+            cur_quad = slot_quad(slot, cur);
             continue;
         }
-        const int nx = xy[2 * cell] + (i == 0 ? 1 : (i == 2 ? -1 : 0)), ny = xy[2 * cell + 1] + (i == 1 ? -1 : (i == 3 ? 1 : 0));
+        const int i = cur_i++;
+        const int nx = cur_x + (i == 0 ? 1 : (i == 2 ? -1 : 0)), ny = cur_y + (i == 1 ? -1 : (i == 3 ? 1 : 0));
         if (nx < -BGR || nx > BGR || ny < -BGR || ny > BGR) {
             status |= TAIL_CAPACITY;
             break;
         }
         const int gpos = (ny + BGR) * BGN + (nx + BGR);
         const int e = grid[gpos];
-        if (e != 0xff && found[e]) {
-            wsync();  // (every lane has read the stack's top)
-            if (lane == 0) stack[2 * (sp - 1) + 1] = (uint8_t)(i + 1);
-            wsync();
-            continue;
-        }
-        const u64 quad = slot_quad(slot, cell);
-        const u64 qs = i ? (quad >> (16 * i) | quad << (64 - 16 * i)) : quad;  // qs[j] = quad[(j + i) & 3]
+        if (e != 0xff && (e & 0x80)) continue;  // :132-136 already found
+        const u64 qs = i ? (cur_quad >> (16 * i) | cur_quad << (64 - 16 * i)) : cur_quad;  // qs[j] = quad[(j + i) & 3]
         u64 nq = 0;
         const bool ok = expand_one_w(c, slot, qs, nq, lane, status, ek);
-        int at = e;
-        if (at == 0xff) {
+        int at = e & 0x7f;
+        if (e == 0xff) {
             if (n_cells == BCELLS) {
                 status |= TAIL_CAPACITY;
                 break;
             }
             at = n_cells++;
         }
-        wsync();  // (reads of this step are done)
+        const u64 v = i ? (nq << (16 * i) | nq >> (64 - 16 * i)) : nq;  // v[(j + i) & 3] = nq[j]
         if (lane == 0) {
-            stack[2 * (sp - 1) + 1] = (uint8_t)(i + 1);
+            grid[gpos] = (uint8_t)(at | (ok ? 0x80 : 0));
             if (e == 0xff) {
-                grid[gpos] = (uint8_t)at;
                 xy[2 * at] = (int8_t)nx;
                 xy[2 * at + 1] = (int8_t)ny;
             }
+            found[at] = ok ? 1 : 0;
+            slot_set_quad(slot, at, ok ? v : 0ull);
             if (ok) {
-                const u64 v = i ? (nq << (16 * i) | nq >> (64 - 16 * i)) : nq;  // v[(j + i) & 3] = nq[j]
                 for (int j = 0; j < 4; ++j) slot_use(slot, q_at(v, j));
-                slot_set_quad(slot, at, v);
-                found[at] = 1;
-                stack[2 * sp] = (uint8_t)at;  // (depth <= found cells <= BCELLS)
-                stack[2 * sp + 1] = 0;
-            } else {
-                slot_set_quad(slot, at, 0ull);
-                found[at] = 0;
+                stack[2 * (sp - 1)] = (uint8_t)cur;  // where to come back to (depth <= found cells <= BCELLS)
+                stack[2 * (sp - 1) + 1] = (uint8_t)cur_i;
             }
         }
-        if (ok) {
+        if (ok) {  // try_expand(&new_board_idx), :146
             ++score;
             ++sp;
+            cur = at;
+            cur_i = 0;
+            cur_x = nx;
+            cur_y = ny;
+            cur_quad = v;
         }
         wsync();
     }
@@ -592,31 +604,58 @@ __device__ bool quad_bits(const TailArgs &a, const uint8_t *luma, const float q[
     return true;
 }
 
-// best_tag (detector.rs:142-169) by the wave: every lane takes every 64th code; the first code with the smallest distance is
-// the smallest (distance, index) pair
-__device__ bool best_tag_w(const TailArgs &a, u64 bits, int lane, int &idx, int &rot)
+// OR over the lane's row of 16, in every lane of the row
+__device__ __forceinline__ uint32_t row_or_u(uint32_t v)
 {
-    const int nb = a.edge * a.edge;
-    for (int rotated = 0; rotated < 4; ++rotated) {
-        uint32_t best = 0xffffffffu;
-        for (int i = lane; i < a.n_codes; i += 64) {
-            const uint32_t key = (uint32_t)__popcll(a.codes[i] ^ bits) << 16 | (uint32_t)i;
-            best = key < best ? key : best;
-        }
-        for (int o = 32; o; o >>= 1) {
-            const uint32_t v = (uint32_t)__shfl_xor((int)best, o);
-            best = v < best ? v : best;
-        }
-        if ((best >> 16) < (uint32_t)a.hamming) {
-            idx = (int)(best & 0xffffu);
+    v |= dpp_u<0xB1>(v);
+    v |= dpp_u<0x4E>(v);
+    v |= dpp_u<0x141>(v);
+    return v | dpp_u<0x140>(v);
+}
+// rotate_bits (detector.rs:124-140) by a row of 16 lanes: output bit `count` is input bit r + c * edge with
+// count = (edge - 1 - r) * edge + c; every lane sets the output bits l, l + 16, l + 32
+__device__ __forceinline__ u64 rotate_bits_row(u64 bits, int edge, int l)
+{
+    u64 out = 0;
+    for (int count = l; count < edge * edge; count += 16) {
+        const int r = edge - 1 - count / edge, cc = count % edge;
+        out |= ((bits >> (r + cc * edge)) & 1ull) << count;
+    }
+    return (u64)row_or_u((uint32_t)(out >> 32)) << 32 | row_or_u((uint32_t)out);
+}
+
+// best_tag (detector.rs:142-169) by a row of 16 lanes (four quads per wave at a time), the family's codes in LDS.  The
+// reference scans the family once per rotation until one matches; here ONE scan serves the four rotations (every lane takes
+// every 16th code; per rotation the first code with the smallest distance = the smallest (distance, index) pair), then the
+// rotations are looked at in the reference's order -- the same (index, rotation).
+__device__ bool best_tag_row(const TailArgs &a, const u64 *codes, u64 bits, int l, int &idx, int &rot)
+{
+    const int n_codes = a.n_codes, edge = a.edge;
+    const uint32_t hamming = (uint32_t)a.hamming;
+    const u64 b0 = bits, b1 = rotate_bits_row(b0, edge, l), b2 = rotate_bits_row(b1, edge, l), b3 = rotate_bits_row(b2, edge, l);
+    uint32_t m0 = 0xffffffffu, m1 = 0xffffffffu, m2 = 0xffffffffu, m3 = 0xffffffffu;
+#pragma unroll 2
+    for (int i = l; i < n_codes; i += 16) {
+        const u64 code = codes[i];
+        const uint32_t k0 = (uint32_t)__popcll(code ^ b0) << 16 | (uint32_t)i, k1 = (uint32_t)__popcll(code ^ b1) << 16 | (uint32_t)i;
+        const uint32_t k2 = (uint32_t)__popcll(code ^ b2) << 16 | (uint32_t)i, k3 = (uint32_t)__popcll(code ^ b3) << 16 | (uint32_t)i;
+        m0 = k0 < m0 ? k0 : m0;
+        m1 = k1 < m1 ? k1 : m1;
+        m2 = k2 < m2 ? k2 : m2;
+        m3 = k3 < m3 ? k3 : m3;
+    }
+    m0 = row_min_u(m0);
+    m1 = row_min_u(m1);
+    m2 = row_min_u(m2);
+    m3 = row_min_u(m3);
+    const uint32_t ms[4] = {m0, m1, m2, m3};
+#pragma unroll
+    for (int rotated = 0; rotated < 4; ++rotated)
+        if ((ms[rotated] >> 16) < hamming) {
+            idx = (int)(ms[rotated] & 0xffffu);
             rot = rotated;
             return true;
         }
-        if (rotated == 3) break;
-        // rotate_bits (:124-140): output bit `count` is input bit r + c * edge with count = (edge - 1 - r) * edge + c -- a bit per lane
-        const int r = a.edge - 1 - lane / a.edge, cc = lane % a.edge;
-        bits = __ballot(lane < nb && ((bits >> (r + cc * a.edge)) & 1ull));
-    }
     return false;
 }
 
@@ -624,8 +663,8 @@ __device__ bool best_tag_w(const TailArgs &a, u64 bits, int lane, int &idx, int 
 // reference's order; returns how many
 __device__ int init_quads_w(const Ctx &c, uint8_t *wv, int s0, int lane, uint32_t &status, unsigned long long *tk)
 {
-    unsigned long long t_last = wall_clock64();
-#define TKS(i) do { const unsigned long long t_now = wall_clock64(); tk[i] += t_now - t_last; t_last = t_now; } while (0)
+    AGX_TT(unsigned long long t_last = wall_clock64();)
+#define TKS(i) AGX_TT(do { const unsigned long long t_now = wall_clock64(); tk[i] += t_now - t_last; t_last = t_now; } while (0))
     const u64 below = (1ull << lane) - 1ull;
     u64 *cand = reinterpret_cast<u64 *>(wv + WV_CAND);
     uint16_t *pairs = reinterpret_cast<uint16_t *>(wv + WV_PAIRS);
@@ -772,8 +811,10 @@ __global__ void __launch_bounds__(64 * TW) k_board_tail(TailArgs a)
     unsigned long long tk[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = wall_clock64();
     const unsigned long long t_start = t_last;
     int n_cands_total = 0, n_seeds_done = 0, n_boards = 0;
-    unsigned long long ek[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define TK(i) do { const unsigned long long t_now = wall_clock64(); tk[i] += t_now - t_last; t_last = t_now; } while (0)
+    unsigned long long ek[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dk[5] = {0, 0, 0, 0, 0};
+    (void)n_cands_total; (void)n_boards; (void)dk;  // (only the timers' build reads them)
+#define DK(i) AGX_TT(do { const unsigned long long t_now = wall_clock64(); dk[i] += t_now - t_last; t_last = t_now; } while (0))
+#define TK(i) AGX_TT(do { const unsigned long long t_now = wall_clock64(); tk[i] += t_now - t_last; t_last = t_now; } while (0))
     const FrameCounters &fc = a.ctr[f];
     int n = (int)fc.n_out;
     const int n_first = n;
@@ -788,6 +829,9 @@ __global__ void __launch_bounds__(64 * TW) k_board_tail(TailArgs a)
         return;
     }
     if (tid == 0) sh[0] = 0;
+    u64 *codes = reinterpret_cast<u64 *>(lds + OFF_CODES);
+    for (int i = tid; i < a.n_codes && i < TCODES; i += 64 * TW) codes[i] = a.codes[i];
+    if (a.n_codes > TCODES) status |= TAIL_CAPACITY;
     {
         const float *src = a.saddles + (size_t)fc.out_offset * 5;
         for (int i = tid; i < n; i += 64 * TW) {
@@ -931,10 +975,9 @@ __global__ void __launch_bounds__(64 * TW) k_board_tail(TailArgs a)
                 for (int t = 1; t < TW; ++t) ci -= (item >= first_item[t]) ? (int)sh[8 + t - 1] : 0;
                 const u64 q = reinterpret_cast<const u64 *>(lds + OFF_WAVES + w * WV_BYTES + WV_CAND)[ci];
                 int cells;
-                const unsigned long long tb0 = wall_clock64();
+                AGX_TT(const unsigned long long tb0 = wall_clock64();)
                 const uint32_t score = (uint32_t)build_board_w(c, wv + WV_SLOT, q, lane, cells, status, ek);
-                tk[8] += wall_clock64() - tb0;
-                tk[9] += (unsigned long long)cells;
+                AGX_TT(tk[8] += wall_clock64() - tb0; tk[9] += (unsigned long long)cells;)
                 ++n_boards;
                 // the seed's best score and the FIRST candidate that reaches it (what the sequential loop is left with, :616-622)
                 if (lane == 0) atomicMax(&sh[8 + TW + w], score << 16 | (uint32_t)(0xffff - ci));
@@ -972,7 +1015,7 @@ __global__ void __launch_bounds__(64 * TW) k_board_tail(TailArgs a)
                 auto find = [&](int x, int y) -> int {
                     if (x < -BGR || x > BGR || y < -BGR || y > BGR) return -1;
                     const int e = slot[SL_GRID + (y + BGR) * BGN + (x + BGR)];
-                    return e == 0xff ? -1 : e;
+                    return e == 0xff ? -1 : (e & 0x7f);
                 };
                 uint8_t *fa = slot + SL_STACK, *fb = fa + BCELLS;  // the fix list: the two found neighbours ...
                 uint8_t *fm = reinterpret_cast<uint8_t *>(wv + WV_PAIRS);  // ... and the cell between them
@@ -1036,23 +1079,27 @@ __global__ void __launch_bounds__(64 * TW) k_board_tail(TailArgs a)
                 }
             }
             wsync();
-            for (int qi = 0; qi < n_quads; ++qi) {  // the family's codes: the wave per quad
-                if (dec_id[qi] != -2) continue;
-                int id = -1, rot = 0;
-                const bool hit = best_tag_w(a, dec_bits[qi], lane, id, rot);
-                wsync();
-                if (lane == 0) {
-                    dec_id[qi] = hit ? id : -1;
-                    if (hit) {
-                        const u64 q = quads[qi];
-                        for (int i = 0; i < 4; ++i) {  // rotate_left(rot) then reverse, :468-469
-                            const int src = q_at(q, ((3 - i) + rot) & 3);
-                            dec_xy[8 * qi + 2 * i] = sx[src];
-                            dec_xy[8 * qi + 2 * i + 1] = sy[src];
+            DK(0);
+            for (int base = 0; base < n_quads; base += 4) {  // the family's codes: a row of 16 lanes per quad
+                const int qi = base + (lane >> 4);
+                if (qi < n_quads && dec_id[qi] == -2) {
+                    int id = -1, rot = 0;
+                    const bool hit = best_tag_row(a, codes, dec_bits[qi], lane & 15, id, rot);
+                    if ((lane & 15) == 0) {
+                        dec_id[qi] = hit ? id : -1;
+                        if (hit) {
+                            const u64 q = quads[qi];
+                            for (int i = 0; i < 4; ++i) {  // rotate_left(rot) then reverse, :468-469
+                                const int src = q_at(q, ((3 - i) + rot) & 3);
+                                dec_xy[8 * qi + 2 * i] = sx[src];
+                                dec_xy[8 * qi + 2 * i + 1] = sy[src];
+                            }
                         }
                     }
                 }
             }
+            wsync();
+            DK(1);
             for (int i = lane; i < TN / 32; i += 64) used[i] = 0;
             wsync();
             int n_used = 0;
@@ -1085,6 +1132,7 @@ __global__ void __launch_bounds__(64 * TW) k_board_tail(TailArgs a)
             n_tags = __shfl(n_tags, 0);
             n_used = __shfl(n_used, 0);
             wsync();
+            DK(2);
             TK(7);
             // the saddles of decoded quads leave the list (:528-538), order kept
             int kept = 0;
@@ -1118,11 +1166,14 @@ __global__ void __launch_bounds__(64 * TW) k_board_tail(TailArgs a)
     }
     __syncthreads();
     const uint32_t st_all = sh[0];
+#ifdef AGX_TAIL_TIMERS
     if (a.debug >= 2 && f == 0 && tid == 0)
         printf("tail frame 0 (wave 0): ticks grid %llu seeds %llu seed loop %llu (sort50 %llu lists %llu cands %llu boards %llu) fix %llu decode %llu; seeds %d cands %d; boards built by this wave %d, their cells %llu\n", tk[0], tk[1], tk[5],
                tk[2], tk[3], tk[4], tk[8], tk[6], tk[7], n_seeds_done, n_cands_total, n_boards, tk[9]);
+    if (a.debug >= 2 && f == 0 && tid == 0) printf("  decode: sample bits %llu best_tag %llu tag map + used %llu\n", dk[0], dk[1], dk[2]);
     if (a.debug >= 2 && f == 0 && tid == 0)
-        printf("  expand_one: scan %llu reduce+filter %llu broadcast %llu combos %llu; calls %llu, with all four lists %llu\n", ek[0], ek[1], ek[2], ek[3], ek[5], ek[6]);
+        printf("  expand_one: scan %llu reduce+filter %llu broadcast %llu combos %llu; calls %llu, with all four lists %llu; queries that missed the memo %llu of %llu\n", ek[0], ek[1], ek[2], ek[3], ek[5], ek[6], ek[7], 4 * ek[5]);
+#endif
     if (tid == 0) {
         a.table[4 * f] = st_all ? 0u : (uint32_t)n_tags;
         a.table[4 * f + 1] = st_all;
