@@ -67,7 +67,8 @@ constexpr int WV_A3 = WV_CAND + TCAND * 8;      // f32[TA3]: angle(v30, v01) of 
 constexpr int WV_PAIRS = WV_A3 + TA3 * 4;       // u16[1176 + pad]; wave 0: the decode's bits and ids
 constexpr int WV_SMALL = WV_PAIRS + 1184 * 2;   // u16[3][64]: same, diff, the white-block test per s1; f32[2][64]: a0, a2 of the current s1
 constexpr int WV_SLOT = WV_SMALL + 1024;        // the board under construction
-constexpr int WV_BYTES = WV_SLOT + SL_BYTES;
+constexpr int WV_KEEP = WV_SLOT + SL_BYTES;     // cells (quads, coordinates, found flags) of the best board this wave has grown in the round
+constexpr int WV_BYTES = WV_KEEP + SL_GRID;
 static_assert(WV_BYTES % 8 == 0 && WV_A3 - WV_CAND + TA3 * 4 >= TN * 8, "alignment / the keys' space");
 // the frame's LDS (bytes)
 constexpr int OFF_SX = 0, OFF_SY = OFF_SX + TN * 4, OFF_ST = OFF_SY + TN * 4;
@@ -803,7 +804,7 @@ __global__ void __launch_bounds__(64 * TW) k_board_tail(TailArgs a)
     uint32_t *tagids = reinterpret_cast<uint32_t *>(lds + OFF_TAGIDS);
     uint32_t *used = reinterpret_cast<uint32_t *>(lds + OFF_USED);
     uint32_t *hist = reinterpret_cast<uint32_t *>(lds + OFF_HIST);
-    uint32_t *sh = reinterpret_cast<uint32_t *>(lds + OFF_SHARED);  // [0] status, [1] n, [2] seeds, [3] saddles removed, [4] the boards handed out, [8 .. 8 + TW) candidates per wave, [8 + TW ..) the seeds' best boards
+    uint32_t *sh = reinterpret_cast<uint32_t *>(lds + OFF_SHARED);  // [0] status, [1] n, [2] seeds, [3] saddles removed, [4] the boards handed out, [5 .. 7] where the chosen board is kept, [8 .. 8 + TW) candidates per wave, [8 + TW ..) the seeds' best boards
     uint8_t *wv = lds + OFF_WAVES + wave * WV_BYTES;  // this wave's own
 
     uint32_t status = 0;  // per lane; merged through sh[0]
@@ -828,7 +829,10 @@ __global__ void __launch_bounds__(64 * TW) k_board_tail(TailArgs a)
         }
         return;
     }
-    if (tid == 0) sh[0] = 0;
+    if (tid == 0) {
+        sh[0] = 0;
+        sh[5] = sh[6] = sh[7] = 0;
+    }
     u64 *codes = reinterpret_cast<u64 *>(lds + OFF_CODES);
     for (int i = tid; i < a.n_codes && i < TCODES; i += 64 * TW) codes[i] = a.codes[i];
     if (a.n_codes > TCODES) status |= TAIL_CAPACITY;
@@ -941,13 +945,15 @@ __global__ void __launch_bounds__(64 * TW) k_board_tail(TailArgs a)
         // ---- try_find_best_board's loop over the seeds (:613-629), TW seeds at a time: every wave lists the candidate quads
         // of one seed, then the waves take the group's boards one by one from a common counter (the boards of a seed that
         // finds the real board cost fifty times what the others cost) ----------------------------------------------------
-        uint32_t best_score = 0;
+        uint32_t best_score = 0, win_stamp = 0;
         u64 best_quad = 0;
         bool stop = false;
         // (the first seed alone: it usually finds the board and ends the loop -- its neighbours in the list would find it again)
         for (int base = 0, gw = 1; base < total && !stop; base += gw, gw = TW) {
             const int k = base + wave;
             int nc_mine = 0;
+            uint32_t kept_score = 0;  // (what this wave kept in earlier groups is either the chosen board, recorded in sh[5], or beaten)
+            int kept_w = 0, kept_ci = 0, kept_cells = 0;
             if (wave < gw && k < total) {
                 nc_mine = init_quads_w(c, wv, seeds[n_seeds - 1 - k], lane, status, tk);
                 n_cands_total += nc_mine;
@@ -981,15 +987,32 @@ __global__ void __launch_bounds__(64 * TW) k_board_tail(TailArgs a)
                 ++n_boards;
                 // the seed's best score and the FIRST candidate that reaches it (what the sequential loop is left with, :616-622)
                 if (lane == 0) atomicMax(&sh[8 + TW + w], score << 16 | (uint32_t)(0xffff - ci));
+                // The board the merge below may choose is kept (its cells), so that it need not be grown again for
+                // try_fix_missing: one that beats the best of the earlier groups and, in the merge's order (score, then seed,
+                // then candidate), everything this wave has kept in this group -- whatever the merge chooses is the best in that
+                // order of all the group's boards, so the wave that grew it still holds it.
+                if (score > best_score && (score > kept_score || (score == kept_score && (w < kept_w || (w == kept_w && ci < kept_ci))))) {
+                    kept_score = score;
+                    kept_w = w;
+                    kept_ci = ci;
+                    kept_cells = cells;
+                    const uint32_t *src = reinterpret_cast<const uint32_t *>(wv + WV_SLOT);
+                    uint32_t *dst = reinterpret_cast<uint32_t *>(wv + WV_KEEP);
+                    for (int i = lane; i < SL_GRID / 4; i += 64) dst[i] = src[i];
+                    wsync();
+                }
             }
             status = wave_or_u(status);
             if (lane == 0 && status) atomicOr(&sh[0], status);
             __syncthreads();
+            int win_w = -1, win_ci = 0;
             for (int w = 0; w < gw && base + w < total; ++w) {  // the reference's order
                 const uint32_t key = sh[8 + TW + w];
                 if ((key >> 16) > best_score) {
                     best_score = key >> 16;
-                    best_quad = reinterpret_cast<const u64 *>(lds + OFF_WAVES + w * WV_BYTES + WV_CAND)[0xffff - (key & 0xffffu)];
+                    win_w = w;
+                    win_ci = (int)(0xffff - (key & 0xffffu));
+                    best_quad = reinterpret_cast<const u64 *>(lds + OFF_WAVES + w * WV_BYTES + WV_CAND)[win_ci];
                 }
                 if (best_score >= 36) {
                     stop = true;
@@ -997,6 +1020,15 @@ __global__ void __launch_bounds__(64 * TW) k_board_tail(TailArgs a)
                 }
             }
             if (sh[0]) stop = true;  // the frame goes to the host anyway
+            // where the chosen board's cells are kept: sh[5] = the wave + 1 (0: nowhere -- it is grown again), sh[6] = its cells
+            if (win_w >= 0) {  // (every thread alike) the group that chose: round and first seed
+                win_stamp = ((uint32_t)round + 1u) << 8 | (uint32_t)(base + 1);
+                if (lane == 0 && kept_score == best_score && kept_w == win_w && kept_ci == win_ci) {
+                    sh[5] = (uint32_t)wave + 1u;
+                    sh[6] = (uint32_t)kept_cells;
+                    sh[7] = win_stamp;
+                }
+            }
             __syncthreads();
         }
         TK(5);
@@ -1007,7 +1039,20 @@ __global__ void __launch_bounds__(64 * TW) k_board_tail(TailArgs a)
             // all_tag_indexes (board.rs:49-112), cells in insertion order
             uint8_t *slot = wv + WV_SLOT;
             int best_cells = 0;
-            (void)build_board_w(c, slot, best_quad, lane, best_cells, status, ek);
+            if (sh[7] == win_stamp && sh[5] != 0) {  // kept by the wave that grew it: its cells, and the grid from them
+                const uint32_t *src = reinterpret_cast<const uint32_t *>(lds + OFF_WAVES + (sh[5] - 1u) * WV_BYTES + WV_KEEP);
+                uint32_t *dst = reinterpret_cast<uint32_t *>(slot);
+                best_cells = (int)sh[6];
+                for (int i = lane; i < SL_GRID / 4; i += 64) dst[i] = src[i];
+                for (int i = lane; i < (SL_ACTIVE - SL_GRID) / 4; i += 64) reinterpret_cast<uint32_t *>(slot + SL_GRID)[i] = 0xffffffffu;
+                wsync();
+                const int8_t *xy = reinterpret_cast<const int8_t *>(slot + SL_XY);
+                for (int i = lane; i < best_cells; i += 64)
+                    slot[SL_GRID + (xy[2 * i + 1] + BGR) * BGN + (xy[2 * i] + BGR)] = (uint8_t)(i | (slot[SL_FOUND + i] ? 0x80 : 0));
+                wsync();
+            } else {
+                (void)build_board_w(c, slot, best_quad, lane, best_cells, status, ek);
+            }
             int n_quads = 0;
             if (lane == 0) {
                 const int8_t *xy = reinterpret_cast<const int8_t *>(slot + SL_XY);
