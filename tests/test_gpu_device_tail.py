@@ -156,6 +156,22 @@ def test_frames_the_kernel_cannot_take(pair):
     assert rc_h == rc_d != 0 and np.array_equal(st_h, st_d) and np.array_equal(cnt_h, cnt_d) and (st_d != 0).any()
 
 
+def test_boards_larger_than_the_kernels_lists(pair, oracle):
+    """A 10 x 10 board has more cells than one board of the kernel holds (128, within 12 cells of the seed): the frame is handed
+    to the host tail -- the same 100 tags as without the option, and as the oracle's.  A 7 x 9 board still fits."""
+    host, dev = pair
+    synth = synth_module()
+    big = np.stack([synth.render_frame(5 + i, 1280, 800, spec=synth.BoardSpec(rows=10, cols=10))[0].numpy() for i in range(3)])
+    counts, back = same_results(host, dev, big, cap=256)
+    assert back == 3 and counts.min() >= 90, (back, counts)
+    got = dev.detect_batch(big[:1], n_threads=2, cap=256)[0]
+    ref = oracle.detect(big[0])
+    assert sorted(got) == sorted(ref) and all(bits_equal(got[t], ref[t]) for t in ref)
+    mid = np.stack([synth.render_frame(9 + i, 1280, 800, spec=synth.BoardSpec(rows=7, cols=9))[0].numpy() for i in range(3)])
+    counts, back = same_results(host, dev, mid, cap=256)
+    assert back <= 1 and counts.min() >= 55, (back, counts)
+
+
 def test_the_option_is_refused_where_libm_differs():
     """The kernel evaluates atan2f by glibc's routine; the option checks the host's atan2f against it first (here: equal)."""
     import ctypes as C
