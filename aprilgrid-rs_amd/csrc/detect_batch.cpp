@@ -482,6 +482,7 @@ static int detect_batch_impl(agx_detector *det, const void *frames, const void *
     if (agx_internal_device_tail(det))
         return detect_batch_device_tail(det, frames, d_frames, n_frames, width, height, row_stride_bytes, frame_stride_bytes, format, out,
                                         cap_per_frame, counts, frame_status, pool);
+    agx_internal_tail_stats(det, 0, 0, 0);  // ("last_device_tail_frames" 0: this call's tails run on the host)
 
     // Chunks of about one frame per worker (8 .. 64): the chain of a chunk takes 0.1 ms on the device, a frame's board
     // search about a millisecond on a host thread, so small chunks cost nothing and the workers start after the first 8 .. 64 frames

@@ -617,7 +617,8 @@ __attribute__((visibility("hidden"))) int agx_internal_fetch_compact(agx_detecto
 // routine -- checked once per process on 2^20 operand pairs (more in tests/test_abi_cpu.py)
 static uint64_t libm_check_once()
 {
-    static const uint64_t mismatches = libm_atan2f_mismatches(1u << 20, 1);
+    // (AGX_DEBUG_LIBM_MISMATCH=1: tests of the refusal path pretend that one input differs)
+    static const uint64_t mismatches = libm_atan2f_mismatches(1u << 20, 1) + (uint64_t)(tuning_env("AGX_DEBUG_LIBM_MISMATCH", 0) != 0);
     return mismatches;
 }
 __attribute__((visibility("hidden"))) int agx_internal_device_tail(agx_detector *det)

@@ -173,8 +173,33 @@ def test_boards_larger_than_the_kernels_lists(pair, oracle):
 
 
 def test_the_option_is_refused_where_libm_differs():
-    """The kernel evaluates atan2f by glibc's routine; the option checks the host's atan2f against it first (here: equal)."""
+    """The kernel evaluates atan2f by glibc's routine; the option checks the host's atan2f against it first (here: equal).  A process
+    whose libm differs (pretended: AGX_DEBUG_LIBM_MISMATCH=1) is refused the option with AGX_ERR_STATE, and the default quietly
+    stays on the host tail -- with the same tags."""
     import ctypes as C
+    import os
+    import subprocess
+    import sys
     import aprilgrid_rs_amd as A
     bad = C.c_uint64(1)
     assert A._ffi.lib().agx_debug_libm_atan2f_check(1 << 22, 7, C.byref(bad)) == 0 and bad.value == 0
+    code = """
+import numpy as np, torch, aprilgrid_rs_amd as A
+from aprilgrid_rs_amd import synth
+d = A.TagDetector("t36h11", None, device=0)
+try:
+    d.set_option("device_tail", 1)
+    raise SystemExit("not refused")
+except A.AgxError as e:
+    assert e.status == A._ffi.AGX_ERR_STATE and "atan2f" in str(e), e
+fr, _ = synth.render_batch(300, 4, 320, 240, device="cuda")
+d.set_option("device_tail", -1)
+tags = d.detect_batch(fr.cpu().numpy(), n_threads=2)
+assert d.get_option("device_tail") == 0 and d.get_option("last_device_tail_frames") == 0, (d.get_option("device_tail"), d.get_option("last_device_tail_frames"))
+assert sum(len(t) for t in tags) > 40, [len(t) for t in tags]
+print("refused, host tail:", [len(t) for t in tags])
+"""
+    env = dict(os.environ, AGX_DEBUG_LIBM_MISMATCH="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "refused, host tail" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
