@@ -18,7 +18,7 @@ enum : uint32_t {
     TAIL_CHAIN = 4u       // the chain itself reported an overflow for the frame (no saddle list): reported as such
 };
 
-constexpr int TAIL_MAX_SADDLES = 512;  // saddles of a frame the device tail takes (more: TAIL_CAPACITY)
+constexpr int TAIL_MAX_SADDLES = 1024;  // saddles of a frame the device tail takes (more: TAIL_CAPACITY)
 
 struct TailArgs {
     // the chain's results of the batch (device): compact agx_saddle array + per-frame counters (n_out, out_offset, flags)

@@ -56,20 +56,20 @@ constexpr int SL_XY = 1024;      // i8[BCELLS][2]
 constexpr int SL_FOUND = 1280;   // u8[BCELLS]
 constexpr int SL_GRID = 1408;    // u8[BGN * BGN] cell coordinates -> cell number (0xff none)
 constexpr int SL_ACTIVE = 2048;  // u32[TN / 32]: board.rs active_idxs
-constexpr int SL_STACK = 2112;   // u8[BCELLS][2]: cell, next direction
-constexpr int SL_BYTES = 2368;
+constexpr int SL_STACK = SL_ACTIVE + TN / 8;  // u8[BCELLS][2]: cell, next direction
+constexpr int SL_BYTES = SL_STACK + 2 * BCELLS;
 static_assert(BGN * BGN <= SL_ACTIVE - SL_GRID, "board grid");
-static_assert(TN / 8 <= SL_STACK - SL_ACTIVE, "active mask");
+static_assert(TN / 8 <= SL_STACK - SL_ACTIVE && SL_BYTES % 8 == 0 && TN <= 1024, "active mask; an index is 10 bits in the memo keys");
 
 // a wave's own LDS (bytes)
-constexpr int WV_CAND = 0;                      // u64[TCAND]; with the table behind it also u64[TN] distance keys and, on wave 0, the decode's corners
+constexpr int WV_CAND = 0;                      // u64[TCAND]; with what lies behind it (up to the kept board) also u64[TN] distance keys; with the table, on wave 0, the decode's corners
 constexpr int WV_A3 = WV_CAND + TCAND * 8;      // f32[TA3]: angle(v30, v01) of the seed's (d0, d1) pairs
 constexpr int WV_PAIRS = WV_A3 + TA3 * 4;       // u16[1176 + pad]; wave 0: the decode's bits and ids
 constexpr int WV_SMALL = WV_PAIRS + 1184 * 2;   // u16[3][64]: same, diff, the white-block test per s1; f32[2][64]: a0, a2 of the current s1
 constexpr int WV_SLOT = WV_SMALL + 1024;        // the board under construction
 constexpr int WV_KEEP = WV_SLOT + SL_BYTES;     // cells (quads, coordinates, found flags) of the best board this wave has grown in the round
 constexpr int WV_BYTES = WV_KEEP + SL_GRID;
-static_assert(WV_BYTES % 8 == 0 && WV_A3 - WV_CAND + TA3 * 4 >= TN * 8, "alignment / the keys' space");
+static_assert(WV_BYTES % 8 == 0 && WV_KEEP - WV_CAND >= TN * 8, "alignment / the keys' space (the candidate list, the tables behind it and the board: all dead while a seed's distances are sorted)");
 // the frame's LDS (bytes)
 constexpr int OFF_SX = 0, OFF_SY = OFF_SX + TN * 4, OFF_ST = OFF_SY + TN * 4;
 constexpr int OFF_GX = OFF_ST + TN * 4, OFF_GY = OFF_GX + TN * 4, OFF_GI = OFF_GY + TN * 4;
@@ -330,8 +330,8 @@ __device__ bool expand_one_w(const Ctx &c, const uint8_t *slot, u64 qs, u64 &out
     const int ia = g < 2 ? q_at(qs, 0) : q_at(qs, 3), ib = g < 2 ? q_at(qs, 1) : q_at(qs, 2);  // the pair (first, second)
     const int anchor = (g & 1) ? ib : ia;                                                      // whose neighbour is looked for
     // what the query finds before the board's own test (radius and orientation, :207-216), from the memo or by the search:
-    // raw = idx0 | idx1 << 9 | idx2 << 18 | count << 27
-    const uint32_t pkey = 0x80000000u | (uint32_t)ia << 10 | (uint32_t)ib << 1 | (uint32_t)(g & 1);
+    // raw = idx0 | idx1 << 10 | idx2 << 20 | count << 30 (an index has 10 bits: TN = 1024)
+    const uint32_t pkey = 0x80000000u | (uint32_t)ia << 11 | (uint32_t)ib << 1 | (uint32_t)(g & 1);
     u64 *pslot = c.memo_p + ((pkey * 2654435761u) >> 21);
     const u64 pe = __hip_atomic_load(pslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     uint32_t raw = (uint32_t)pe;
@@ -380,14 +380,14 @@ __device__ bool expand_one_w(const Ctx &c, const uint8_t *slot, u64 qs, u64 &out
         const uint32_t m3 = (uint32_t)(__ballot(ok) >> (16 * g)) & 7u;  // this query's three
         uint32_t rcnt = 0;
         raw = 0;
-        if (m3 & 1u) { raw |= ((uint32_t)top0 & 0x1ffu) << (9 * rcnt); ++rcnt; }
-        if (m3 & 2u) { raw |= ((uint32_t)top1 & 0x1ffu) << (9 * rcnt); ++rcnt; }
-        if (m3 & 4u) { raw |= ((uint32_t)top2 & 0x1ffu) << (9 * rcnt); ++rcnt; }
-        raw |= rcnt << 27;
+        if (m3 & 1u) { raw |= ((uint32_t)top0 & 0x3ffu) << (10 * rcnt); ++rcnt; }
+        if (m3 & 2u) { raw |= ((uint32_t)top1 & 0x3ffu) << (10 * rcnt); ++rcnt; }
+        if (m3 & 4u) { raw |= ((uint32_t)top2 & 0x3ffu) << (10 * rcnt); ++rcnt; }
+        raw |= rcnt << 30;
         if (l == 0) __hip_atomic_store(pslot, (u64)pkey << 32 | raw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     EK(0);
-    if (__ballot((raw >> 27) == 0)) {  // a query that finds nothing leaves an empty list, and try_expand_one's loops are empty with it
+    if (__ballot((raw >> 30) == 0)) {  // a query that finds nothing leaves an empty list, and try_expand_one's loops are empty with it
         AGX_TT(ek[5] += 1;)
         return false;
     }
@@ -395,10 +395,10 @@ __device__ bool expand_one_w(const Ctx &c, const uint8_t *slot, u64 qs, u64 &out
     u64 list = 0;
     int cnt = 0;
     {
-        const int rn = (int)(raw >> 27);
+        const int rn = (int)(raw >> 30);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const int idx = (int)((raw >> (9 * i)) & 0x1ffu);
+            const int idx = (int)((raw >> (10 * i)) & 0x3ffu);
             if (i < rn && slot_active(slot, idx)) {
                 list |= (u64)idx << (16 * cnt);
                 ++cnt;
@@ -425,14 +425,14 @@ __device__ bool expand_one_w(const Ctx &c, const uint8_t *slot, u64 qs, u64 &out
         const int a = q_at(l0, j0 < 3 ? j0 : 0), b = q_at(l1, j1), cc = q_at(l2, j2), d = q_at(l3, j3);
         int v = 0;
         if (in) {  // is_valid_quad of these four: from the memo, or evaluated and kept
-            const u64 qkey = 1ull << 63 | (u64)a | (u64)b << 9 | (u64)cc << 18 | (u64)d << 27;
+            const u64 qkey = 1ull << 63 | (u64)a | (u64)b << 10 | (u64)cc << 20 | (u64)d << 30;
             u64 *qslot = c.memo_q + (((uint32_t)qkey * 2654435761u ^ (uint32_t)(qkey >> 20) * 40503u) >> 21);
             const u64 qe = __hip_atomic_load(qslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if ((qe & ~(3ull << 36)) == qkey) {
-                v = (int)((qe >> 36) & 3ull);
+            if ((qe & ~(3ull << 40)) == qkey) {
+                v = (int)((qe >> 40) & 3ull);
             } else {
                 v = valid_quad(c, a, b, cc, d);
-                __hip_atomic_store(qslot, qkey | (u64)v << 36, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(qslot, qkey | (u64)v << 40, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
         const u64 mv = __ballot(v == 1), mu = __ballot(v == 2);

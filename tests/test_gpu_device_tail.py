@@ -156,6 +156,19 @@ def test_frames_the_kernel_cannot_take(pair):
     assert rc_h == rc_d != 0 and np.array_equal(st_h, st_d) and np.array_equal(cnt_h, cnt_d) and (st_d != 0).any()
 
 
+def test_frames_with_more_than_512_saddles_stay_on_the_device(pair):
+    """Three board frames side by side: 600 or so saddles, three boards for the two rounds of the search -- within the kernel's 1024."""
+    host, dev = pair
+    synth = synth_module()
+    fr, _ = synth.render_batch(500, 24, 640, 480, device="cuda")
+    a = fr.cpu().numpy()
+    wide = np.ascontiguousarray(np.concatenate([a[0::3], a[1::3], a[2::3]], axis=2))  # 8 frames of 1920 x 480
+    n_saddles = [len(host.refined_saddle_points(w, as_array=True)) for w in wide]
+    assert max(n_saddles) > 512, n_saddles
+    counts, back = same_results(host, dev, wide, cap=128)
+    assert back <= 1 and counts.min() >= 30, (back, counts, n_saddles)  # (the boards carry the same 36 ids: the later board's corners replace the earlier's)
+
+
 def test_boards_larger_than_the_kernels_lists(pair, oracle):
     """A 10 x 10 board has more cells than one board of the kernel holds (128, within 12 cells of the seed): the frame is handed
     to the host tail -- the same 100 tags as without the option, and as the oracle's.  A 7 x 9 board still fits."""
