@@ -19,19 +19,22 @@
 // itself).  So do frames beyond the fixed list sizes (TAIL_CAPACITY).  A frame the kernel reports TAIL_OK for has the host
 // tail's tags, bit for bit (tests/test_gpu_device_tail.py).
 //
-// Mapping.  One workgroup of four waves per frame; the frame's saddles and a uniform-grid index for the 3-NN queries of
-// find_closest_potential_saddle_idxs (src/board.rs:177-233) are shared in LDS, every wave has its own candidate list and
-// board (~75 KB per frame: two frames per CU).
-//   seeds     the waves take the seeds of try_find_best_board four at a time, one each; what a seed contributes to the
-//             sequential loop (:613-629) is its best score and the first quad that reaches it, so the merge walks the four
-//             results in the reference's order with the reference's rules (strict improvement, stop at >= 36, 30 seeds) --
-//             as host_tail.cpp's find_best_board_parallel does on threads;
+// Mapping.  One workgroup of eight waves per frame (a frame = a CU); the frame's saddles, a uniform-grid index for the 3-NN
+// queries of find_closest_potential_saddle_idxs (src/board.rs:177-233), two memo tables and the family's codes are shared in
+// LDS, every wave has its own candidate list, angle tables, the board it is growing and the best board it has grown (155 KB).
+//   seeds     the first seed of try_find_best_board alone (it usually ends the loop), then eight at a time, one wave each; what
+//             a seed contributes to the sequential loop (:613-629) is its best score and the first quad that reaches it, so the
+//             merge walks the group's results in the reference's order with the reference's rules (strict improvement, stop at
+//             >= 36, 30 seeds) -- as host_tail.cpp's find_best_board_parallel does on threads;
 //   init_quads  50-NN by a bitonic sort of the distance keys; the same / different orientation lists and the (d0, d1)
-//             combinations by ballot + prefix count, in the reference's order; is_valid_quad per lane;
-//   a board   is grown by the whole wave: board.rs's recursion is a stack walked in lock step, the four 3-NN queries of a
-//             try_expand_one run on 16 lanes each over the grid cells their radius reaches, its up to 81 candidate
-//             quadruples are tested one per lane and the first valid one in the reference's loop order is taken;
-//   the rest  (try_fix_missing, decode, the tag map, removing the used saddles) on the first wave.
+//             combinations by ballot + prefix count, in the reference's order; a lane per combination, the angle terms that
+//             depend on fewer than four saddles from tables;
+//   boards    the group's candidate quads are handed out to the waves from a common counter; a board is grown by the whole wave:
+//             board.rs's recursion is a stack walked in lock step (its top in registers), the four 3-NN queries of a
+//             try_expand_one run on 16 lanes each over the grid cells their radius reaches (memoised per pair), its up to 81
+//             candidate quadruples are tested one per lane (is_valid_quad memoised) and the first valid one in the reference's
+//             loop order is taken; the wave that grew the chosen board keeps its cells;
+//   the rest  (try_fix_missing, decode -- best_tag by rows of 16 lanes --, the tag map, removing the used saddles) on the first wave.
 #include <hip/hip_runtime.h>
 
 #include "libm_f32.h"

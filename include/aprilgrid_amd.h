@@ -142,7 +142,7 @@ int agx_detector_set_limits(agx_detector *det, uint32_t max_candidates, uint32_t
  *                          atan2f is glibc's own routine -- the kernel evaluates angle_degree (math_util.rs:31-33) by that routine,
  *                          restated; decided at the first batch --, else off; 1: on, AGX_ERR_STATE where libm differs; 0: off.
  *                          The tags are the host tail's bit for bit either way: a frame the kernel cannot decide (an angle
- *                          within 1e-4 degrees of the white-block thresholds, saddle.rs:26-38) or hold (more than 512 saddles,
+ *                          within 1e-4 degrees of the white-block thresholds, saddle.rs:26-38) or hold (more than 1024 saddles,
  *                          128 board cells ...) is handed to the host tail.  Read back: "last_device_tail_frames",
  *                          "last_device_tail_fallbacks", "last_device_tail_uncertain" of the last agx_detect_batch call
  *   "debug_ablation"       measurement switches of the kernels (tools/): bits 1 .. 1024 remove parts of the blur kernel's
