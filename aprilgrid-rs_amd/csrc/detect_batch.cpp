@@ -294,23 +294,42 @@ static int detect_batch_device_tail(agx_detector *det, const void *frames, const
     std::deque<std::vector<agx_saddle>> handed_back;  // saddle lists of frames for the host tail (alive until the pool is drained)
     int rc = AGX_OK, n_fallback = 0, n_uncertain = 0;
     bool pending_batch = false;
-    std::mutex one_upload;  // the chunks go up one after the other: three large copies side by side share the link, and the first
-                            // chunk -- the one the device waits for -- would arrive with the third
-    auto upload_task = [&, device](int ci) {
+    // A chunk goes up in S parts on S workers at once (a copy from pageable memory is staged by the calling thread: one thread
+    // does not fill the link on every host), the chunks one after the other (three large chunks side by side would share the
+    // link, and the first -- the one the device waits for -- would arrive with the third): a part starts when fewer than S
+    // parts with smaller numbers are unfinished.
+    int parts_done = 0;                 // (guarded by m)
+    std::vector<int> parts_left;        // per chunk                                   (guarded by m)
+    std::vector<char> chunk_failed;     //                                             (guarded by m)
+    auto upload_part = [&, device](int ci, int part) {
         const int c0 = ci * chunk, nf = std::min(chunk, n_frames - c0), slot = ci % S;
-        std::lock_guard<std::mutex> one(one_upload);
-        const bool ok = hipSetDevice(device) == hipSuccess &&
-                        hipMemcpyAsync(d_stage + (size_t)slot * chunk_bytes, (const uint8_t *)frames + (size_t)c0 * frame_stride_bytes,
-                                       (size_t)nf * frame_stride_bytes, hipMemcpyHostToDevice, up[slot]) == hipSuccess &&
-                        hipStreamSynchronize(up[slot]) == hipSuccess;
+        const int f0 = (int)((long long)nf * part / S), f1 = (int)((long long)nf * (part + 1) / S);
+        {
+            std::unique_lock<std::mutex> lk(m);
+            cv.wait(lk, [&] { return ci * S + part - parts_done < S; });
+        }
+        const bool ok = f1 <= f0 ||
+                        (hipSetDevice(device) == hipSuccess &&
+                         hipMemcpyAsync(d_stage + (size_t)slot * chunk_bytes + (size_t)f0 * frame_stride_bytes,
+                                        (const uint8_t *)frames + (size_t)(c0 + f0) * frame_stride_bytes, (size_t)(f1 - f0) * frame_stride_bytes,
+                                        hipMemcpyHostToDevice, up[part]) == hipSuccess &&
+                         hipStreamSynchronize(up[part]) == hipSuccess);
         {
             std::lock_guard<std::mutex> lk(m);
-            uploaded[(size_t)ci] = ok ? 1 : -1;
+            ++parts_done;
+            if (!ok) chunk_failed[(size_t)ci] = 1;
+            if (--parts_left[(size_t)ci] == 0) uploaded[(size_t)ci] = chunk_failed[(size_t)ci] ? -1 : 1;
         }
         cv.notify_all();
     };
+    auto upload_task = [&](int ci) {  // (queue order = start order: the parts of a chunk side by side)
+        for (int part = 1; part < S; ++part) pool->submit_front([&upload_part, ci, part] { upload_part(ci, part); });
+        upload_part(ci, 0);
+    };
     try {
     uploaded.assign((size_t)n_chunks, 0);
+    parts_left.assign((size_t)n_chunks, S);
+    chunk_failed.assign((size_t)n_chunks, 0);
     if (!d_frames)
         for (int ci = 0; ci < std::min(S, n_chunks); ++ci) pool->submit([&upload_task, ci] { upload_task(ci); });
     std::vector<uint32_t> ns, offs;
