@@ -464,10 +464,13 @@ def detect_end_to_end_leg(torch, A, dev, n_frames, width, height, quick=False):
             c2 = np.zeros(len(big), np.uint32)
             s2 = np.zeros(len(big), np.int32)
             det.detect_batch_raw(big[:1024], n_threads=quota, cap=cap, out=o2[:1024], counts=c2[:1024], status=s2[:1024])  # (staging of the stream's chunk size)
-            t0 = time.perf_counter()
-            rc, _, _, _ = det.detect_batch_raw(big, n_threads=quota, cap=cap, out=o2, counts=c2, status=s2)
-            dt = time.perf_counter() - t0
-            assert rc == 0 and np.array_equal(c2[:n_frames], c2[-n_frames:]) and (s2 == 0).all()
+            dt = None
+            for _ in range(2):  # (the better of two: the box's other tenants share its host memory and PCIe root)
+                t0 = time.perf_counter()
+                rc, _, _, _ = det.detect_batch_raw(big, n_threads=quota, cap=cap, out=o2, counts=c2, status=s2)
+                d1 = time.perf_counter() - t0
+                dt = d1 if dt is None or d1 < dt else dt
+                assert rc == 0 and np.array_equal(c2[:n_frames], c2[-n_frames:]) and (s2 == 0).all()
             res["frames_per_s_%d_frames" % len(big)] = round(len(big) / dt, 1)
             del o2, c2, s2
         # the same frames in PINNED host memory (hipHostMalloc / torch pin_memory): the runtime's pageable path already runs at
