@@ -116,7 +116,7 @@ struct agx_detector {
 
     // option "device_tail": agx_detect_batch's board search + decode on the device (tail_kernels.hip); frames the kernel
     // hands back (TAIL_UNCERTAIN / TAIL_CAPACITY) take the host tail
-    int device_tail = -1;  // -1: where this process's atan2f is the routine the kernel restates (decided at the first batch), 0 off, 1 on
+    int device_tail = -1;  // -1: by the batch's size, where this process's atan2f is the routine the kernel restates; 0 off; 1 on
     uint64_t *d_codes = nullptr;                                     // the family's code list
     agx_tag *h_tags = nullptr, *h_tags_dev = nullptr;                // mapped pinned [tail_frames][tail_tag_cap]
     uint32_t *h_tail_table = nullptr, *h_tail_table_dev = nullptr;   // mapped pinned [tail_frames][4]: count, status, ticks, saddles | seeds << 16
@@ -621,9 +621,10 @@ static uint64_t libm_check_once()
     static const uint64_t mismatches = libm_atan2f_mismatches(1u << 20, 1) + (uint64_t)(tuning_env("AGX_DEBUG_LIBM_MISMATCH", 0) != 0);
     return mismatches;
 }
+// 0: the host tail; 1: the device tail (asked for); 2: the device tail is available and the call may choose by its size
 __attribute__((visibility("hidden"))) int agx_internal_device_tail(agx_detector *det)
 {
-    if (det->device_tail < 0) det->device_tail = libm_check_once() == 0 ? 1 : 0;
+    if (det->device_tail < 0) return libm_check_once() == 0 ? 2 : 0;
     return det->device_tail;
 }
 __attribute__((visibility("hidden"))) void agx_internal_tail_stats(agx_detector *det, int frames, int fallbacks, int uncertain)
@@ -934,7 +935,7 @@ int agx_detector_get_option(const agx_detector *det, const char *name, int *valu
     else if (!std::strcmp(name, "store_response")) *value = det->store_resp;
     else if (!std::strcmp(name, "debug_ablation")) *value = det->dbg;
     else if (!std::strcmp(name, "tail_threads")) *value = det->tail_threads;
-    else if (!std::strcmp(name, "device_tail")) *value = det->device_tail;  // (-1: not decided yet)
+    else if (!std::strcmp(name, "device_tail")) *value = det->device_tail;  // (-1: by the batch's size, where available)
     else if (!std::strcmp(name, "last_device_tail_frames")) *value = det->last_tail_frames;
     else if (!std::strcmp(name, "last_device_tail_fallbacks")) *value = det->last_tail_fallbacks;
     else if (!std::strcmp(name, "last_device_tail_uncertain")) *value = det->last_tail_uncertain;  // (of them: an angle inside its guard band)
