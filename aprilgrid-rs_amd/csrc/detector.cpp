@@ -679,6 +679,7 @@ __attribute__((visibility("hidden"))) int agx_internal_enqueue_tail(agx_detector
     t.table = det->h_tail_table_dev;
     t.tag_cap = det->tail_tag_cap;
     t.debug = tuning_env("AGX_TAIL_DEBUG", 0);
+    t.debug_frame = tuning_env("AGX_TAIL_DEBUG_FRAME", 0);
     if (launch_board_tail(t, det->stream) != 0) return AGX_ERR_HIP;
     return AGX_OK;
 }

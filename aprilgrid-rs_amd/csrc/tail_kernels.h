@@ -38,7 +38,8 @@ struct TailArgs {
     agx_tag *tags;
     uint32_t *table;
     uint32_t tag_cap;
-    int debug;  // AGX_TAIL_DEBUG >= 2: frame 0's wave prints where its time went (100 MHz ticks)
+    int debug;  // AGX_TAIL_DEBUG >= 2 (and a build with -DAGX_TAIL_TIMERS): frame debug_frame's first wave prints where its time went (100 MHz ticks)
+    int debug_frame;  // AGX_TAIL_DEBUG_FRAME (default 0)
 };
 
 // Enqueue the device tail of the batch on `stream`; hipError_t.

@@ -394,48 +394,34 @@ __device__ bool expand_one_w(const Ctx &c, const uint8_t *slot, u64 qs, u64 &out
         AGX_TT(ek[5] += 1;)
         return false;
     }
-    // the board's own test (:207 active_idxs)
-    u64 list = 0;
-    int cnt = 0;
-    {
-        const int rn = (int)(raw >> 30);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int idx = (int)((raw >> (10 * i)) & 0x3ffu);
-            if (i < rn && slot_active(slot, idx)) {
-                list |= (u64)idx << (16 * cnt);
-                ++cnt;
-            }
-        }
-        if (__ballot(cnt == 0)) {
-            EK(1);
-            AGX_TT(ek[5] += 1;)
-            return false;
-        }
-    }
-    list |= (u64)cnt << 48;
-    EK(1);
-    const u64 l0 = shfl_u64(list, 0), l1 = shfl_u64(list, 16), l3 = shfl_u64(list, 32), l2 = shfl_u64(list, 48);
-    const int n0 = (int)(l0 >> 48), n1 = (int)(l1 >> 48), n2 = (int)(l2 >> 48), n3 = (int)(l3 >> 48);
+    // The four lists to every lane (they sit in lanes 0, 16, 32, 48), then the reference's four nested loops (:160-174) as one
+    // combination per lane, numbered in loop order over the lists BEFORE the board's own test (:207 active_idxs): a combination
+    // counts if its four saddles are still unused by this board -- dropping the used ones from the lists first, as the
+    // reference does, leaves the same combinations in the same order.  The used-bits and the memo are read side by side.
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)raw, 0), r1 = (uint32_t)__builtin_amdgcn_readlane((int)raw, 16);
+    const uint32_t r3 = (uint32_t)__builtin_amdgcn_readlane((int)raw, 32), r2 = (uint32_t)__builtin_amdgcn_readlane((int)raw, 48);
+    const int n0 = (int)(r0 >> 30), n1 = (int)(r1 >> 30), n2 = (int)(r2 >> 30), n3 = (int)(r3 >> 30);
     EK(2);
-    AGX_TT(ek[5] += 1;)
-    if (n0 == 0 || n1 == 0 || n2 == 0 || n3 == 0) return false;  // (an empty loop)
-    AGX_TT(ek[6] += 1;)
+    AGX_TT(ek[5] += 1; ek[6] += 1;)
     for (int pass = 0; pass < 2; ++pass) {
-        const int L = lane + 64 * pass;  // the combination's number in loop order: ((i0 * 3 + i1) * 3 + i2) * 3 + i3
+        const int L = lane + 64 * pass;  // ((i0 * 3 + i1) * 3 + i2) * 3 + i3
         const int j0 = L / 27, j1 = (L / 9) % 3, j2 = (L / 3) % 3, j3 = L % 3;
         const bool in = L < 81 && j0 < n0 && j1 < n1 && j2 < n2 && j3 < n3;
-        const int a = q_at(l0, j0 < 3 ? j0 : 0), b = q_at(l1, j1), cc = q_at(l2, j2), d = q_at(l3, j3);
+        const int a = (int)((r0 >> (10 * (j0 < 3 ? j0 : 0))) & 0x3ffu), b = (int)((r1 >> (10 * j1)) & 0x3ffu);
+        const int cc = (int)((r2 >> (10 * j2)) & 0x3ffu), d = (int)((r3 >> (10 * j3)) & 0x3ffu);
         int v = 0;
-        if (in) {  // is_valid_quad of these four: from the memo, or evaluated and kept
+        if (in) {
             const u64 qkey = 1ull << 63 | (u64)a | (u64)b << 10 | (u64)cc << 20 | (u64)d << 30;
             u64 *qslot = c.memo_q + (((uint32_t)qkey * 2654435761u ^ (uint32_t)(qkey >> 20) * 40503u) >> 21);
             const u64 qe = __hip_atomic_load(qslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if ((qe & ~(3ull << 40)) == qkey) {
-                v = (int)((qe >> 40) & 3ull);
-            } else {
-                v = valid_quad(c, a, b, cc, d);
-                __hip_atomic_store(qslot, qkey | (u64)v << 40, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const bool unused = slot_active(slot, a) && slot_active(slot, b) && slot_active(slot, cc) && slot_active(slot, d);
+            if (unused) {  // is_valid_quad of these four: from the memo, or evaluated and kept
+                if ((qe & ~(3ull << 40)) == qkey) {
+                    v = (int)((qe >> 40) & 3ull);
+                } else {
+                    v = valid_quad(c, a, b, cc, d);
+                    __hip_atomic_store(qslot, qkey | (u64)v << 40, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
             }
         }
         const u64 mv = __ballot(v == 1), mu = __ballot(v == 2);
@@ -1215,11 +1201,11 @@ __global__ void __launch_bounds__(64 * TW) k_board_tail(TailArgs a)
     __syncthreads();
     const uint32_t st_all = sh[0];
 #ifdef AGX_TAIL_TIMERS
-    if (a.debug >= 2 && f == 0 && tid == 0)
-        printf("tail frame 0 (wave 0): ticks grid %llu seeds %llu seed loop %llu (sort50 %llu lists %llu cands %llu boards %llu) fix %llu decode %llu; seeds %d cands %d; boards built by this wave %d, their cells %llu\n", tk[0], tk[1], tk[5],
+    if (a.debug >= 2 && f == a.debug_frame && tid == 0)
+        printf("tail frame (wave 0): ticks grid %llu seeds %llu seed loop %llu (sort50 %llu lists %llu cands %llu boards %llu) fix %llu decode %llu; seeds %d cands %d; boards built by this wave %d, their cells %llu\n", tk[0], tk[1], tk[5],
                tk[2], tk[3], tk[4], tk[8], tk[6], tk[7], n_seeds_done, n_cands_total, n_boards, tk[9]);
-    if (a.debug >= 2 && f == 0 && tid == 0) printf("  decode: sample bits %llu best_tag %llu tag map + used %llu\n", dk[0], dk[1], dk[2]);
-    if (a.debug >= 2 && f == 0 && tid == 0)
+    if (a.debug >= 2 && f == a.debug_frame && tid == 0) printf("  decode: sample bits %llu best_tag %llu tag map + used %llu\n", dk[0], dk[1], dk[2]);
+    if (a.debug >= 2 && f == a.debug_frame && tid == 0)
         printf("  expand_one: scan %llu reduce+filter %llu broadcast %llu combos %llu; calls %llu, with all four lists %llu; queries that missed the memo %llu of %llu\n", ek[0], ek[1], ek[2], ek[3], ek[5], ek[6], ek[7], 4 * ek[5]);
 #endif
     if (tid == 0) {
