@@ -185,6 +185,37 @@ def test_boards_larger_than_the_kernels_lists(pair, oracle):
     assert back <= 1 and counts.min() >= 55, (back, counts)
 
 
+def test_several_detectors_in_threads(pair):
+    """The reference's detect(&self) may be called from any number of threads; here that is a handle per thread.
+    Three threads, a detector each, the device tail's kernels side by side on the GPU: every call gives the host tail's tags."""
+    import threading
+    import aprilgrid_rs_amd as A
+    host, _ = pair
+    synth = synth_module()
+    fr, _ = synth.render_batch(700, 96, 640, 480, device="cuda")
+    frames = fr.cpu().numpy()
+    rc0, out0, cnt0, st0 = host.detect_batch_raw(frames, n_threads=4, cap=64)
+    bad = {}
+
+    def work(k):
+        d = A.TagDetector("t36h11", None, device=0)
+        d.set_option("device_tail", 1)
+        n_bad = 0
+        for _ in range(4):
+            rc, out, cnt, st = d.detect_batch_raw(frames, n_threads=2, cap=64)
+            ok = rc == rc0 and np.array_equal(cnt, cnt0) and all(out[f, : cnt[f]].tobytes() == out0[f, : cnt0[f]].tobytes() for f in range(len(frames)))
+            n_bad += not ok
+        bad[k] = n_bad
+        d.close()
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert bad == {0: 0, 1: 0, 2: 0}, bad
+
+
 def test_left_to_itself_a_call_chooses_by_its_size():
     """Option -1 (the default): the device tail's launch costs its slowest frame (2 .. 5 ms) whatever the batch, the host tail ~0.9 ms
     per frame and thread -- a call of fewer than six frames per host thread keeps the host tail, a larger one takes the device's."""
