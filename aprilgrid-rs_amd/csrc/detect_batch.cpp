@@ -294,26 +294,27 @@ static int detect_batch_device_tail(agx_detector *det, const void *frames, const
     std::deque<std::vector<agx_saddle>> handed_back;  // saddle lists of frames for the host tail (alive until the pool is drained)
     int rc = AGX_OK, n_fallback = 0, n_uncertain = 0;
     bool pending_batch = false;
-    // A chunk goes up in S parts on S workers at once (a copy from pageable memory is staged by the calling thread: one thread
-    // does not fill the link on every host), the chunks one after the other (three large chunks side by side would share the
-    // link, and the first -- the one the device waits for -- would arrive with the third): a part starts when fewer than S
-    // parts with smaller numbers are unfinished.
+    // A chunk goes up in P parts on P workers at once (a copy from pageable memory is staged by the calling thread at 10 .. 15 GB/s:
+    // it takes four to six of them to fill the link), the chunks one after the other (three large chunks side by side would
+    // share the link, and the first -- the one the device waits for -- would arrive with the third): a part starts when fewer
+    // than P parts with smaller numbers are unfinished.  Parts share the S upload streams (the streams only order the copies).
+    const int P = std::max(1, std::min(6, pool->size()));
     int parts_done = 0;                 // (guarded by m)
     std::vector<int> parts_left;        // per chunk                                   (guarded by m)
     std::vector<char> chunk_failed;     //                                             (guarded by m)
-    auto upload_part = [&, device](int ci, int part) {
+    auto upload_part = [&, device, P](int ci, int part) {
         const int c0 = ci * chunk, nf = std::min(chunk, n_frames - c0), slot = ci % S;
-        const int f0 = (int)((long long)nf * part / S), f1 = (int)((long long)nf * (part + 1) / S);
+        const int f0 = (int)((long long)nf * part / P), f1 = (int)((long long)nf * (part + 1) / P);
         {
             std::unique_lock<std::mutex> lk(m);
-            cv.wait(lk, [&] { return ci * S + part - parts_done < S; });
+            cv.wait(lk, [&] { return ci * P + part - parts_done < P; });
         }
         const bool ok = f1 <= f0 ||
                         (hipSetDevice(device) == hipSuccess &&
                          hipMemcpyAsync(d_stage + (size_t)slot * chunk_bytes + (size_t)f0 * frame_stride_bytes,
                                         (const uint8_t *)frames + (size_t)(c0 + f0) * frame_stride_bytes, (size_t)(f1 - f0) * frame_stride_bytes,
-                                        hipMemcpyHostToDevice, up[part]) == hipSuccess &&
-                         hipStreamSynchronize(up[part]) == hipSuccess);
+                                        hipMemcpyHostToDevice, up[part % S]) == hipSuccess &&
+                         hipStreamSynchronize(up[part % S]) == hipSuccess);
         {
             std::lock_guard<std::mutex> lk(m);
             ++parts_done;
@@ -322,13 +323,13 @@ static int detect_batch_device_tail(agx_detector *det, const void *frames, const
         }
         cv.notify_all();
     };
-    auto upload_task = [&](int ci) {  // (queue order = start order: the parts of a chunk side by side)
-        for (int part = 1; part < S; ++part) pool->submit_front([&upload_part, ci, part] { upload_part(ci, part); });
+    auto upload_task = [&, P](int ci) {  // (queue order = start order: the parts of a chunk side by side)
+        for (int part = 1; part < P; ++part) pool->submit_front([&upload_part, ci, part] { upload_part(ci, part); });
         upload_part(ci, 0);
     };
     try {
     uploaded.assign((size_t)n_chunks, 0);
-    parts_left.assign((size_t)n_chunks, S);
+    parts_left.assign((size_t)n_chunks, P);
     chunk_failed.assign((size_t)n_chunks, 0);
     if (!d_frames)
         for (int ci = 0; ci < std::min(S, n_chunks); ++ci) pool->submit([&upload_task, ci] { upload_task(ci); });
