@@ -185,6 +185,20 @@ def test_boards_larger_than_the_kernels_lists(pair, oracle):
     assert back <= 1 and counts.min() >= 55, (back, counts)
 
 
+@pytest.mark.parametrize("w,h", [(2, 2), (17, 5), (64, 48), (1280, 64), (192, 128), (333, 217)])
+def test_odd_and_tiny_geometries(pair, w, h):
+    """Frames with no, few or many saddles in sizes that are nobody's default (odd widths take the blur kernel's unaligned form):
+    checkerboards and noise (saddles without tags), small boards."""
+    host, dev = pair
+    synth = synth_module()
+    if w >= 192 and h >= 128:
+        frames = synth.render_batch(900, 48, w, h, device="cuda")[0].cpu().numpy()
+    else:
+        frames = np.random.default_rng(w * 1000 + h).integers(0, 256, (48, h, w), dtype=np.uint8)
+        frames[::2] = (np.indices((h, w)).sum(0) // 4 % 2 * 200 + 20).astype(np.uint8)
+    same_results(host, dev, frames, cap=64)
+
+
 def test_several_detectors_in_threads(pair):
     """The reference's detect(&self) may be called from any number of threads; here that is a handle per thread.
     Three threads, a detector each, the device tail's kernels side by side on the GPU: every call gives the host tail's tags."""
