@@ -77,6 +77,7 @@ SYMBOLS = {
     "agx_debug_angle_pairs": (C.c_int, [_P, C.c_size_t, _P, _P, _P]),
     "agx_debug_angle_pairs_coarse": (C.c_int, [_P, C.c_size_t, _P, _P]),
     "agx_debug_libm_atan2f_check": (C.c_int, [C.c_uint64, C.c_uint64, _P]),
+    "agx_debug_white_block_angles": (C.c_int, [_P, C.c_size_t, _P, _P]),
     "agx_profile_enable": (C.c_int, [_P, C.c_int]),
     "agx_profile_reset": (C.c_int, [_P]),
     "agx_profile_read": (C.c_int, [_P, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),

@@ -1242,6 +1242,15 @@ int agx_debug_angle_pairs_coarse(const float *vectors, size_t n, float *coarse, 
     });
 }
 
+int agx_debug_white_block_angles(const float *triples, size_t n, float *reference, double *binary64)
+{
+    return agx_guard(nullptr, [&]() -> int {
+    if (!triples || !reference || !binary64) return AGX_ERR_ARG;
+    debug_white_block_angles(triples, n, reference, binary64);
+    return AGX_OK;
+    });
+}
+
 int agx_debug_libm_atan2f_check(uint64_t n, uint64_t seed, uint64_t *mismatches)
 {
     return agx_guard(nullptr, [&]() -> int {

@@ -278,6 +278,21 @@ uint64_t libm_atan2f_mismatches(uint64_t n, uint64_t seed)
     return bad;
 }
 
+// The white-block angle (saddle.rs:26-38) of n (theta, v02x, v02y) triples as the reference evaluates it (binary32, this process's
+// cosf / sinf / atan2f) and as the device tail's decisive evaluation does (binary64 from the binary32 theta, the kernel's own
+// conversion constant): the kernel decides from the latter only outside a band around 60 / 120 that must exceed their difference.
+void debug_white_block_angles(const float *t, size_t n, float *reference, double *binary64)
+{
+    const double deg = 180.0 / (double)kPi;
+    for (size_t i = 0; i < n; ++i) {
+        const float theta = t[3 * i], v02x = t[3 * i + 1], v02y = t[3 * i + 2];
+        const float th = theta / 180.0f * kPi;
+        reference[i] = std::fabs(angle_degree(v02x, v02y, std::cos(th), std::sin(th)));
+        const double sd = std::sin((double)th), cd = std::cos((double)th);
+        binary64[i] = std::fabs(std::atan2(sd * (double)v02x - cd * (double)v02y, (double)v02x * cd + (double)v02y * sd)) * deg;
+    }
+}
+
 void debug_angle_pairs(const float *v, size_t n, float *exact, float *approx, uint8_t *has_approx, float *coarse, uint8_t *has_coarse)
 {
     for (size_t i = 0; i < n; ++i) {

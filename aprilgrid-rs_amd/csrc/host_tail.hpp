@@ -33,6 +33,8 @@ void debug_angle_pairs(const float *v, size_t n, float *exact, float *approx, ui
 // this process's atan2f against libm_f32.h's restatement of glibc's routine on n pseudo-random operand pairs + the special
 // cases: the number of disagreements (the device tail is offered only where it is 0)
 uint64_t libm_atan2f_mismatches(uint64_t n, uint64_t seed);
+// test hook: the white-block angle as the reference evaluates it and as the device tail's binary64 evaluation does (t = n x (theta, v02x, v02y))
+void debug_white_block_angles(const float *t, size_t n, float *reference, double *binary64);
 // saddle.rs:17-67
 bool is_valid_quad(const agx_saddle &s0, const agx_saddle &d0, const agx_saddle &s1, const agx_saddle &d1);
 

@@ -378,6 +378,11 @@ int agx_debug_angle_pairs_coarse(const float *vectors, size_t n, float *coarse, 
  * floats, cross / dot products of image-sized vectors, ratios at the ends of the routine's reduction intervals, plus the
  * special cases) this process's atan2f disagrees with the restatement; the option is refused unless that is 0. */
 int agx_debug_libm_atan2f_check(uint64_t n, uint64_t seed, uint64_t *mismatches);
+/* The one test of is_valid_quad the device tail cannot restate bit for bit is "filter white block" (saddle.rs:26-38: cosf, sinf):
+ * for n triples (s0.theta, v02.x, v02.y) the angle as the reference evaluates it (binary32, this process's libm) and as the
+ * kernel's decisive evaluation does (binary64).  The kernel decides 60 <= angle <= 120 from the latter only when it is farther
+ * than 1e-4 degrees from both thresholds; the CPU suite checks that the two never differ by more than half of that. */
+int agx_debug_white_block_angles(const float *triples, size_t n, float *reference, double *binary64);
 int agx_debug_fetch(agx_detector *det, int frame, int what, void *host_out, size_t cap_bytes,
                     size_t *n_items);
 

@@ -496,3 +496,31 @@ def test_this_libm_atan2f_is_the_routine_the_device_tail_restates():
         assert lib.agx_debug_libm_atan2f_check(1 << 24, seed, C.byref(bad)) == 0
         assert bad.value == 0, (seed, bad.value)
     assert lib.agx_debug_libm_atan2f_check(16, 1, None) != 0  # (null output: an argument error, not a crash)
+
+
+def test_the_device_tails_white_block_band_covers_the_references_roundings():
+    """The device tail decides the white-block test (saddle.rs:26-38) from a binary64 evaluation when the angle is farther than
+    1e-4 degrees (kBandAbs, csrc/tail_kernels.hip) from 60 and 120.  That is sound if the reference's own binary32 value -- cosf,
+    sinf, six roundings, atan2f, the conversion to degrees -- is never that far from the binary64 one: on ten million random
+    (theta, vector) triples, and on vectors whose angle sits at the thresholds, the two differ by less than 5e-5 degrees."""
+    import numpy as np
+    from aprilgrid_rs_amd import _ffi
+    lib = _ffi.lib()
+    rng = np.random.default_rng(11)
+    worst = 0.0
+    for part in range(10):
+        n = 1_000_000
+        t = np.empty((n, 3), np.float32)
+        t[:, 0] = rng.uniform(-90.0, 90.0, n)
+        r = np.exp(rng.uniform(np.log(2.0), np.log(2000.0), n))
+        if part % 2:  # directions at the thresholds: theta + 60 / + 120 degrees (both signs), jittered by up to a millidegree
+            a = np.deg2rad(t[:, 0].astype(np.float64) + rng.choice([60.0, 120.0, -60.0, -120.0], n) + rng.uniform(-1e-3, 1e-3, n))
+        else:
+            a = rng.uniform(-np.pi, np.pi, n)
+        t[:, 1] = (r * np.cos(a)).astype(np.float32)
+        t[:, 2] = (r * np.sin(a)).astype(np.float32)
+        ref = np.empty(n, np.float32)
+        f64 = np.empty(n, np.float64)
+        assert lib.agx_debug_white_block_angles(t.ctypes.data, n, ref.ctypes.data, f64.ctypes.data) == 0
+        worst = max(worst, float(np.max(np.abs(ref.astype(np.float64) - f64))))
+    assert worst < 5e-5, worst
