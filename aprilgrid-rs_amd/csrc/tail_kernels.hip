@@ -526,7 +526,7 @@ __device__ int build_board_w(const Ctx &c, uint8_t *slot, u64 seed, int lane, in
 // ---- decode (detector.rs:42-169, 448-476; image_util.rs:39-70) -----------------------------------------------------
 
 // decode_positions + bit_code (detector.rs:42-122) of one quad: false = None
-__device__ bool quad_bits(const TailArgs &a, const uint8_t *luma, const float q[8], u64 &bits_out)
+__device__ bool quad_bits(const TailArgs &a, const uint8_t *luma, const float q[8], uint8_t *stage /* 36 bytes of this lane's */, u64 &bits_out)
 {
     const uint32_t w = (uint32_t)a.W, h = (uint32_t)a.H;
     for (int i = 0; i < 4; ++i) {
@@ -556,38 +556,35 @@ __device__ bool quad_bits(const TailArgs &a, const uint8_t *luma, const float q[
             aff[3 * axis + 2] = (float)(mean / 4.0 - hu * cc - hv * cc);
         }
     }
-    const int nb = a.edge * a.edge;
-    u64 samples_lo = 0;  // sample values are compared twice: keep them (8 bits each would need 36 bytes) -- second pass re-reads
-    (void)samples_lo;
+    // the samples in the reference's order (x outer, y inner), kept in the lane's bytes of LDS: the loads do not wait for one
+    // another (a sample outside the image ends the reference's loop with None: here it is remembered and the loop runs on over
+    // clamped coordinates)
+    const int nb = a.edge * a.edge, edge = a.edge, border = a.border, pitch = a.luma_row_stride;
     int lo = 255, hi = 0;
-    for (int gx = a.border; gx < a.border + a.edge; ++gx)
-        for (int gy = a.border; gy < a.border + a.edge; ++gy) {
-            const float fx = (float)gx, fy = (float)gy;
-            const float px = aff[0] * fx + aff[1] * fy + aff[2] * 1.0f;
-            const float py = aff[3] * fx + aff[4] * fy + aff[5] * 1.0f;
-            const uint32_t ix = f32_as_u32(round_half_away(px)), iy = f32_as_u32(round_half_away(py));
-            if (ix >= w || iy >= h) return false;
-            const int b = luma[(size_t)iy * (size_t)a.luma_row_stride + ix];
-            lo = b < lo ? b : lo;
-            hi = b > hi ? b : hi;
-        }
-    if (hi - lo < 50) return false;
+    bool outside = false;
+#pragma unroll 4
+    for (int n = 0; n < nb; ++n) {
+        const float fx = (float)(border + n / edge), fy = (float)(border + n % edge);
+        const float px = aff[0] * fx + aff[1] * fy + aff[2] * 1.0f;
+        const float py = aff[3] * fx + aff[4] * fy + aff[5] * 1.0f;
+        uint32_t ix = f32_as_u32(round_half_away(px)), iy = f32_as_u32(round_half_away(py));
+        outside = outside || ix >= w || iy >= h;
+        ix = ix < w ? ix : w - 1;
+        iy = iy < h ? iy : h - 1;
+        const int b = luma[(size_t)iy * (size_t)pitch + ix];
+        stage[n] = (uint8_t)b;
+        lo = b < lo ? b : lo;
+        hi = b > hi ? b : hi;
+    }
+    if (outside || hi - lo < 50) return false;
     const int mid = (int)(uint8_t)f32_as_u32(round_half_away(((float)lo + (float)hi) / 2.0f));
     u64 bits = 0;
     uint32_t invalid = 0;
-    {
-        int n = 0;  // sample number in the reference's order; the first sample is the most significant bit
-        for (int gx = a.border; gx < a.border + a.edge; ++gx)
-            for (int gy = a.border; gy < a.border + a.edge; ++gy, ++n) {
-                const float fx = (float)gx, fy = (float)gy;
-                const float px = aff[0] * fx + aff[1] * fy + aff[2] * 1.0f;
-                const float py = aff[3] * fx + aff[4] * fy + aff[5] * 1.0f;
-                const uint32_t ix = f32_as_u32(round_half_away(px)), iy = f32_as_u32(round_half_away(py));
-                const int b = luma[(size_t)iy * (size_t)a.luma_row_stride + ix];
-                const int d = mid - b;
-                if ((d < 0 ? -d : d) < 10) ++invalid;
-                if (b > mid) bits |= 1ull << (nb - 1 - n);
-            }
+    for (int n = 0; n < nb; ++n) {  // the first sample is the most significant bit
+        const int b = stage[n];
+        const int d = mid - b;
+        if ((d < 0 ? -d : d) < 10) ++invalid;
+        if (b > mid) bits |= 1ull << (nb - 1 - n);
     }
     if (invalid > 3) return false;
     bits_out = bits;
@@ -1108,7 +1105,7 @@ __global__ void __launch_bounds__(64 * TW) k_board_tail(TailArgs a)
                         qxy[2 * i + 1] = sy[q_at(q, i)];
                     }
                     u64 bits = 0;
-                    dec_id[qi] = quad_bits(a, luma, qxy, bits) ? -2 : -1;
+                    dec_id[qi] = quad_bits(a, luma, qxy, wv + WV_SLOT + 36 * lane, bits) ? -2 : -1;  // (the board's slot: its quads are in the list)
                     dec_bits[qi] = bits;
                 }
             }
