@@ -289,6 +289,11 @@ __device__ __forceinline__ uint32_t row_min_u(uint32_t v)
     t = dpp_u<0x140>(v);          // row_mirror
     return t < v ? t : v;
 }
+__device__ __forceinline__ u64 shfl_xor_u64(u64 v, int mask)
+{
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, mask), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), mask);
+    return (u64)hi << 32 | lo;
+}
 __device__ __forceinline__ u64 shfl_u64(u64 v, int src)
 {
     const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src), hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), src);
@@ -661,12 +666,46 @@ __device__ int init_quads_w(const Ctx &c, uint8_t *wv, int s0, int lane, uint32_
     const float *sx = c.sx, *sy = c.sy, *st = c.st;
     const float s0x = sx[s0], s0y = sy[s0], s0t = st[s0];
     int nc = 0;
-    // 50 nearest: every distance key, sorted
+    // 50 nearest: the distance keys, sorted.  Of more than 128 saddles only those are sorted that can be among the 50: the 50th
+    // smallest of the 64 lanes' minima (each lane's own keys: every 64th saddle) is one of 64 keys of the set, so the set's 50th
+    // smallest is not above it -- usually 50 to 80 keys are left.
     int P = 64;
-    while (P < n) P <<= 1;
     u64 *keys = cand;
     wsync();  // (the previous seed's candidates are done with)
-    for (int i = lane; i < P; i += 64) keys[i] = i < n ? dist_key(s0x, s0y, sx[i], sy[i], (uint32_t)i) : ~0ull;
+    bool pruned = false;
+    if (n > 128) {
+        u64 v = ~0ull;
+        for (int i = lane; i < n; i += 64) {
+            const u64 k = dist_key(s0x, s0y, sx[i], sy[i], (uint32_t)i);
+            v = k < v ? k : v;
+        }
+        for (int k2 = 2; k2 <= 64; k2 <<= 1)  // the 64 minima sorted across the lanes (ascending with the lane)
+            for (int j = k2 >> 1; j > 0; j >>= 1) {
+                const u64 o = shfl_xor_u64(v, j);
+                const bool keep_min = ((lane & j) == 0) == ((lane & k2) == 0);
+                v = (o < v) == keep_min ? o : v;
+            }
+        const u64 bound = shfl_u64(v, 49);
+        int cnt = 0;
+        for (int base = 0; base < n; base += 64) {
+            const int i = base + lane;
+            const u64 k = i < n ? dist_key(s0x, s0y, sx[i], sy[i], (uint32_t)i) : ~0ull;
+            const bool keep = i < n && k <= bound;
+            const u64 mk = __ballot(keep);
+            const int at = cnt + __popcll(mk & below);
+            if (keep && at < 128) keys[at] = k;
+            cnt += __popcll(mk);
+        }
+        if (cnt <= 128) {
+            pruned = true;
+            P = cnt <= 64 ? 64 : 128;
+            for (int i = cnt + lane; i < P; i += 64) keys[i] = ~0ull;
+        }
+    }
+    if (!pruned) {
+        while (P < n) P <<= 1;
+        for (int i = lane; i < P; i += 64) keys[i] = i < n ? dist_key(s0x, s0y, sx[i], sy[i], (uint32_t)i) : ~0ull;
+    }
     wsync();
     for (int k = 2; k <= P; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
