@@ -352,7 +352,7 @@ __device__ bool expand_one_w(const Ctx &c, const uint8_t *slot, u64 qs, u64 &out
         const float v10x = bx - ax, v10y = by - ay;
         const float qx = c.sx[anchor] + v10x * ratio0, qy = c.sy[anchor] + v10y * ratio0;
         u64 k0 = ~0ull, k1 = ~0ull, k2 = ~0ull;
-        const float r = sqrtf(radius_sq) * 1.0001f + 1e-3f;
+        const float r = __builtin_amdgcn_sqrtf(radius_sq) * 1.0001f + 1e-3f;  // (only bounds the cells looked at: the hardware's square root, 1 ulp, and a margin)
         if (!(r < 3e38f)) {  // (not on image coordinates) everything
             for (int t = l; t < c.n; t += 16) top3_insert(dist_key(qx, qy, c.gx[t], c.gy[t], c.gi[t]), k0, k1, k2);
         } else {
