@@ -82,12 +82,12 @@ constexpr int OFF_QUADS = OFF_SEEDS + TN * 2;              // u64[BCELLS]
 constexpr int OFF_TAGIDS = OFF_QUADS + BCELLS * 8;         // u32[TTAGS]
 constexpr int OFF_USED = OFF_TAGIDS + TTAGS * 4;           // u32[TN / 32]
 constexpr int OFF_HIST = OFF_USED + TN / 8;                // u32[364]
-constexpr int OFF_SHARED = OFF_HIST + 364 * 4;             // u32[8 + 2 * TW]: what the waves tell each other
+constexpr int OFF_SHARED = OFF_HIST + 364 * 4;             // u32[8 + 6 * TW]: what the waves tell each other (the per-group words twice: groups alternate)
 // Boards grown from different seed quads ask the same questions again: what find_closest_potential_saddle_idxs finds for an
 // ordered pair of saddles before the board's own "still unused" test (a function of the pair), and is_valid_quad of four
 // saddles (a function of the four).  Both are kept per round in direct-mapped tables shared by the frame's waves -- an
 // entry is one aligned 64-bit word carrying its whole key, read and written atomically; a collision just overwrites.
-constexpr int OFF_MEMO_P = OFF_SHARED + (8 + 2 * TW) * 4;  // u64[TMEMO]: key (i0, i1, side) -> up to three candidates
+constexpr int OFF_MEMO_P = OFF_SHARED + (8 + 6 * TW) * 4;  // u64[TMEMO]: key (i0, i1, side) -> up to three candidates
 constexpr int OFF_MEMO_Q = OFF_MEMO_P + TMEMO * 8;         // u64[TMEMO]: key (four indices) -> is_valid_quad's 0 / 1 / 2
 constexpr int OFF_CODES = OFF_MEMO_Q + TMEMO * 8;          // u64[TCODES]: the family's code list (best_tag reads all of it per quad and rotation)
 constexpr int TCODES = 640;
@@ -829,7 +829,7 @@ __global__ void __launch_bounds__(64 * TW) k_board_tail(TailArgs a)
     uint32_t *tagids = reinterpret_cast<uint32_t *>(lds + OFF_TAGIDS);
     uint32_t *used = reinterpret_cast<uint32_t *>(lds + OFF_USED);
     uint32_t *hist = reinterpret_cast<uint32_t *>(lds + OFF_HIST);
-    uint32_t *sh = reinterpret_cast<uint32_t *>(lds + OFF_SHARED);  // [0] status, [1] n, [2] seeds, [3] saddles removed, [4] the boards handed out, [5 .. 7] where the chosen board is kept, [8 .. 8 + TW) candidates per wave, [8 + TW ..) the seeds' best boards
+    uint32_t *sh = reinterpret_cast<uint32_t *>(lds + OFF_SHARED);  // [0] status, [1] n, [2] seeds, [3] saddles removed, [5 .. 7] where the chosen board is kept, [8 ..) the groups' words (two sets)
     uint8_t *wv = lds + OFF_WAVES + wave * WV_BYTES;  // this wave's own
 
     uint32_t status = 0;  // per lane; merged through sh[0]
@@ -854,10 +854,8 @@ __global__ void __launch_bounds__(64 * TW) k_board_tail(TailArgs a)
         }
         return;
     }
-    if (tid == 0) {
-        sh[0] = 0;
-        sh[5] = sh[6] = sh[7] = 0;
-    }
+    if (tid < 8 + 6 * TW) sh[tid] = 0;
+    int group_no = 0;  // (counts the groups of seeds over all rounds)
     u64 *codes = reinterpret_cast<u64 *>(lds + OFF_CODES);
     for (int i = tid; i < a.n_codes && i < TCODES; i += 64 * TW) codes[i] = a.codes[i];
     if (a.n_codes > TCODES) status |= TAIL_CAPACITY;
@@ -974,7 +972,11 @@ __global__ void __launch_bounds__(64 * TW) k_board_tail(TailArgs a)
         u64 best_quad = 0;
         bool stop = false;
         // (the first seed alone: it usually finds the board and ends the loop -- its neighbours in the list would find it again)
-        for (int base = 0, gw = 1; base < total && !stop; base += gw, gw = TW) {
+        for (int base = 0, gw = 1; base < total && !stop; base += gw, gw = TW, ++group_no) {
+            // the group's words: [0 .. TW) a seed's list published (bit 31) with its length, [TW .. 2 TW) the seed's best board,
+            // [2 TW .. 3 TW) its candidates handed out.  Two sets, used alternately: a wave clears its words of the other set
+            // when it has built its last board of this group, behind the barrier at which that set was last read
+            uint32_t *gs = sh + 8 + 3 * TW * (group_no & 1), *gs_other = sh + 8 + 3 * TW * ((group_no & 1) ^ 1);
             const int k = base + wave;
             int nc_mine = 0;
             uint32_t kept_score = 0;  // (what this wave kept in earlier groups is either the chosen board, recorded in sh[5], or beaten)
@@ -984,26 +986,17 @@ __global__ void __launch_bounds__(64 * TW) k_board_tail(TailArgs a)
                 n_cands_total += nc_mine;
                 ++n_seeds_done;
             }
-            if (lane == 0) {
-                sh[8 + wave] = (uint32_t)nc_mine;
-                sh[8 + TW + wave] = 0;
-                if (wave == 0) sh[4] = 0;
-            }
-            __syncthreads();
-            int first_item[TW + 1];
-            first_item[0] = 0;
-#pragma unroll
-            for (int w = 0; w < TW; ++w) first_item[w + 1] = first_item[w] + (int)sh[8 + w];
+            // the list is complete: published with its length (bit 31).  No barrier: a wave takes boards of the seeds that are
+            // listed while others still list theirs -- seed by seed in the reference's order, candidates from a counter per seed
+            if (lane == 0) __hip_atomic_store(&gs[wave], (uint32_t)nc_mine | 0x80000000u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (int w = 0; w < TW; ++w) {
+                uint32_t pub;
+                while (!((pub = __hip_atomic_load(&gs[w], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) & 0x80000000u)) __builtin_amdgcn_s_sleep(2);
+                const int nc_w = (int)(pub & 0x7fffffffu);
             for (;;) {
-                int item = lane == 0 ? (int)atomicAdd(&sh[4], 1u) : 0;
-                item = __shfl(item, 0);
-                if (item >= first_item[TW]) break;
-                int w = 0;
-#pragma unroll
-                for (int t = 1; t < TW; ++t) w += item >= first_item[t];
-                int ci = item;
-#pragma unroll
-                for (int t = 1; t < TW; ++t) ci -= (item >= first_item[t]) ? (int)sh[8 + t - 1] : 0;
+                int ci = lane == 0 ? (int)atomicAdd(&gs[2 * TW + w], 1u) : 0;
+                ci = __shfl(ci, 0);
+                if (ci >= nc_w) break;
                 const u64 q = reinterpret_cast<const u64 *>(lds + OFF_WAVES + w * WV_BYTES + WV_CAND)[ci];
                 int cells;
                 AGX_TT(const unsigned long long tb0 = wall_clock64();)
@@ -1011,7 +1004,7 @@ __global__ void __launch_bounds__(64 * TW) k_board_tail(TailArgs a)
                 AGX_TT(tk[8] += wall_clock64() - tb0; tk[9] += (unsigned long long)cells;)
                 ++n_boards;
                 // the seed's best score and the FIRST candidate that reaches it (what the sequential loop is left with, :616-622)
-                if (lane == 0) atomicMax(&sh[8 + TW + w], score << 16 | (uint32_t)(0xffff - ci));
+                if (lane == 0) atomicMax(&gs[TW + w], score << 16 | (uint32_t)(0xffff - ci));
                 // The board the merge below may choose is kept (its cells), so that it need not be grown again for
                 // try_fix_missing: one that beats the best of the earlier groups and, in the merge's order (score, then seed,
                 // then candidate), everything this wave has kept in this group -- whatever the merge chooses is the best in that
@@ -1027,12 +1020,18 @@ __global__ void __launch_bounds__(64 * TW) k_board_tail(TailArgs a)
                     wsync();
                 }
             }
+            }
             status = wave_or_u(status);
-            if (lane == 0 && status) atomicOr(&sh[0], status);
+            if (lane == 0) {
+                if (status) atomicOr(&sh[0], status);
+                gs_other[wave] = 0;
+                gs_other[TW + wave] = 0;
+                gs_other[2 * TW + wave] = 0;
+            }
             __syncthreads();
             int win_w = -1, win_ci = 0;
             for (int w = 0; w < gw && base + w < total; ++w) {  // the reference's order
-                const uint32_t key = sh[8 + TW + w];
+                const uint32_t key = gs[TW + w];
                 if ((key >> 16) > best_score) {
                     best_score = key >> 16;
                     win_w = w;
