@@ -971,16 +971,17 @@ __global__ void __launch_bounds__(64 * TW) k_board_tail(TailArgs a)
         uint32_t best_score = 0, win_stamp = 0;
         u64 best_quad = 0;
         bool stop = false;
-        // (the first seed alone: it usually finds the board and ends the loop -- its neighbours in the list would find it again)
-        for (int base = 0, gw = 1; base < total && !stop; base += gw, gw = TW, ++group_no) {
+        // Seeds in groups of TW: every wave lists the candidate quads of one; then the boards.  The first group's boards in two
+        // steps -- the first seed alone (it usually finds the board and ends the loop: its neighbours in the list would find
+        // it again, fifty times the work), then the other seven, whose lists are there already.
+        for (int base = 0; base < total && !stop; base += TW, ++group_no) {
+            const int gw = total - base < TW ? total - base : TW;
             // the group's words: [0 .. TW) a seed's list published (bit 31) with its length, [TW .. 2 TW) the seed's best board,
             // [2 TW .. 3 TW) its candidates handed out.  Two sets, used alternately: a wave clears its words of the other set
             // when it has built its last board of this group, behind the barrier at which that set was last read
             uint32_t *gs = sh + 8 + 3 * TW * (group_no & 1), *gs_other = sh + 8 + 3 * TW * ((group_no & 1) ^ 1);
             const int k = base + wave;
             int nc_mine = 0;
-            uint32_t kept_score = 0;  // (what this wave kept in earlier groups is either the chosen board, recorded in sh[5], or beaten)
-            int kept_w = 0, kept_ci = 0, kept_cells = 0;
             if (wave < gw && k < total) {
                 nc_mine = init_quads_w(c, wv, seeds[n_seeds - 1 - k], lane, status, tk);
                 n_cands_total += nc_mine;
@@ -989,7 +990,12 @@ __global__ void __launch_bounds__(64 * TW) k_board_tail(TailArgs a)
             // the list is complete: published with its length (bit 31).  No barrier: a wave takes boards of the seeds that are
             // listed while others still list theirs -- seed by seed in the reference's order, candidates from a counter per seed
             if (lane == 0) __hip_atomic_store(&gs[wave], (uint32_t)nc_mine | 0x80000000u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            for (int w = 0; w < TW; ++w) {
+            const int n_steps = (base == 0 && gw > 1) ? 2 : 1;
+            for (int step = 0; step < n_steps && !stop; ++step) {
+            const int w_from = (base == 0 && step == 1) ? 1 : 0, w_to = (base == 0 && step == 0) ? 1 : gw;
+            uint32_t kept_score = 0;  // (what this wave kept in earlier steps is either the chosen board, recorded in sh[5], or beaten)
+            int kept_w = 0, kept_ci = 0, kept_cells = 0;
+            for (int w = w_from; w < w_to; ++w) {
                 uint32_t pub;
                 while (!((pub = __hip_atomic_load(&gs[w], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) & 0x80000000u)) __builtin_amdgcn_s_sleep(2);
                 const int nc_w = (int)(pub & 0x7fffffffu);
@@ -1030,7 +1036,7 @@ __global__ void __launch_bounds__(64 * TW) k_board_tail(TailArgs a)
             }
             __syncthreads();
             int win_w = -1, win_ci = 0;
-            for (int w = 0; w < gw && base + w < total; ++w) {  // the reference's order
+            for (int w = w_from; w < w_to; ++w) {  // the reference's order
                 const uint32_t key = gs[TW + w];
                 if ((key >> 16) > best_score) {
                     best_score = key >> 16;
@@ -1046,7 +1052,7 @@ __global__ void __launch_bounds__(64 * TW) k_board_tail(TailArgs a)
             if (sh[0]) stop = true;  // the frame goes to the host anyway
             // where the chosen board's cells are kept: sh[5] = the wave + 1 (0: nowhere -- it is grown again), sh[6] = its cells
             if (win_w >= 0) {  // (every thread alike) the group that chose: round and first seed
-                win_stamp = ((uint32_t)round + 1u) << 8 | (uint32_t)(base + 1);
+                win_stamp = ((uint32_t)round + 1u) << 8 | (uint32_t)(base + w_from + 1);
                 if (lane == 0 && kept_score == best_score && kept_w == win_w && kept_ci == win_ci) {
                     sh[5] = (uint32_t)wave + 1u;
                     sh[6] = (uint32_t)kept_cells;
@@ -1054,6 +1060,7 @@ __global__ void __launch_bounds__(64 * TW) k_board_tail(TailArgs a)
                 }
             }
             __syncthreads();
+            }
         }
         TK(5);
         if (sh[0] || best_score == 0) break;  // (None: the remaining rounds would find nothing either)
