@@ -182,6 +182,31 @@ __device__ __forceinline__ float angle_degree(float v0x, float v0y, float v1x, f
     return fdlibm_atan2f(v1y * v0x - v1x * v0y, v0x * v1x + v0y * v1y) * 180.0f / kPiF;
 }
 
+// angle_degree within 0.04 degrees: the host tail's first level (host_tail.cpp, LazyAngle::set -- the same binary32 operations, so the
+// bound its tests establish holds here: tests/test_abi_cpu.py), NaN where only the exact expression will do (zero / non-finite
+// operands, the sign-of-zero cases).  The comparisons below decide from it when they are farther than kCoarseBand per angle from
+// their threshold -- nearly always -- and evaluate angle_degree itself otherwise: the decisions are the exact expression's.
+constexpr float kCoarseBand = 0.1f;
+__device__ __forceinline__ float angle_coarse(float v0x, float v0y, float v1x, float v1y)
+{
+    const float yf = v1y * v0x - v1x * v0y, xf = v0x * v1x + v0y * v1y;
+    const float ya = fabsf(yf), xa = fabsf(xf);
+    const float mx = xa > ya ? xa : ya, mn = xa > ya ? ya : xa;
+    if (!(mx > 0.0f && mx < 3.0e38f && yf != 0.0f)) return __builtin_nanf("");
+    const float z = mn / mx, z2 = z * z;
+    float a = z * (0.9953585f + z2 * (-0.2886936f + z2 * 0.07934251f));
+    if (ya > xa) a = 1.5707964f - a;
+    if (xf < 0.0f) a = 3.1415927f - a;
+    if (yf < 0.0f) a = -a;
+    return a * 57.29578f;
+}
+// fabsf(p - q) > 10 (saddle.rs:59-61) from the coarse values: 1 yes, 0 no, -1 the exact angles must say (also for a NaN marker)
+__device__ __forceinline__ int differ10_coarse(float pc, float qc)
+{
+    const float d = fabsf(pc - qc);
+    return d > 10.0f + 2.0f * kCoarseBand ? 1 : (d < 10.0f - 2.0f * kCoarseBand ? 0 : -1);
+}
+
 // saddle.rs:26-38 "filter white block" for (s0, s1): 1 passes, 0 fails, 2 too close to a threshold to say here.
 // Nearly every angle is degrees away from 60 and 120: those are decided from the reference's expression evaluated with
 // this device's sincosf (<= 4 ulp, the OpenCL bound: the angle within 2e-4 degrees of the reference's -- the argument of
@@ -195,6 +220,11 @@ __device__ __forceinline__ int white_block(float s0_theta, float v02x, float v02
     {
         float sf, cf;
         sincosf(th, &sf, &cf);
+        {  // degrees away from both thresholds: from the coarse angle (this device's sincosf adds 2e-5 degrees to its 0.04)
+            const float ac = fabsf(angle_coarse(v02x, v02y, cf, sf));
+            if (ac < 60.0f - kCoarseBand || ac > 120.0f + kCoarseBand) return 0;
+            if (ac > 60.0f + kCoarseBand && ac < 120.0f - kCoarseBand) return 1;
+        }
         const float yf = sf * v02x - cf * v02y, xf = v02x * cf + v02y * sf;
         const float af = fabsf(fdlibm_atan2f(yf, xf) * 180.0f / kPiF);
         if (af < 60.0f - 1e-3f || af > 120.0f + 1e-3f) return 0;
@@ -225,10 +255,14 @@ __device__ bool quad_rest(const Ctx &c, int i0, int i1, int i2, int i3)
     if (cross2(v01x, v01y, v12x, v12y) * cross2(v12x, v12y, v23x, v23y) < 0.0f) return false;  // :51-53
     if (dot2(v01x, v01y, v02x, v02y) < 0.0f || dot2(v03x, v03y, v02x, v02y) < 0.0f) return false;  // :62-64
     const float v30x = s0x - d1x, v30y = s0y - d1y;
-    const float a0 = angle_degree(v01x, v01y, v12x, v12y), a2 = angle_degree(v23x, v23y, v30x, v30y);  // :55-61
-    if (fabsf(a0 - a2) > 10.0f) return false;
-    const float a1 = angle_degree(v12x, v12y, v23x, v23y), a3 = angle_degree(v30x, v30y, v01x, v01y);
-    if (fabsf(a1 - a3) > 10.0f) return false;
+    {  // :55-61, a0 against a2
+        const int r = differ10_coarse(angle_coarse(v01x, v01y, v12x, v12y), angle_coarse(v23x, v23y, v30x, v30y));
+        if (r > 0 || (r < 0 && fabsf(angle_degree(v01x, v01y, v12x, v12y) - angle_degree(v23x, v23y, v30x, v30y)) > 10.0f)) return false;
+    }
+    {  // a1 against a3
+        const int r = differ10_coarse(angle_coarse(v12x, v12y, v23x, v23y), angle_coarse(v30x, v30y, v01x, v01y));
+        if (r > 0 || (r < 0 && fabsf(angle_degree(v12x, v12y, v23x, v23y) - angle_degree(v30x, v30y, v01x, v01y)) > 10.0f)) return false;
+    }
     return true;
 }
 // is_valid_quad: 1 valid, 0 not, 2 everything but the white-block test passes and that one is undecided here
@@ -748,10 +782,10 @@ __device__ int init_quads_w(const Ctx &c, uint8_t *wv, int s0, int lane, uint32_
         // the white-block test depends on (s0, s1) only: once per s1 (0 fails, 1 passes, 2 undecided here)
         if (lane < ns) s1ok[lane] = (uint16_t)white_block(s0t, sx[same[lane]] - s0x, sy[same[lane]] - s0y);
         wsync();
-        // a3 = angle(v30, v01) (saddle.rs:59) depends on (d0, d1) only: once per pair
+        // a3 = angle(v30, v01) (saddle.rs:59) depends on (d0, d1) only: once per pair (its coarse value; the exact one on demand)
         for (int p = lane; p < n_pairs && p < TA3; p += 64) {
             const int d0 = diff[pairs[p] & 0xff], d1 = diff[pairs[p] >> 8];
-            a3tab[p] = angle_degree(s0x - sx[d1], s0y - sy[d1], sx[d0] - s0x, sy[d0] - s0y);
+            a3tab[p] = angle_coarse(s0x - sx[d1], s0y - sy[d1], sx[d0] - s0x, sy[d0] - s0y);
         }
     }
     wsync();
@@ -767,8 +801,8 @@ __device__ int init_quads_w(const Ctx &c, uint8_t *wv, int s0, int lane, uint32_
             wsync();
             if (lane < nd) {
                 const float dx = sx[diff[lane]], dy = sy[diff[lane]];
-                a0s[lane] = angle_degree(dx - s0x, dy - s0y, s1x - dx, s1y - dy);
-                a2s[lane] = angle_degree(dx - s1x, dy - s1y, s0x - dx, s0y - dy);
+                a0s[lane] = angle_coarse(dx - s0x, dy - s0y, s1x - dx, s1y - dy);
+                a2s[lane] = angle_coarse(dx - s1x, dy - s1y, s0x - dx, s0y - dy);
             }
             wsync();
             for (int base = 0; base < n_pairs; base += 64) {
@@ -785,12 +819,15 @@ __device__ int init_quads_w(const Ctx &c, uint8_t *wv, int s0, int lane, uint32_
                         const float v12x = s1x - d0x, v12y = s1y - d0y, v23x = d1x - s1x, v23y = d1y - s1y;
                         ok = !(cross2(v01x, v01y, v02x, v02y) * cross2(v02x, v02y, v03x, v03y) < 0.0f) &&
                              !(cross2(v01x, v01y, v12x, v12y) * cross2(v12x, v12y, v23x, v23y) < 0.0f) &&
-                             !(dot2(v01x, v01y, v02x, v02y) < 0.0f || dot2(v03x, v03y, v02x, v02y) < 0.0f) &&
-                             !(fabsf(a0s[pa] - a2s[pb]) > 10.0f);
-                        if (ok) {
-                            const float a1 = angle_degree(v12x, v12y, v23x, v23y);
-                            const float a3 = p < TA3 ? a3tab[p] : angle_degree(s0x - d1x, s0y - d1y, v01x, v01y);
-                            ok = !(fabsf(a1 - a3) > 10.0f);
+                             !(dot2(v01x, v01y, v02x, v02y) < 0.0f || dot2(v03x, v03y, v02x, v02y) < 0.0f);
+                        if (ok) {  // a0 against a2 (:55-61): the tables' coarse values, the exact angles where those are too close to say
+                            const float v30x = s0x - d1x, v30y = s0y - d1y;
+                            int r = differ10_coarse(a0s[pa], a2s[pb]);
+                            ok = !(r > 0 || (r < 0 && fabsf(angle_degree(v01x, v01y, v12x, v12y) - angle_degree(v23x, v23y, v30x, v30y)) > 10.0f));
+                            if (ok) {  // a1 against a3
+                                r = differ10_coarse(angle_coarse(v12x, v12y, v23x, v23y), p < TA3 ? a3tab[p] : angle_coarse(v30x, v30y, v01x, v01y));
+                                ok = !(r > 0 || (r < 0 && fabsf(angle_degree(v12x, v12y, v23x, v23y) - angle_degree(v30x, v30y, v01x, v01y)) > 10.0f));
+                            }
                         }
                     }
                     if (ok && wb == 2) {  // a quad hangs on the undecided test
