@@ -351,10 +351,6 @@ __device__ __forceinline__ bool slot_active(const uint8_t *slot, int i)
 {
     return (reinterpret_cast<const uint32_t *>(slot + SL_ACTIVE)[i >> 5] >> (i & 31)) & 1u;
 }
-__device__ __forceinline__ void slot_use(uint8_t *slot, int i)
-{
-    reinterpret_cast<uint32_t *>(slot + SL_ACTIVE)[i >> 5] &= ~(1u << (i & 31));
-}
 __device__ __forceinline__ int q_at(u64 q, int j) { return (int)((q >> (16 * j)) & 0xffffull); }
 __device__ __forceinline__ u64 q_make(int a, int b, int c, int d) { return (u64)a | (u64)b << 16 | (u64)c << 32 | (u64)d << 48; }
 
@@ -485,13 +481,20 @@ __device__ int build_board_w(const Ctx &c, uint8_t *slot, u64 seed, int lane, in
     {
         uint32_t *g = reinterpret_cast<uint32_t *>(slot + SL_GRID);
         for (int i = lane; i < (SL_ACTIVE - SL_GRID) / 4; i += 64) g[i] = 0xffffffffu;
-        if (lane < TN / 32) reinterpret_cast<uint32_t *>(slot + SL_ACTIVE)[lane] = 0xffffffffu;
+        if (lane < TN / 32) {  // active_idxs: everything but the seed quad's saddles 1 .. 3 (:35-37) -- a word per lane, no read-modify-write
+            uint32_t word = 0xffffffffu;
+#pragma unroll
+            for (int j = 1; j < 4; ++j) {
+                const int idx = q_at(seed, j);
+                if ((idx >> 5) == lane) word &= ~(1u << (idx & 31));
+            }
+            reinterpret_cast<uint32_t *>(slot + SL_ACTIVE)[lane] = word;
+        }
     }
     wsync();
     uint8_t *grid = slot + SL_GRID, *found = slot + SL_FOUND, *stack = slot + SL_STACK;
     int8_t *xy = reinterpret_cast<int8_t *>(slot + SL_XY);
     if (lane == 0) {
-        for (int j = 1; j < 4; ++j) slot_use(slot, q_at(seed, j));  // :35-37
         slot_set_quad(slot, 0, seed);
         xy[0] = 0;
         xy[1] = 0;
@@ -542,10 +545,13 @@ __device__ int build_board_w(const Ctx &c, uint8_t *slot, u64 seed, int lane, in
             found[at] = ok ? 1 : 0;
             slot_set_quad(slot, at, ok ? v : 0ull);
             if (ok) {
-                for (int j = 0; j < 4; ++j) slot_use(slot, q_at(v, j));
                 stack[2 * (sp - 1)] = (uint8_t)cur;  // where to come back to (depth <= found cells <= BCELLS)
                 stack[2 * (sp - 1) + 1] = (uint8_t)cur_i;
             }
+        }
+        if (ok && lane < 4) {  // the new cell's four saddles are used (:140-142): a lane each, an atomic each (two may share a word)
+            const int idx = q_at(v, lane);
+            atomicAnd(reinterpret_cast<uint32_t *>(slot + SL_ACTIVE) + (idx >> 5), ~(1u << (idx & 31)));
         }
         if (ok) {  // try_expand(&new_board_idx), :146
             ++score;
