@@ -499,12 +499,12 @@ static int detect_batch_impl(agx_detector *det, const void *frames, const void *
     const int max_boards = agx_internal_max_boards(det);
     if (hipSetDevice(agx_internal_device(det)) != hipSuccess) return AGX_ERR_HIP;
     const int device = agx_internal_device(det);
-    // The device tail costs a launch whose length is its slowest frame's (2 .. 5 ms) whatever the batch; the host tail costs
-    // ~0.9 ms per frame and thread.  Measured on 16 threads the two meet at ~100 frames (1: 1.0 / 2.2 ms, 16: 2.2 / 4.7,
-    // 64: 4.3 / 5.8, 96: 6.3 / 6.7, 128: 8.4 / 7.4, 256: 14.9 / 9.9): left to choose, a call of fewer than six frames per
-    // host thread keeps the host tail.
+    // The device tail costs a launch whose length is its slowest frame's (1.5 .. 3.5 ms) whatever the batch; the host tail costs
+    // ~0.9 ms per frame and thread.  Measured on 16 threads the two meet at ~60 frames (1: 1.0 / 1.7 ms, 16: 2.1 / 3.6,
+    // 48: 4.3 / 4.4, 64: 4.6 / 4.7, 96: 6.8 / 5.3, 128: 8.9 / 6.0, 256: 15.7 / 8.5): left to choose, a call of fewer than four
+    // frames per host thread keeps the host tail.
     const int tail_mode = agx_internal_device_tail(det);
-    if (tail_mode == 1 || (tail_mode == 2 && n_frames >= 6 * pool->size()))
+    if (tail_mode == 1 || (tail_mode == 2 && n_frames >= 4 * pool->size()))
         return detect_batch_device_tail(det, frames, d_frames, n_frames, width, height, row_stride_bytes, frame_stride_bytes, format, out,
                                         cap_per_frame, counts, frame_status, pool);
     agx_internal_tail_stats(det, 0, 0, 0);  // ("last_device_tail_frames" 0: this call's tails run on the host)

@@ -138,7 +138,7 @@ int agx_detector_set_limits(agx_detector *det, uint32_t max_candidates, uint32_t
  *                          latency of a single detect, at the price of host cores).  Default 1, like the
  *                          reference; agx_detect_batch parallelises over frames instead
  *   "device_tail"          agx_detect_batch's board search + decode (detector.rs:510-539) on the device, behind the chain
- *                          (csrc/tail_kernels.hip), instead of on the pool of host threads.  -1 (default): for calls of at least six
+ *                          (csrc/tail_kernels.hip), instead of on the pool of host threads.  -1 (default): for calls of at least four
  *                          frames per host thread (below that the host tail is the faster one), where this process's atan2f is
  *                          glibc's own routine -- the kernel evaluates angle_degree (math_util.rs:31-33) by that routine,
  *                          restated --, else off; 1: on for every call, AGX_ERR_STATE where libm differs; 0: off.

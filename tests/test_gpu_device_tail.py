@@ -232,17 +232,17 @@ def test_several_detectors_in_threads(pair):
 
 def test_left_to_itself_a_call_chooses_by_its_size():
     """Option -1 (the default): the device tail's launch costs its slowest frame (2 .. 5 ms) whatever the batch, the host tail ~0.9 ms
-    per frame and thread -- a call of fewer than six frames per host thread keeps the host tail, a larger one takes the device's."""
+    per frame and thread -- a call of fewer than four frames per host thread keeps the host tail, a larger one takes the device's."""
     import aprilgrid_rs_amd as A
     synth = synth_module()
     d = A.TagDetector("t36h11", None, device=0)
     fr, _ = synth.render_batch(300, 64, 320, 240, device="cuda")
     frames = fr.cpu().numpy()
-    small = d.detect_batch(frames[:20], n_threads=4)
+    small = d.detect_batch(frames[:12], n_threads=4)
     assert d.get_option("last_device_tail_frames") == 0
     large = d.detect_batch(frames, n_threads=4)
     assert d.get_option("last_device_tail_frames") == 64 and d.get_option("device_tail") == -1
-    for i in range(20):
+    for i in range(12):
         assert list(small[i]) == list(large[i]) and all(bits_equal(small[i][t], large[i][t]) for t in small[i])
     d.close()
 
