@@ -14,7 +14,7 @@ cp aprilgrid-rs_amd/libaprilgrid_amd.so /tmp/lib_keep.so
 for r in 1 2 3; do
   for v in "$A" "$B"; do
     cp "$v" aprilgrid-rs_amd/libaprilgrid_amd.so
-    echo "== $v"; $CMD 2>&1 | grep -E "ticks per frame|device tail|frames/s" | tail -2 | cut -c1-140
+    echo "== $v"; $CMD 2>&1 | grep -E "ticks per frame|device tail:" | tail -2 | cut -c1-140
   done
 done
 cp /tmp/lib_keep.so aprilgrid-rs_amd/libaprilgrid_amd.so
