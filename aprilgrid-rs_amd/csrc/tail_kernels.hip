@@ -571,12 +571,23 @@ __device__ int build_board_w(const Ctx &c, uint8_t *slot, u64 seed, int lane, in
 // ---- decode (detector.rs:42-169, 448-476; image_util.rs:39-70) -----------------------------------------------------
 
 // decode_positions + bit_code (detector.rs:42-122) of one quad: false = None
-__device__ bool quad_bits(const TailArgs &a, const uint8_t *luma, const float q[8], uint8_t *stage /* 36 bytes of this lane's */, u64 &bits_out)
+// reductions over the lane's EIGHT (half a row of 16), in every lane of the eight
+template <typename F>
+__device__ __forceinline__ uint32_t half_reduce_u(uint32_t v, F f)
+{
+    v = f(v, dpp_u<0xB1>(v));   // quad_perm [1, 0, 3, 2]
+    v = f(v, dpp_u<0x4E>(v));   // quad_perm [2, 3, 0, 1]
+    return f(v, dpp_u<0x141>(v));  // row_half_mirror
+}
+// decode_positions + bit_code (detector.rs:42-122) of one quad by EIGHT lanes (sub = 0 .. 7 takes every eighth sample of the up to 40:
+// the samples' loads side by side instead of one after the other): true + the bits in every lane of the eight; false = None
+__device__ bool quad_bits8(const TailArgs &a, const uint8_t *luma, const float q[8], int sub, u64 &bits_out)
 {
     const uint32_t w = (uint32_t)a.W, h = (uint32_t)a.H;
+    bool outside = false;
     for (int i = 0; i < 4; ++i) {
         const uint32_t x = f32_as_u32(round_half_away(q[2 * i])), y = f32_as_u32(round_half_away(q[2 * i + 1]));
-        if (x >= w || y >= h) return false;
+        outside = outside || x >= w || y >= h;
     }
     // tag_affine: least squares over the corners of an axis-aligned square, in binary64, rounded once (host_tail.cpp)
     float aff[6];
@@ -601,38 +612,46 @@ __device__ bool quad_bits(const TailArgs &a, const uint8_t *luma, const float q[
             aff[3 * axis + 2] = (float)(mean / 4.0 - hu * cc - hv * cc);
         }
     }
-    // the samples in the reference's order (x outer, y inner), kept in the lane's bytes of LDS: the loads do not wait for one
-    // another (a sample outside the image ends the reference's loop with None: here it is remembered and the loop runs on over
-    // clamped coordinates)
+    // the samples in the reference's order (x outer, y inner): number sub, sub + 8, ...  (a sample outside the image ends the
+    // reference's loop with None: here it is remembered and the coordinates are clamped)
     const int nb = a.edge * a.edge, edge = a.edge, border = a.border, pitch = a.luma_row_stride;
     int lo = 255, hi = 0;
-    bool outside = false;
-#pragma unroll 4
-    for (int n = 0; n < nb; ++n) {
-        const float fx = (float)(border + n / edge), fy = (float)(border + n % edge);
+    int vals[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const int n = sub + 8 * k;
+        const bool valid = n < nb;
+        const int nn = valid ? n : 0;
+        const float fx = (float)(border + nn / edge), fy = (float)(border + nn % edge);
         const float px = aff[0] * fx + aff[1] * fy + aff[2] * 1.0f;
         const float py = aff[3] * fx + aff[4] * fy + aff[5] * 1.0f;
         uint32_t ix = f32_as_u32(round_half_away(px)), iy = f32_as_u32(round_half_away(py));
-        outside = outside || ix >= w || iy >= h;
+        outside = outside || (valid && (ix >= w || iy >= h));
         ix = ix < w ? ix : w - 1;
         iy = iy < h ? iy : h - 1;
         const int b = luma[(size_t)iy * (size_t)pitch + ix];
-        stage[n] = (uint8_t)b;
-        lo = b < lo ? b : lo;
-        hi = b > hi ? b : hi;
+        vals[k] = valid ? b : -1;
+        lo = valid && b < lo ? b : lo;
+        hi = valid && b > hi ? b : hi;
     }
-    if (outside || hi - lo < 50) return false;
+    lo = (int)half_reduce_u((uint32_t)lo, [](uint32_t x, uint32_t y) { return x < y ? x : y; });
+    hi = (int)half_reduce_u((uint32_t)hi, [](uint32_t x, uint32_t y) { return x > y ? x : y; });
+    outside = half_reduce_u(outside ? 1u : 0u, [](uint32_t x, uint32_t y) { return x | y; }) != 0;
+    if (outside || hi - lo < 50) return false;  // (the eight alike)
     const int mid = (int)(uint8_t)f32_as_u32(round_half_away(((float)lo + (float)hi) / 2.0f));
     u64 bits = 0;
     uint32_t invalid = 0;
-    for (int n = 0; n < nb; ++n) {  // the first sample is the most significant bit
-        const int b = stage[n];
-        const int d = mid - b;
-        if ((d < 0 ? -d : d) < 10) ++invalid;
-        if (b > mid) bits |= 1ull << (nb - 1 - n);
-    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+        if (vals[k] >= 0) {  // the first sample is the most significant bit
+            const int b = vals[k], d = mid - b;
+            if ((d < 0 ? -d : d) < 10) ++invalid;
+            if (b > mid) bits |= 1ull << (nb - 1 - (sub + 8 * k));
+        }
+    invalid = half_reduce_u(invalid, [](uint32_t x, uint32_t y) { return x + y; });
     if (invalid > 3) return false;
-    bits_out = bits;
+    bits_out = (u64)half_reduce_u((uint32_t)(bits >> 32), [](uint32_t x, uint32_t y) { return x | y; }) << 32 |
+               half_reduce_u((uint32_t)bits, [](uint32_t x, uint32_t y) { return x | y; });
     return true;
 }
 
@@ -1182,18 +1201,20 @@ __global__ void __launch_bounds__(64 * TW) k_board_tail(TailArgs a)
             float *dec_xy = reinterpret_cast<float *>(wv + WV_CAND);           // [BCELLS][8]
             int *dec_id = reinterpret_cast<int *>(wv + WV_PAIRS + BCELLS * 8);    // [BCELLS]: tag id or -1
             u64 *dec_bits = reinterpret_cast<u64 *>(wv + WV_PAIRS);  // [BCELLS] (the pair list is dead)
-            for (int base = 0; base < n_quads; base += 64) {  // the sample bits: a quad per lane
-                const int qi = base + lane;
-                if (qi < n_quads) {
-                    const u64 q = quads[qi];
-                    float qxy[8];
+            for (int base = 0; base < n_quads; base += 8) {  // the sample bits: eight lanes per quad
+                const int qi = base + (lane >> 3);
+                const bool mine = qi < n_quads;
+                const u64 q = quads[mine ? qi : 0];
+                float qxy[8];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        qxy[2 * i] = sx[q_at(q, i)];
-                        qxy[2 * i + 1] = sy[q_at(q, i)];
-                    }
-                    u64 bits = 0;
-                    dec_id[qi] = quad_bits(a, luma, qxy, wv + WV_SLOT + 36 * lane, bits) ? -2 : -1;  // (the board's slot: its quads are in the list)
+                for (int i = 0; i < 4; ++i) {
+                    qxy[2 * i] = sx[q_at(q, i)];
+                    qxy[2 * i + 1] = sy[q_at(q, i)];
+                }
+                u64 bits = 0;
+                const bool have = quad_bits8(a, luma, qxy, lane & 7, bits);
+                if (mine && (lane & 7) == 0) {
+                    dec_id[qi] = have ? -2 : -1;
                     dec_bits[qi] = bits;
                 }
             }
