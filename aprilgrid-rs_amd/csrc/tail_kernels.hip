@@ -1147,7 +1147,7 @@ __global__ void __launch_bounds__(64 * TW) k_board_tail(TailArgs a)
                 (void)build_board_w(c, slot, best_quad, lane, best_cells, status, ek);
             }
             int n_quads = 0;
-            if (lane == 0) {
+            {
                 const int8_t *xy = reinterpret_cast<const int8_t *>(slot + SL_XY);
                 uint8_t *found = slot + SL_FOUND;
                 auto find = [&](int x, int y) -> int {
@@ -1158,42 +1158,67 @@ __global__ void __launch_bounds__(64 * TW) k_board_tail(TailArgs a)
                 uint8_t *fa = slot + SL_STACK, *fb = fa + BCELLS;  // the fix list: the two found neighbours ...
                 uint8_t *fm = reinterpret_cast<uint8_t *>(wv + WV_PAIRS);  // ... and the cell between them
                 int n_fix = 0;
-                for (int i = 0; i < best_cells; ++i) {
-                    if (found[i]) continue;
-                    const int x = xy[2 * i], y = xy[2 * i + 1];
-                    const int c0 = find(x + 1, y), c1 = find(x - 1, y);
-                    if (c0 >= 0 && c1 >= 0) {
-                        if (found[c0] && found[c1]) { fa[n_fix] = (uint8_t)c0; fb[n_fix] = (uint8_t)c1; fm[n_fix] = (uint8_t)i; ++n_fix; }
-                    } else {
-                        const int c2 = find(x, y + 1), c3 = find(x, y - 1);
-                        if (c2 >= 0 && c3 >= 0 && found[c2] && found[c3]) { fa[n_fix] = (uint8_t)c2; fb[n_fix] = (uint8_t)c3; fm[n_fix] = (uint8_t)i; ++n_fix; }
-                    }
-                }
-                for (int k = 0; k < n_fix; ++k) {
-                    const u64 q0 = slot_quad(slot, fa[k]), q1 = slot_quad(slot, fb[k]);
-                    int mid[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int i0 = q_at(q0, i), i1 = q_at(q1, i);
-                        const float x = (sx[i0] + sx[i1]) / 2.0f, y = (sy[i0] + sy[i1]) / 2.0f;
-                        u64 bestk = ~0ull;
-                        for (int t = 0; t < n; ++t) {
-                            const u64 kk = dist_key(x, y, sx[t], sy[t], (uint32_t)t);
-                            bestk = kk < bestk ? kk : bestk;
+                for (int base = 0; base < best_cells; base += 64) {  // (a cell per lane; the list in the cells' order)
+                    const int i = base + lane;
+                    bool want = false;
+                    int ca = 0, cb = 0;
+                    if (i < best_cells && !found[i]) {
+                        const int x = xy[2 * i], y = xy[2 * i + 1];
+                        const int c0 = find(x + 1, y), c1 = find(x - 1, y);
+                        if (c0 >= 0 && c1 >= 0) {
+                            want = found[c0] && found[c1];
+                            ca = c0;
+                            cb = c1;
+                        } else {
+                            const int c2 = find(x, y + 1), c3 = find(x, y - 1);
+                            want = c2 >= 0 && c3 >= 0 && found[c2] && found[c3];
+                            ca = c2;
+                            cb = c3;
                         }
-                        mid[i] = (int)(uint32_t)bestk;
                     }
-                    const int v = valid_quad(c, mid[0], mid[1], mid[2], mid[3]);
-                    if (v == 2) status |= TAIL_UNCERTAIN;
-                    if (v == 1) {  // the cell between the two is the missing one ((b0 + b1) / 2, :100): it exists, not found
-                        slot_set_quad(slot, fm[k], q_make(mid[0], mid[1], mid[2], mid[3]));
-                        found[fm[k]] = 1;
+                    const u64 mk = __ballot(want);
+                    if (want) {
+                        const int at = n_fix + __popcll(mk & below);
+                        fa[at] = (uint8_t)ca;
+                        fb[at] = (uint8_t)cb;
+                        fm[at] = (uint8_t)i;
                     }
+                    n_fix += __popcll(mk);
                 }
-                for (int i = 0; i < best_cells; ++i)
-                    if (found[i]) quads[n_quads++] = slot_quad(slot, i);
+                if (n_fix) {  // (rare)
+                    wsync();
+                    if (lane == 0)
+                        for (int k = 0; k < n_fix; ++k) {
+                            const u64 q0 = slot_quad(slot, fa[k]), q1 = slot_quad(slot, fb[k]);
+                            int mid[4];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const int i0 = q_at(q0, i), i1 = q_at(q1, i);
+                                const float x = (sx[i0] + sx[i1]) / 2.0f, y = (sy[i0] + sy[i1]) / 2.0f;
+                                u64 bestk = ~0ull;
+                                for (int t = 0; t < n; ++t) {
+                                    const u64 kk = dist_key(x, y, sx[t], sy[t], (uint32_t)t);
+                                    bestk = kk < bestk ? kk : bestk;
+                                }
+                                mid[i] = (int)(uint32_t)bestk;
+                            }
+                            const int v = valid_quad(c, mid[0], mid[1], mid[2], mid[3]);
+                            if (v == 2) status |= TAIL_UNCERTAIN;
+                            if (v == 1) {  // the cell between the two is the missing one ((b0 + b1) / 2, :100): it exists, not found
+                                slot_set_quad(slot, fm[k], q_make(mid[0], mid[1], mid[2], mid[3]));
+                                found[fm[k]] = 1;
+                            }
+                        }
+                    wsync();
+                }
+                for (int base = 0; base < best_cells; base += 64) {  // all_tag_indexes: the found cells' quads, in the cells' order
+                    const int i = base + lane;
+                    const bool f = i < best_cells && found[i];
+                    const u64 mk = __ballot(f);
+                    if (f) quads[n_quads + __popcll(mk & below)] = slot_quad(slot, i);
+                    n_quads += __popcll(mk);
+                }
             }
-            n_quads = __shfl(n_quads, 0);
             wsync();
             TK(6);
 
