@@ -1267,35 +1267,51 @@ __global__ void __launch_bounds__(64 * TW) k_board_tail(TailArgs a)
             DK(1);
             for (int i = lane; i < TN / 32; i += 64) used[i] = 0;
             wsync();
+            // detected_tags.insert(tag_id, corners) (:520) in the quads' order: a tag keeps the place of its first insertion and the
+            // corners of its last; the saddles of every decoded quad are marked (:521-523).  A quad per lane.
             int n_used = 0;
-            if (lane == 0) {
-                for (int qi = 0; qi < n_quads; ++qi) {
-                    const int id = dec_id[qi];
-                    if (id < 0) continue;
-                    int at = -1;
+            for (int base = 0; base < n_quads; base += 64) {
+                const int qi = base + lane, in_pass = n_quads - base < 64 ? n_quads - base : 64;
+                const int id = qi < n_quads ? dec_id[qi] : -1;
+                int at = -1;  // its place, if an earlier round or pass inserted it
+                if (id >= 0)
                     for (int t = 0; t < n_tags; ++t)
                         if (tagids[t] == (uint32_t)id) at = t;
-                    if (at < 0) {
-                        if ((uint32_t)n_tags >= tag_cap) {
-                            status |= TAIL_CAPACITY;
-                            break;
-                        }
-                        at = n_tags++;
-                        tagids[at] = (uint32_t)id;
-                    }
-                    agx_tag *o = a.tags + (size_t)f * a.tag_cap + at;
-                    o->id = (uint32_t)id;
-                    for (int i = 0; i < 8; ++i) o->xy[i] = dec_xy[8 * qi + i];
-                    const u64 q = quads[qi];
-                    for (int i = 0; i < 4; ++i) {
-                        const int s = q_at(q, i);
-                        if (!((used[s >> 5] >> (s & 31)) & 1u)) ++n_used;
-                        used[s >> 5] |= 1u << (s & 31);
+                int first = lane, last = lane;  // the first and the last quad of this pass with the same id (nearly always itself)
+                for (int k = 0; k < in_pass; ++k) {
+                    const int other = __shfl(id, k);
+                    if (id >= 0 && other == id) {
+                        first = k < first ? k : first;
+                        last = k > last ? k : last;
                     }
                 }
+                const bool is_new = id >= 0 && at < 0 && first == lane;
+                const u64 mnew = __ballot(is_new);
+                if (is_new) at = n_tags + __popcll(mnew & below);
+                const int at_first = __shfl(at, first);
+                if (id >= 0 && at < 0) at = at_first;
+                if ((uint32_t)(n_tags + __popcll(mnew)) > tag_cap) {  // (every lane alike)
+                    status |= TAIL_CAPACITY;
+                    break;
+                }
+                if (is_new) tagids[at] = (uint32_t)id;
+                if (id >= 0) {
+                    if (last == lane) {
+                        agx_tag *o = a.tags + (size_t)f * a.tag_cap + at;
+                        o->id = (uint32_t)id;
+                        for (int i = 0; i < 8; ++i) o->xy[i] = dec_xy[8 * qi + i];
+                    }
+                    const u64 q = quads[qi];
+                    for (int i = 0; i < 4; ++i) {
+                        const int sdl = q_at(q, i);
+                        const uint32_t bit = 1u << (sdl & 31);
+                        n_used += !(atomicOr(&used[sdl >> 5], bit) & bit);
+                    }
+                }
+                n_tags += __popcll(mnew);
+                wsync();
             }
-            n_tags = __shfl(n_tags, 0);
-            n_used = __shfl(n_used, 0);
+            for (int o = 32; o; o >>= 1) n_used += __shfl_xor(n_used, o);
             wsync();
             DK(2);
             TK(7);
