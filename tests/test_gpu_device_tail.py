@@ -199,6 +199,21 @@ def test_odd_and_tiny_geometries(pair, w, h):
     same_results(host, dev, frames, cap=64)
 
 
+def test_a_board_that_repeats_its_tags(pair):
+    """HashMap::insert (detector.rs:520): a tag decoded from several quads of one board keeps the place of its first insertion
+    and the corners of its last -- a board drawn with the same five tags over and over."""
+    host, dev = pair
+    synth = synth_module()
+
+    class Repeating(synth.BoardSpec):
+        def tag_id(self, ix, iy_from_top):
+            return (ix + 2 * iy_from_top) % 5
+
+    imgs = np.stack([synth.render_frame(40 + i, 960, 720, spec=Repeating(rows=6, cols=6))[0].numpy() for i in range(6)])
+    counts, _ = same_results(host, dev, imgs, cap=64)
+    assert list(counts) == [5] * 6, counts
+
+
 def test_several_detectors_in_threads(pair):
     """The reference's detect(&self) may be called from any number of threads; here that is a handle per thread.
     Three threads, a detector each, the device tail's kernels side by side on the GPU: every call gives the host tail's tags."""
