@@ -473,6 +473,78 @@ __device__ bool expand_one_w(const Ctx &c, const uint8_t *slot, u64 qs, u64 &out
     return false;
 }
 
+// minimum over the lane's quad of four, in every lane of the four
+__device__ __forceinline__ uint32_t quad_min_u(uint32_t v)
+{
+    uint32_t t = dpp_u<0xB1>(v);  // quad_perm [1, 0, 3, 2]
+    v = t < v ? t : v;
+    t = dpp_u<0x4E>(v);           // quad_perm [2, 3, 0, 1]
+    return t < v ? t : v;
+}
+
+// The SIXTEEN queries of a cell's four directions at once, four lanes each (a lane per cell row): which directions cannot be
+// expanded whatever the board has used -- one of the direction's four lists is empty before the board's own test, and
+// try_expand_one's loops are empty with it (:160-174).  Most directions of most cells are such (a board grown from a quad that
+// is no tag's: all four): try_expand then need not ask.  Asked of a board's first cell only -- most boards end there; for the
+// cells found later it costs more than it saves (measured).  The lists go to the memo: a direction that can be expanded
+// finds them there.  -> bit d: direction d cannot be expanded
+__device__ uint32_t probe4_w(const Ctx &c, u64 quad, int lane)
+{
+    const int q16 = lane >> 2, sub = lane & 3, dir = q16 >> 2, g = q16 & 3;
+    const u64 qs = dir ? (quad >> (16 * dir) | quad << (64 - 16 * dir)) : quad;  // qs[j] = quad[(j + dir) & 3]
+    const int ia = g < 2 ? q_at(qs, 0) : q_at(qs, 3), ib = g < 2 ? q_at(qs, 1) : q_at(qs, 2);
+    const int anchor = (g & 1) ? ib : ia;
+    const uint32_t pkey = 0x80000000u | (uint32_t)ia << 11 | (uint32_t)ib << 1 | (uint32_t)(g & 1);
+    u64 *pslot = c.memo_p + ((pkey * 2654435761u) >> 21);
+    const u64 pe = __hip_atomic_load(pslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    uint32_t raw = (uint32_t)pe;
+    if ((uint32_t)(pe >> 32) != pkey) {  // (the four lanes of a query alike)
+        const float ax = c.sx[ia], ay = c.sy[ia], bx = c.sx[ib], by = c.sy[ib];
+        const float ratio0 = 1.0f + 0.3f;
+        const float ex = ax - bx, ey = ay - by;
+        const float radius_sq = 0.5f * (ex * ex + ey * ey);
+        const float v10x = bx - ax, v10y = by - ay;
+        const float qx = c.sx[anchor] + v10x * ratio0, qy = c.sy[anchor] + v10y * ratio0;
+        u64 k0 = ~0ull, k1 = ~0ull, k2 = ~0ull;
+        const float r = __builtin_amdgcn_sqrtf(radius_sq) * 1.0001f + 1e-3f;
+        if (!(r < 3e38f)) {
+            for (int t = sub; t < c.n; t += 4) top3_insert(dist_key(qx, qy, c.gx[t], c.gy[t], c.gi[t]), k0, k1, k2);
+        } else {
+            const int xa = cell_x(c, qx - r), xb = cell_x(c, qx + r), ya = cell_y(c, qy - r), yb = cell_y(c, qy + r);
+            for (int y = ya + sub; y <= yb; y += 4) {
+                const int t0 = c.gstart[y * c.nx + xa], t1 = c.gstart[y * c.nx + xb + 1];
+                for (int t = t0; t < t1; ++t) top3_insert(dist_key(qx, qy, c.gx[t], c.gy[t], c.gi[t]), k0, k1, k2);
+            }
+        }
+        u64 top0, top1, top2;
+        uint32_t hi0 = (uint32_t)(k0 >> 32), mh = quad_min_u(hi0);
+        uint32_t ml = quad_min_u(hi0 == mh ? (uint32_t)k0 : 0xffffffffu);
+        top0 = (u64)mh << 32 | ml;
+        if (k0 == top0 && top0 != ~0ull) { k0 = k1; k1 = k2; k2 = ~0ull; }
+        hi0 = (uint32_t)(k0 >> 32); mh = quad_min_u(hi0);
+        ml = quad_min_u(hi0 == mh ? (uint32_t)k0 : 0xffffffffu);
+        top1 = (u64)mh << 32 | ml;
+        if (k0 == top1 && top1 != ~0ull) { k0 = k1; k1 = k2; k2 = ~0ull; }
+        hi0 = (uint32_t)(k0 >> 32); mh = quad_min_u(hi0);
+        ml = quad_min_u(hi0 == mh ? (uint32_t)k0 : 0xffffffffu);
+        top2 = (u64)mh << 32 | ml;
+        const u64 mine = sub == 0 ? top0 : (sub == 1 ? top1 : top2);
+        const bool have = sub < 3 && mine != ~0ull;
+        const int idx = have ? (int)(uint32_t)mine : 0;
+        const bool ok = have && __uint_as_float((uint32_t)(mine >> 32)) <= radius_sq && theta_dist(c.st[anchor], c.st[idx]) < 5.0f;
+        const uint32_t m3 = (uint32_t)(__ballot(ok) >> (4 * q16)) & 7u;  // this query's three
+        uint32_t rcnt = 0;
+        raw = 0;
+        if (m3 & 1u) { raw |= ((uint32_t)top0 & 0x3ffu) << (10 * rcnt); ++rcnt; }
+        if (m3 & 2u) { raw |= ((uint32_t)top1 & 0x3ffu) << (10 * rcnt); ++rcnt; }
+        if (m3 & 4u) { raw |= ((uint32_t)top2 & 0x3ffu) << (10 * rcnt); ++rcnt; }
+        raw |= rcnt << 30;
+        if (sub == 0) __hip_atomic_store(pslot, (u64)pkey << 32 | raw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    const u64 empty = __ballot((raw >> 30) == 0);
+    return ((empty & 0xffffull) ? 1u : 0u) | ((empty >> 16 & 0xffffull) ? 2u : 0u) | ((empty >> 32 & 0xffffull) ? 4u : 0u) | ((empty >> 48) ? 8u : 0u);
+}
+
 // Board::new (board.rs:26-48): the board grown from a seed quad; returns its score, the cells stay in the slot.
 // try_expand's recursion (:114-152) is a stack of (cell, next direction) walked by all lanes alike: the top of the stack lives
 // in registers, lane 0 writes the slot, one wave-level ordering point per step.  A grid byte = the cell's number, bit 7 = found.
@@ -505,11 +577,13 @@ __device__ int build_board_w(const Ctx &c, uint8_t *slot, u64 seed, int lane, in
     int n_cells = 1, score = 1, sp = 1;
     int cur = 0, cur_i = 0, cur_x = 0, cur_y = 0;  // the top of the stack: cell, next direction, the cell's coordinates and quad
     u64 cur_quad = seed;
+    uint32_t cur_dead = probe4_w(c, seed, lane);  // its directions that cannot be expanded (probe4_w)
     for (;;) {
         if (cur_i == 4) {  // this cell is done: back to the one it was reached from
             if (--sp == 0) break;
             cur = stack[2 * (sp - 1)];
-            cur_i = stack[2 * (sp - 1) + 1];
+            cur_i = stack[2 * (sp - 1) + 1] & 15;
+            cur_dead = stack[2 * (sp - 1) + 1] >> 4;
             cur_x = xy[2 * cur];
             cur_y = xy[2 * cur + 1];
             cur_quad = slot_quad(slot, cur);
@@ -526,7 +600,7 @@ __device__ int build_board_w(const Ctx &c, uint8_t *slot, u64 seed, int lane, in
         if (e != 0xff && (e & 0x80)) continue;  // :132-136 already found
         const u64 qs = i ? (cur_quad >> (16 * i) | cur_quad << (64 - 16 * i)) : cur_quad;  // qs[j] = quad[(j + i) & 3]
         u64 nq = 0;
-        const bool ok = expand_one_w(c, slot, qs, nq, lane, status, ek);
+        const bool ok = ((cur_dead >> i) & 1u) ? false : expand_one_w(c, slot, qs, nq, lane, status, ek);
         int at = e & 0x7f;
         if (e == 0xff) {
             if (n_cells == BCELLS) {
@@ -546,7 +620,7 @@ __device__ int build_board_w(const Ctx &c, uint8_t *slot, u64 seed, int lane, in
             slot_set_quad(slot, at, ok ? v : 0ull);
             if (ok) {
                 stack[2 * (sp - 1)] = (uint8_t)cur;  // where to come back to (depth <= found cells <= BCELLS)
-                stack[2 * (sp - 1) + 1] = (uint8_t)cur_i;
+                stack[2 * (sp - 1) + 1] = (uint8_t)(cur_i | cur_dead << 4);
             }
         }
         if (ok && lane < 4) {  // the new cell's four saddles are used (:140-142): a lane each, an atomic each (two may share a word)
@@ -561,6 +635,7 @@ __device__ int build_board_w(const Ctx &c, uint8_t *slot, u64 seed, int lane, in
             cur_x = nx;
             cur_y = ny;
             cur_quad = v;
+            cur_dead = 0;  // (asked only of the seed's cell: a found cell's neighbours are mostly found or expandable, measured)
         }
         wsync();
     }
