@@ -199,6 +199,22 @@ def test_odd_and_tiny_geometries(pair, w, h):
     same_results(host, dev, frames, cap=64)
 
 
+@pytest.mark.parametrize("threads", [1, 2, 3])
+def test_several_chunks_on_few_host_threads(pair, threads):
+    """A call of more than two 1024-frame chunks: the chunks' uploads go up in parts on the pool's threads, in order, under the
+    kernels of the chunk before -- also when the pool is a single thread (the parts then simply follow one another)."""
+    host, dev = pair
+    synth = synth_module()
+    fr = synth.render_batch(1200, 96, 320, 240, device="cuda")[0].cpu().numpy()
+    big = np.concatenate([fr] * 23)[:2150]
+    rc_h, out_h, cnt_h, st_h = host.detect_batch_raw(big[:96], n_threads=4, cap=64)
+    rc_d, out_d, cnt_d, st_d = dev.detect_batch_raw(big, n_threads=threads, cap=64)
+    assert rc_d == rc_h == 0 and dev.get_option("last_device_tail_frames") == len(big)
+    for f in range(len(big)):
+        g = f % 96
+        assert cnt_d[f] == cnt_h[g] and out_d[f, : cnt_d[f]].tobytes() == out_h[g, : cnt_h[g]].tobytes(), f
+
+
 def test_a_board_that_repeats_its_tags(pair):
     """HashMap::insert (detector.rs:520): a tag decoded from several quads of one board keeps the place of its first insertion
     and the corners of its last -- a board drawn with the same five tags over and over."""
