@@ -6,7 +6,7 @@ clustering -> rochade_refine -> k/phi filter, kernels K1..K4) over one batch of 
 1280x800 u8 frames that is already resident in HBM.  N = 1 is BASELINE.json configs[1]
 (256 frames on one MI355X); N > 1 is configs[2]: every rank owns 256 frames (weak scaling,
 2048 frames on 8 GPUs) and the only collective is the RCCL gather of the result slabs to rank 0
-(every step's slab is delivered; --gather-steps consecutive steps share one collective).
+(one collective per step; a second pass with --grouped-gather steps per collective is reported beside it).
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -61,7 +61,7 @@ IN_BYTES = {"L8": 1, "L16": 2, "RGB8": 3}
 ANGLE_TOL_DEG = 1e-3          # theta / phi: device acosf / atan2f vs glibc (tests/util.py)
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -96,13 +96,17 @@ def parse_args():
     ap.add_argument("--gather-every", type=int, default=1,
                     help="N > 1: gather the result slabs to rank 0 every n-th step (and the last one) instead of every step; "
                          "the default -- and what the headline is quoted on -- is every step")
-    ap.add_argument("--gather-steps", type=int, default=4,
+    ap.add_argument("--gather-steps", type=int, default=1,
                     help="N > 1: the result slabs of this many consecutive steps travel to rank 0 in ONE collective (every step's results "
-                         "are delivered, the fence sends a group that is not full; fewer, larger messages: one rank through nccl pays "
-                         "+18 us per step with 1, +11 with 4, +9 with 8 -- profiles/r5_gather_steps.txt); 1 = a collective per step")
+                         "are delivered, the fence sends a group that is not full).  Default 1 = a collective per step: BASELINE.json "
+                         "configs[2] as written, and what `value` is quoted on")
+    ap.add_argument("--grouped-gather", type=int, default=4,
+                    help="N > 1: after the timed region, a second, separately reported timed pass with this many steps per collective "
+                         "(fewer, larger messages: one rank through nccl pays +18 us per step with 1, +11 with 4, +9 with 8 -- "
+                         "profiles/r5_gather_steps.txt); reported as `grouped_gather`, never `value`; 0 = skip")
     ap.add_argument("--pmc-traffic", type=float, default=None,
                     help="HBM bytes per K1 launch from a separate rocprofv3 --pmc run (profiles/)")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 def make_workload(first_frame, n_frames, width, height, fmt, unique, noise, device):
@@ -618,8 +622,79 @@ class CudaRuntime:
         return self.torch.cuda.Event(enable_timing=True)
 
 
-def main():
-    args = parse_args()
+def visible_gpus():
+    """GPUs this process would see, counted WITHOUT initialising HIP here (the parent of the ranks must never touch the
+    GPU): KFD topology nodes with SIMDs, cut down by *_VISIBLE_DEVICES.  None when sysfs does not say (no KFD)."""
+    import glob
+    n = 0
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return None
+    for p in nodes:
+        try:
+            with open(p) as f:
+                props = dict(l.split()[:2] for l in f if len(l.split()) >= 2)
+        except OSError:
+            return None  # (a node this user may not read: let the ranks find out)
+        if int(props.get("simd_count", "0")) > 0:
+            n += 1
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as a CHILD
+    (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>
+    bench.py <the same arguments>), hand rank 0's one JSON line through on stdout and return the child's exit code.
+    This process has imported neither torch nor the package and never touches the GPU; nothing is exec'd."""
+    import socket
+    import subprocess
+    stub = os.environ.get("AGX_BENCH_STUB") == "1"
+    if not stub:
+        seen = visible_gpus()
+        if seen is not None and seen < args.gpus:
+            print("bench.py: --gpus %d but %d GPU%s visible on this node (KFD topology, *_VISIBLE_DEVICES applied)"
+                  % (args.gpus, seen, "" if seen == 1 else "s"), file=sys.stderr)
+            return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs between the ranks on this pool
+    env.setdefault("OMP_NUM_THREADS", "1")  # (what the launcher would set itself, with a warning)
+    env["PYTHONPATH"] = ROOT + (os.pathsep + env["PYTHONPATH"] if env.get("PYTHONPATH") else "")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    print("bench.py: launching %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    # cwd = the repository: `python -m` puts the working directory on sys.path, and whatever lies there must not shadow a module
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, bufsize=1, cwd=ROOT)
+    try:
+        for line in child.stdout:  # rank 0's JSON line -> stdout; anything else a rank printed -> stderr
+            if line.startswith("{") and '"metric"' in line:
+                sys.stdout.write(line)
+                sys.stdout.flush()
+            else:
+                sys.stderr.write(line)
+        return child.wait()
+    except BaseException:
+        child.terminate()  # (the exact process started here; the launcher takes its ranks down with it)
+        try:
+            child.wait(30)
+        except subprocess.TimeoutExpired:
+            child.kill()
+        raise
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around this process: become the parent of the ranks -- BEFORE torch, the package or HIP
+        raise SystemExit(launch_ranks(args, argv))
     if args.images:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import bench_images
@@ -642,9 +717,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs the torch.distributed.run launcher (WORLD_SIZE=%d)" % (args.gpus, world))
+    if world != args.gpus:  # (a launcher around this process that disagrees with --gpus: say so, do not guess)
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     dev = rt.device(local_rank)
     coll1 = world == 1 and args.collective_world_1
@@ -818,6 +891,36 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    # N > 1: the same K steps again with the slabs of --grouped-gather consecutive steps per collective (every rank
+    # walks the same sequence; reported beside `value`, which stays on one collective per step)
+    grouped = None
+    if world > 1 and args.grouped_gather > 1 and args.gather_steps == 1 and args.gather_every <= 1 and args.pipeline == 1:
+        pipe_g = sharding.ChainPipeline(A.TagFamily.T36H11, F, dev, depth=1, dst=0, slab_records=slab,
+                                        detector_cls=rt.detector_cls, steps_per_gather=args.grouped_gather)
+
+        def fence_g():
+            pipe_g.finish()
+            rt.synchronize(dev)
+            dist.barrier()
+            rt.synchronize(dev)
+
+        for _ in range(max(args.warmup, 2 * args.grouped_gather)):
+            pipe_g.submit(frames)
+        fence_g()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            pipe_g.submit(frames)
+        fence_g()
+        tg = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+        dtg = float(tg.item())
+        grouped = {"steps_per_collective": pipe_g.gather.k, "ms_per_step": round(1e3 * dtg / args.steps, 4),
+                   "value": round(px_per_step_rank * world * args.steps / dtg / 1e6, 1), "unit": "Mpix/s",
+                   "note": "the same K steps, result slabs of %d consecutive steps per collective (results up to %d steps late): "
+                           "never `value`" % (pipe_g.gather.k, pipe_g.gather.k - 1)}
+        pipe_g.close()
+        del pipe_g
+
     result = None
     if rank == 0:
         total_px = px_per_step_rank * world * args.steps
@@ -886,6 +989,7 @@ def main():
                 "saddles_per_frame": round(saddles_per_frame, 1),
                 "clusters_per_frame": round(clusters_per_frame, 1),
                 "parallelism": "frame-sharded x%d, RCCL gather of result slabs (%d steps per collective)" % (world, pipe.gather.k) if world > 1 else "1 GPU",
+                "steps_per_gather": pipe.gather.k,
                 "batches_in_flight": pipe.depth,
                 "k1_rows_per_segment": rows_per_seg,
             },
@@ -918,6 +1022,8 @@ def main():
             result["ms_per_step_min"] = round(min(per_step), 4)
         if pipelined:
             result["pipelined"] = pipelined
+        if grouped:
+            result["grouped_gather"] = grouped
         if world == 1:
             host = host_view(frames[:uniq], args.format)
             if not args.no_verify:

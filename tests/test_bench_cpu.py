@@ -22,10 +22,56 @@ def test_cpu_baseline_leg_reports_the_contract_fields():
     assert r["all_cores"]["cores"] >= 1 and r["all_cores"]["value"] > 0
 
 
-def test_bench_refuses_multi_gpu_without_the_launcher():
+def test_plain_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher around it (the form the driver uses for N = 1, and the likeliest form of its
+    N = 8 command): bench.py starts the ranks itself as a child under torch.distributed.run -- before it has imported torch or
+    touched a device -- hands rank 0's one JSON line through and exits with the child's code."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update({"AGX_BENCH_STUB": "1", "OMP_NUM_THREADS": "1"})
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--frames", "2",
+           "--width", "192", "--height", "128", "--settle-ms", "30", "--no-extra", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd="/tmp")  # (from any directory)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]  # stdout carries the one line and nothing else
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["gather_check"]["ranks"] == 2 and out["gather_check"]["through_collective"] is True
+    assert out["config"]["steps_per_gather"] == 1 and out["grouped_gather"]["steps_per_collective"] == 4
+    assert "torch.distributed.run" in r.stderr  # the launch is announced on stderr
+
+
+def test_a_failing_rank_fails_the_plain_form():
+    """The child's exit code is the parent's: a launcher-less run whose ranks die reports non-zero and prints no JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update({"AGX_BENCH_STUB": "1", "OMP_NUM_THREADS": "1"})
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "0", "--warmup", "0", "--frames", "2",
+           "--width", "192", "--height", "128", "--settle-ms", "0", "--no-extra"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)  # (zero timed steps: rank 0 divides by it)
+    assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_a_launcher_that_disagrees_with_gpus_is_refused():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
-                       capture_output=True, text=True, env={**os.environ, "WORLD_SIZE": "1"})
-    assert r.returncode != 0 and "torch.distributed.run" in (r.stderr + r.stdout)
+                       capture_output=True, text=True, env={**os.environ, "WORLD_SIZE": "1", "AGX_BENCH_STUB": "1"})
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+def test_more_gpus_than_the_node_shows_is_refused_early():
+    """No stub: the parent counts the node's GPUs from the KFD topology (never through HIP) and refuses before starting anything."""
+    sys.path.insert(0, ROOT)
+    import bench
+    seen = bench.visible_gpus()
+    if seen is None:  # no KFD in this container: the count is left to the ranks
+        seen = 0
+        cmd_n = None
+    else:
+        cmd_n = seen + 1
+    assert bench.visible_gpus() in (None, seen)
+    if cmd_n is not None and cmd_n > 1:
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "AGX_BENCH_STUB")}
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(cmd_n)], capture_output=True, text=True, env=env)
+        assert r.returncode == 2 and "visible" in r.stderr
 
 
 def test_bench_two_rank_control_flow_under_gloo():
@@ -87,7 +133,8 @@ def test_bench_eight_rank_control_flow_under_gloo():
     assert out["n_gpus"] == 8 and out["steps"] == 2 and out["scaling"] == "weak" and out["backend"] == "cpu-stub"
     gc = out["gather_check"]
     assert gc["ranks"] == 8 and gc["frames"] == 2048 and gc["oracle_checked_remote_frames"] == 7 and gc["through_collective"] is True
-    assert out["config"]["frames_per_gpu"] == 256 and "x8" in out["config"]["parallelism"] and "4 steps per collective" in out["config"]["parallelism"]
+    assert out["config"]["frames_per_gpu"] == 256 and "x8" in out["config"]["parallelism"] and "1 steps per collective" in out["config"]["parallelism"]
+    assert out["grouped_gather"]["steps_per_collective"] == 4 and out["grouped_gather"]["value"] > 0
     # whole-job value: all eight ranks' pixels over the slowest rank's time
     assert abs(out["value"] - 8 * 256 * 192 * 128 * 2 / (out["ms_per_step"] * 2 * 1e-3) / 1e6) < 0.02 * out["value"]
 
@@ -102,8 +149,8 @@ def test_bench_gathers_every_nth_step_and_always_the_last():
 
 
 def test_bench_one_collective_per_step_or_per_three():
-    """The default sends the slabs of four consecutive steps in one collective (the 2- and 8-rank tests above run it: the group that is
-    not full at a fence is sent by the fence).  Here: --gather-steps 1 (a collective per step) and 3, over 7 timed steps on 3 ranks;
+    """The default is a collective per step, with a second reported pass at four steps per collective (the 2- and 8-rank tests above
+    run both: the group that is not full at a fence is sent by the fence).  Here: --gather-steps 1 and 3, over 7 timed steps on 3 ranks;
     rank 0 still finds every rank's LAST step complete and checks it like any other run."""
     for k in ("1", "3"):
         out = _launch(3, ["--steps", "7", "--warmup", "1", "--frames", "3", "--width", "192", "--height", "128", "--settle-ms", "0",
