@@ -296,43 +296,69 @@ static int detect_batch_device_tail(agx_detector *det, const void *frames, const
     bool pending_batch = false;
     // A chunk goes up in P parts on P workers at once (a copy from pageable memory is staged by the calling thread at 10 .. 15 GB/s:
     // it takes four to six of them to fill the link), the chunks one after the other (three large chunks side by side would
-    // share the link, and the first -- the one the device waits for -- would arrive with the third): a part starts when fewer
-    // than P parts with smaller numbers are unfinished.  Parts share the S upload streams (the streams only order the copies).
+    // share the link, and the first -- the one the device waits for -- would arrive with the third).  The parts form ONE
+    // in-order list (index ci * P + part); up to P uploader tasks take the lowest part nobody has taken yet, copy it, and take
+    // the next, until no released part is left -- then they end.  No task ever waits for another one: a pool of a single
+    // thread uploads the parts one by one (a task that waited for "its" turn while lower-numbered parts were still queued
+    // behind it deadlocked pools of <= 6 threads on calls of >= 4 chunks).  A chunk's parts are released when its staging
+    // slot is free: the first S chunks at once, chunk ci + S when chunk ci's kernels are through.
     const int P = std::max(1, std::min(6, pool->size()));
-    int parts_done = 0;                 // (guarded by m)
+    int next_part = 0, released_parts = 0, live_uploaders = 0;  // (guarded by m)
+    bool stop_uploads = false;                                   // an error ended the call: nothing more is taken (guarded by m)
     std::vector<int> parts_left;        // per chunk                                   (guarded by m)
     std::vector<char> chunk_failed;     //                                             (guarded by m)
-    auto upload_part = [&, device, P](int ci, int part) {
-        const int c0 = ci * chunk, nf = std::min(chunk, n_frames - c0), slot = ci % S;
-        const int f0 = (int)((long long)nf * part / P), f1 = (int)((long long)nf * (part + 1) / P);
-        {
-            std::unique_lock<std::mutex> lk(m);
-            cv.wait(lk, [&] { return ci * P + part - parts_done < P; });
+    auto uploader = [&, device, P] {
+        for (;;) {
+            int idx;
+            {
+                std::lock_guard<std::mutex> lk(m);
+                if (stop_uploads || next_part >= released_parts) {
+                    --live_uploaders;
+                    return;
+                }
+                idx = next_part++;
+            }
+            const int ci = idx / P, part = idx % P;
+            const int c0 = ci * chunk, nf = std::min(chunk, n_frames - c0), slot = ci % S;
+            const int f0 = (int)((long long)nf * part / P), f1 = (int)((long long)nf * (part + 1) / P);
+            const bool ok = f1 <= f0 ||
+                            (hipSetDevice(device) == hipSuccess &&
+                             hipMemcpyAsync(d_stage + (size_t)slot * chunk_bytes + (size_t)f0 * frame_stride_bytes,
+                                            (const uint8_t *)frames + (size_t)(c0 + f0) * frame_stride_bytes, (size_t)(f1 - f0) * frame_stride_bytes,
+                                            hipMemcpyHostToDevice, up[part % S]) == hipSuccess &&
+                             hipStreamSynchronize(up[part % S]) == hipSuccess);
+            {
+                std::lock_guard<std::mutex> lk(m);
+                if (!ok) chunk_failed[(size_t)ci] = 1;
+                if (--parts_left[(size_t)ci] == 0) uploaded[(size_t)ci] = chunk_failed[(size_t)ci] ? -1 : 1;
+            }
+            cv.notify_all();
         }
-        const bool ok = f1 <= f0 ||
-                        (hipSetDevice(device) == hipSuccess &&
-                         hipMemcpyAsync(d_stage + (size_t)slot * chunk_bytes + (size_t)f0 * frame_stride_bytes,
-                                        (const uint8_t *)frames + (size_t)(c0 + f0) * frame_stride_bytes, (size_t)(f1 - f0) * frame_stride_bytes,
-                                        hipMemcpyHostToDevice, up[part % S]) == hipSuccess &&
-                         hipStreamSynchronize(up[part % S]) == hipSuccess);
+    };
+    // `n_more` chunks' parts may go up: tops the uploaders up to P (ahead of every queued host tail)
+    auto release_chunks = [&, P](int n_more) {
+        int spawn;
         {
             std::lock_guard<std::mutex> lk(m);
-            ++parts_done;
-            if (!ok) chunk_failed[(size_t)ci] = 1;
-            if (--parts_left[(size_t)ci] == 0) uploaded[(size_t)ci] = chunk_failed[(size_t)ci] ? -1 : 1;
+            released_parts += n_more * P;
+            spawn = std::max(0, std::min(P - live_uploaders, released_parts - next_part));
+            live_uploaders += spawn;
         }
-        cv.notify_all();
-    };
-    auto upload_task = [&, P](int ci) {  // (queue order = start order: the parts of a chunk side by side)
-        for (int part = 1; part < P; ++part) pool->submit_front([&upload_part, ci, part] { upload_part(ci, part); });
-        upload_part(ci, 0);
+        int started = 0;
+        try {
+            for (; started < spawn; ++started) pool->submit_front(uploader);
+        } catch (...) {  // (a task could not be queued: the count must not include uploaders that will never run)
+            std::lock_guard<std::mutex> lk(m);
+            live_uploaders -= spawn - started;
+            throw;
+        }
     };
     try {
     uploaded.assign((size_t)n_chunks, 0);
     parts_left.assign((size_t)n_chunks, P);
     chunk_failed.assign((size_t)n_chunks, 0);
-    if (!d_frames)
-        for (int ci = 0; ci < std::min(S, n_chunks); ++ci) pool->submit([&upload_task, ci] { upload_task(ci); });
+    if (!d_frames) release_chunks(std::min(S, n_chunks));
+    const int tail_debug = agx_internal_tail_debug(det);  // AGX_TAIL_DEBUG as the handle read it when it was created
     std::vector<uint32_t> ns, offs;
     std::vector<int> fst;
     for (int ci = 0; ci < n_chunks; ++ci) {
@@ -367,7 +393,7 @@ static int detect_batch_device_tail(agx_detector *det, const void *frames, const
         rc = agx_internal_fetch_tail(det, &tags, &table, &tag_cap);  // waits for the device
         if (rc) break;
         bool any_back = false;
-        if (std::getenv("AGX_TAIL_DEBUG")) {
+        if (tail_debug) {
             int h[32] = {0};
             for (int f = 0; f < nf; ++f)
                 for (int b = 0; b < 32; ++b) h[b] += (table[4 * f + 1] >> b) & 1u;
@@ -397,7 +423,7 @@ static int detect_batch_device_tail(agx_detector *det, const void *frames, const
             }
             counts[gf] = nt;
             int stf = AGX_OK;
-            if (nt > cap_per_frame) {  // (cannot happen: the kernel's own capacity is at most the caller's)
+            if (nt > cap_per_frame) {  // (the kernel was given min(cap_per_frame, 128) as its limit and hands frames beyond it back)
                 stf = AGX_ERR_CAPACITY;
                 int exp = AGX_OK;
                 first_bad.compare_exchange_strong(exp, stf);
@@ -464,10 +490,14 @@ static int detect_batch_device_tail(agx_detector *det, const void *frames, const
             pending_batch = false;
         }
         // chain, luma and tail have read the staging slot: the chunk S ahead may go up
-        if (!d_frames && ci + S < n_chunks) pool->submit_front([&upload_task, ci] { upload_task(ci + S); });
+        if (!d_frames && ci + S < n_chunks) release_chunks(1);
     }
     } catch (...) {
         rc = AGX_ERR_NOMEM;
+    }
+    if (rc) {  // the call has failed: the uploaders stop at their next part instead of copying the rest of the caller's frames
+        std::lock_guard<std::mutex> lk(m);
+        stop_uploads = true;
     }
     (void)pool->wait();
     if (pending_batch) agx_internal_abandon_batch(det);
@@ -504,7 +534,13 @@ static int detect_batch_impl(agx_detector *det, const void *frames, const void *
     // 48: 4.3 / 4.4, 64: 4.6 / 4.7, 96: 6.8 / 5.3, 128: 8.9 / 6.0, 256: 15.7 / 8.5): left to choose, a call of fewer than four
     // frames per host thread keeps the host tail.
     const int tail_mode = agx_internal_device_tail(det);
-    if (tail_mode == 1 || (tail_mode == 2 && n_frames >= 4 * pool->size()))
+    bool on_device = tail_mode == 1 || (tail_mode == 2 && n_frames >= 4 * pool->size());
+    if (on_device) {  // the one-time set-up (code list, 155 KB of LDS for the kernel): asked for -> its failure is the call's;
+        const int prc = agx_internal_tail_prepare(det);  // left to choose -> the host tail, which needs nothing from the device
+        if (prc && tail_mode == 1) return prc;
+        if (prc) on_device = false;
+    }
+    if (on_device)
         return detect_batch_device_tail(det, frames, d_frames, n_frames, width, height, row_stride_bytes, frame_stride_bytes, format, out,
                                         cap_per_frame, counts, frame_status, pool);
     agx_internal_tail_stats(det, 0, 0, 0);  // ("last_device_tail_frames" 0: this call's tails run on the host)

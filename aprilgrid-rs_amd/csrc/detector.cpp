@@ -69,6 +69,16 @@ struct agx_detector {
     // (AGX_DBG_REDZONES) reports the guard bytes that no longer hold the pattern
     size_t redzone = 0;
     std::vector<size_t> alloc_bytes;  // payload bytes per entry of device_allocs
+    // Buffers outside the chain's workspace (staging, luma planes, the device tail's code list and result tables): the same
+    // guard bytes around each, device memory or mapped pinned host memory; AGX_DBG_REDZONES counts them after the workspace's
+    struct SideBuf {
+        void *base = nullptr;  // start of the front guard (what hipMalloc / hipHostMalloc returned)
+        size_t bytes = 0;      // payload
+        bool host = false;     // pinned host memory (mapped when dev != nullptr)
+        void *dev = nullptr;   // device address of the payload of a mapped host buffer
+    };
+    enum { SB_STAGE, SB_LUMA_D, SB_LUMA_H, SB_CODES, SB_TAGS, SB_TAIL_TABLE, SB_COUNT };
+    SideBuf side[SB_COUNT];
     // staging for the single-frame host API
     uint8_t *d_stage = nullptr;
     size_t stage_bytes = 0;
@@ -117,6 +127,8 @@ struct agx_detector {
     // option "device_tail": agx_detect_batch's board search + decode on the device (tail_kernels.hip); frames the kernel
     // hands back (TAIL_UNCERTAIN / TAIL_CAPACITY) take the host tail
     int device_tail = -1;  // -1: by the batch's size, where this process's atan2f is the routine the kernel restates; 0 off; 1 on
+    bool tail_ready = false;        // code list on the device and the kernel's attributes set for this device: all or nothing
+    int tail_debug_band_mdeg = 0;   // option "tail_debug_band" (tests of the hand-back path), thousandths of a degree
     uint64_t *d_codes = nullptr;                                     // the family's code list
     agx_tag *h_tags = nullptr, *h_tags_dev = nullptr;                // mapped pinned [tail_frames][tail_tag_cap]
     uint32_t *h_tail_table = nullptr, *h_tail_table_dev = nullptr;   // mapped pinned [tail_frames][4]: count, status, ticks, saddles | seeds << 16
@@ -258,6 +270,47 @@ int dev_alloc(agx_detector *d, T *&ptr, size_t count)
     }
     ptr = (T *)((char *)p + rz);
     return AGX_OK;
+}
+
+// A buffer outside the workspace, with the handle's guard bytes around it.  kind: 0 device, 1 pinned host, 2 pinned host
+// mapped into the device (b.dev = its device address).  The old buffer is freed first; on failure the slot is empty.
+void side_free(agx_detector *d, int which)
+{
+    agx_detector::SideBuf &b = d->side[which];
+    if (b.base) (void)(b.host ? hipHostFree(b.base) : hipFree(b.base));
+    b = agx_detector::SideBuf();
+}
+void *side_alloc(agx_detector *d, int which, size_t bytes, int kind)
+{
+    side_free(d, which);
+    agx_detector::SideBuf &b = d->side[which];
+    const size_t rz = d->redzone, payload = std::max<size_t>(bytes, 1);
+    void *p = nullptr;
+    if (kind == 0) {
+        if (hipMalloc(&p, payload + 2 * rz) != hipSuccess) return nullptr;
+        if (rz && (hipMemset(p, 0xA5, rz) != hipSuccess || hipMemset((char *)p + rz + payload, 0xA5, rz) != hipSuccess)) {
+            (void)hipFree(p);
+            return nullptr;
+        }
+    } else {
+        if (hipHostMalloc(&p, payload + 2 * rz, kind == 2 ? hipHostMallocMapped : hipHostMallocDefault) != hipSuccess) return nullptr;
+        if (rz) {
+            std::memset(p, 0xA5, rz);
+            std::memset((char *)p + rz + payload, 0xA5, rz);
+        }
+        if (kind == 2) {
+            void *dp = nullptr;
+            if (hipHostGetDevicePointer(&dp, p, 0) != hipSuccess) {
+                (void)hipHostFree(p);
+                return nullptr;
+            }
+            b.dev = (char *)dp + rz;
+        }
+    }
+    b.base = p;
+    b.bytes = payload;
+    b.host = kind != 0;
+    return (char *)p + rz;
 }
 
 void free_workspace(agx_detector *d)
@@ -552,12 +605,10 @@ __attribute__((visibility("hidden"))) int agx_internal_chunk_luma8(agx_detector 
     if (slot < 0 || slot >= n_slots) return AGX_ERR_ARG;
     if ((size_t)n_slots * one > det->luma_bytes) {
         if (hipStreamSynchronize(det->stream) != hipSuccess) return AGX_ERR_HIP;
-        if (det->d_luma) (void)hipFree(det->d_luma);
-        if (det->h_luma) (void)hipHostFree(det->h_luma);
-        det->d_luma = det->h_luma = nullptr;
         det->luma_bytes = 0;
-        if (hipMalloc((void **)&det->d_luma, (size_t)n_slots * one) != hipSuccess) return AGX_ERR_HIP;
-        if (hipHostMalloc((void **)&det->h_luma, (size_t)n_slots * one, hipHostMallocDefault) != hipSuccess) return AGX_ERR_HIP;
+        det->d_luma = static_cast<uint8_t *>(side_alloc(det, agx_detector::SB_LUMA_D, (size_t)n_slots * one, 0));
+        det->h_luma = static_cast<uint8_t *>(side_alloc(det, agx_detector::SB_LUMA_H, (size_t)n_slots * one, 1));
+        if (!det->d_luma || !det->h_luma) return AGX_ERR_HIP;
         det->luma_bytes = (size_t)n_slots * one;
     }
     uint8_t *d = det->d_luma + (size_t)slot * one, *h = det->h_luma + (size_t)slot * one;
@@ -633,6 +684,24 @@ __attribute__((visibility("hidden"))) void agx_internal_tail_stats(agx_detector 
     det->last_tail_fallbacks = fallbacks;
     det->last_tail_uncertain = uncertain;
 }
+// One-time set-up of the device tail on this handle's device: the family's code list in device memory and the kernel's
+// attributes (155 KB of LDS).  All or nothing: a failure leaves nothing behind, and a later call starts over.
+__attribute__((visibility("hidden"))) int agx_internal_tail_prepare(agx_detector *det)
+{
+    if (det->tail_ready) return AGX_OK;
+    if (hipSetDevice(det->device) != hipSuccess) return AGX_ERR_HIP;
+    det->d_codes = static_cast<uint64_t *>(side_alloc(det, agx_detector::SB_CODES, (size_t)det->fam.n_codes * sizeof(uint64_t), 0));
+    if (!det->d_codes ||
+        hipMemcpy(det->d_codes, det->fam.codes, (size_t)det->fam.n_codes * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess ||
+        init_tail_kernels() != 0) {
+        side_free(det, agx_detector::SB_CODES);
+        det->d_codes = nullptr;
+        return AGX_ERR_HIP;
+    }
+    det->tail_ready = true;
+    return AGX_OK;
+}
+__attribute__((visibility("hidden"))) int agx_internal_tail_debug(const agx_detector *) { return tuning_env("AGX_TAIL_DEBUG", 0); }  // (read at create)
 __attribute__((visibility("hidden"))) int agx_internal_enqueue_tail(agx_detector *det, const void *d_luma, size_t luma_row_stride,
                                                                     size_t luma_frame_stride, uint32_t tag_cap)
 {
@@ -640,23 +709,26 @@ __attribute__((visibility("hidden"))) int agx_internal_enqueue_tail(agx_detector
     const ChainArgs &a = det->args;
     if (tag_cap == 0 || luma_row_stride > 0x7fffffffu) return AGX_ERR_ARG;
     if (tag_cap > 128u) tag_cap = 128u;  // (the kernel's own list of distinct ids; frames beyond it take the host tail)
-    if (!det->d_codes) {
-        if (hipMalloc((void **)&det->d_codes, (size_t)det->fam.n_codes * sizeof(uint64_t)) != hipSuccess) return AGX_ERR_HIP;
-        if (hipMemcpy(det->d_codes, det->fam.codes, (size_t)det->fam.n_codes * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess) return AGX_ERR_HIP;
-        if (init_tail_kernels() != 0) return AGX_ERR_HIP;
+    if (!det->tail_ready) {
+        const int rc = agx_internal_tail_prepare(det);
+        if (rc) return rc;
     }
     if ((size_t)a.n_frames > det->tail_frames || tag_cap > det->tail_tag_cap) {
         if (hipStreamSynchronize(det->stream) != hipSuccess) return AGX_ERR_HIP;
-        if (det->h_tags) (void)hipHostFree(det->h_tags);
-        if (det->h_tail_table) (void)hipHostFree(det->h_tail_table);
-        det->h_tags = det->h_tags_dev = nullptr;
-        det->h_tail_table = det->h_tail_table_dev = nullptr;
-        det->tail_frames = 0;
         const size_t F = std::max((size_t)a.n_frames, det->tail_frames), cap = std::max(tag_cap, det->tail_tag_cap);
-        if (hipHostMalloc((void **)&det->h_tags, F * cap * sizeof(agx_tag), hipHostMallocMapped) != hipSuccess) return AGX_ERR_HIP;
-        if (hipHostMalloc((void **)&det->h_tail_table, F * 4 * sizeof(uint32_t), hipHostMallocMapped) != hipSuccess) return AGX_ERR_HIP;
-        if (hipHostGetDevicePointer((void **)&det->h_tags_dev, det->h_tags, 0) != hipSuccess) return AGX_ERR_HIP;
-        if (hipHostGetDevicePointer((void **)&det->h_tail_table_dev, det->h_tail_table, 0) != hipSuccess) return AGX_ERR_HIP;
+        det->tail_frames = 0;  // (nothing usable until both tables exist)
+        det->tail_tag_cap = 0;
+        det->h_tags = static_cast<agx_tag *>(side_alloc(det, agx_detector::SB_TAGS, F * cap * sizeof(agx_tag), 2));
+        det->h_tail_table = static_cast<uint32_t *>(side_alloc(det, agx_detector::SB_TAIL_TABLE, F * 4 * sizeof(uint32_t), 2));
+        if (!det->h_tags || !det->h_tail_table) {
+            side_free(det, agx_detector::SB_TAGS);
+            side_free(det, agx_detector::SB_TAIL_TABLE);
+            det->h_tags = det->h_tags_dev = nullptr;
+            det->h_tail_table = det->h_tail_table_dev = nullptr;
+            return AGX_ERR_HIP;
+        }
+        det->h_tags_dev = static_cast<agx_tag *>(det->side[agx_detector::SB_TAGS].dev);
+        det->h_tail_table_dev = static_cast<uint32_t *>(det->side[agx_detector::SB_TAIL_TABLE].dev);
         det->tail_frames = F;
         det->tail_tag_cap = (uint32_t)cap;
     }
@@ -677,7 +749,9 @@ __attribute__((visibility("hidden"))) int agx_internal_enqueue_tail(agx_detector
     t.max_boards = det->params.max_num_of_boards;
     t.tags = det->h_tags_dev;
     t.table = det->h_tail_table_dev;
-    t.tag_cap = det->tail_tag_cap;
+    t.tag_cap = tag_cap;  // this call's: a frame with more tags is handed back (TAIL_CAPACITY), whatever the table could hold
+    t.tag_stride = det->tail_tag_cap;
+    t.debug_band = (float)det->tail_debug_band_mdeg * 1e-3f;
     t.debug = tuning_env("AGX_TAIL_DEBUG", 0);
     t.debug_frame = tuning_env("AGX_TAIL_DEBUG_FRAME", 0);
     if (launch_board_tail(t, det->stream) != 0) return AGX_ERR_HIP;
@@ -704,10 +778,9 @@ __attribute__((visibility("hidden"))) void *agx_internal_stage(agx_detector *det
 {
     if (bytes > det->stage_bytes) {
         if (hipSetDevice(det->device) != hipSuccess || hipStreamSynchronize(det->stream) != hipSuccess) return nullptr;
-        if (det->d_stage) (void)hipFree(det->d_stage);
-        det->d_stage = nullptr;
         det->stage_bytes = 0;
-        if (hipMalloc((void **)&det->d_stage, bytes) != hipSuccess) return nullptr;
+        det->d_stage = static_cast<uint8_t *>(side_alloc(det, agx_detector::SB_STAGE, bytes, 0));
+        if (!det->d_stage) return nullptr;
         det->stage_bytes = bytes;
     }
     return det->d_stage;
@@ -835,13 +908,8 @@ void agx_detector_destroy(agx_detector *det)
     free_workspace(det);
     if (det->pool) destroy_worker_pool(det->pool);
     if (det->tail_workers) destroy_tail_workers(det->tail_workers);
-    if (det->d_stage) (void)hipFree(det->d_stage);
-    if (det->d_luma) (void)hipFree(det->d_luma);
-    if (det->h_luma) (void)hipHostFree(det->h_luma);
+    for (int i = 0; i < agx_detector::SB_COUNT; ++i) side_free(det, i);  // staging, luma planes, the device tail's buffers
     if (det->h_table) (void)hipHostFree(det->h_table);
-    if (det->d_codes) (void)hipFree(det->d_codes);
-    if (det->h_tags) (void)hipHostFree(det->h_tags);
-    if (det->h_tail_table) (void)hipHostFree(det->h_tail_table);
     if (det->d_dbg_resp) (void)hipFree(det->d_dbg_resp);
     if (det->d_resp_store) (void)hipFree(det->d_resp_store);
     for (int i = 0; i < AGX_UPLOAD_STREAMS; ++i)
@@ -912,6 +980,7 @@ int agx_detector_set_option(agx_detector *det, const char *name, int value)
         }
         det->device_tail = value > 0 ? 1 : (value < 0 ? -1 : 0);
     }
+    else if (!std::strcmp(name, "tail_debug_band")) det->tail_debug_band_mdeg = value > 0 ? std::min(value, 30000) : 0;  // tests: thousandths of a degree
     else if (!std::strcmp(name, "reload_tuning_env")) tuning_env_reload();  // (process-wide: the AGX_* overrides are read again)
     else if (!std::strcmp(name, "tail_threads")) {
         const int n = value < 1 ? 1 : (value > 64 ? 64 : value);
@@ -937,6 +1006,7 @@ int agx_detector_get_option(const agx_detector *det, const char *name, int *valu
     else if (!std::strcmp(name, "debug_ablation")) *value = det->dbg;
     else if (!std::strcmp(name, "tail_threads")) *value = det->tail_threads;
     else if (!std::strcmp(name, "device_tail")) *value = det->device_tail;  // (-1: by the batch's size, where available)
+    else if (!std::strcmp(name, "tail_debug_band")) *value = det->tail_debug_band_mdeg;
     else if (!std::strcmp(name, "last_device_tail_frames")) *value = det->last_tail_frames;
     else if (!std::strcmp(name, "last_device_tail_fallbacks")) *value = det->last_tail_fallbacks;
     else if (!std::strcmp(name, "last_device_tail_uncertain")) *value = det->last_tail_uncertain;  // (of them: an angle inside its guard band)
@@ -1160,10 +1230,9 @@ int refined_saddle_points_impl(agx_detector *det, const void *pixels, int width,
     const size_t need = pitch * (size_t)height;
     if (need > det->stage_bytes) {
         HIP_TRY(det, hipStreamSynchronize(det->stream));
-        if (det->d_stage) (void)hipFree(det->d_stage);
-        det->d_stage = nullptr;
         det->stage_bytes = 0;
-        HIP_TRY(det, hipMalloc((void **)&det->d_stage, need));
+        det->d_stage = static_cast<uint8_t *>(side_alloc(det, agx_detector::SB_STAGE, need, 0));
+        if (!det->d_stage) return fail(det, AGX_ERR_HIP, "hipMalloc: staging buffer");
         det->stage_bytes = need;
     }
     HIP_TRY(det, hipMemcpy2DAsync(det->d_stage, pitch, pixels, row_stride_bytes, row_bytes, (size_t)height,
@@ -1174,12 +1243,10 @@ int refined_saddle_points_impl(agx_detector *det, const void *pixels, int width,
         const size_t lb = (size_t)width * (size_t)height;
         if (lb > det->luma_bytes) {
             HIP_TRY(det, hipStreamSynchronize(det->stream));
-            if (det->d_luma) (void)hipFree(det->d_luma);
-            if (det->h_luma) (void)hipHostFree(det->h_luma);
-            det->d_luma = det->h_luma = nullptr;
             det->luma_bytes = 0;
-            HIP_TRY(det, hipMalloc((void **)&det->d_luma, lb));
-            HIP_TRY(det, hipHostMalloc((void **)&det->h_luma, lb, hipHostMallocDefault));
+            det->d_luma = static_cast<uint8_t *>(side_alloc(det, agx_detector::SB_LUMA_D, lb, 0));
+            det->h_luma = static_cast<uint8_t *>(side_alloc(det, agx_detector::SB_LUMA_H, lb, 1));
+            if (!det->d_luma || !det->h_luma) return fail(det, AGX_ERR_HIP, "hipMalloc / hipHostMalloc: luma planes");
             det->luma_bytes = lb;
         }
         hipError_t e = (hipError_t)launch_luma8(det->d_stage, pitch, need, 1, format, det->d_luma, width, height, det->stream);
@@ -1428,10 +1495,58 @@ int agx_detector_constants(const agx_detector *det, float *blur_w7, float *cone2
     });
 }
 
+namespace {
+// AGX_DBG_REDZONES: {buffers, damaged guard bytes, first damaged buffer, its offset (from the payload start, as int32),
+// device address of buffer 0's payload (lo, hi)}.  Buffers = the chain's workspace in allocation order, then the side
+// buffers that exist (staging, luma planes, the device tail's code list / tag rows / frame table) -- the last three in
+// mapped pinned HOST memory, whose guards are read in place.
+int fetch_redzones(agx_detector *det, void *host_out, size_t cap_bytes, size_t *n_items)
+{
+    *n_items = 6;
+    if (cap_bytes < 6 * sizeof(uint32_t)) return AGX_ERR_CAPACITY;
+    HIP_TRY(det, hipSetDevice(det->device));
+    HIP_TRY(det, hipStreamSynchronize(det->stream));
+    const size_t rz = det->redzone;
+    const uint64_t first_payload = det->device_allocs.empty() ? 0ull : (uint64_t)(uintptr_t)((char *)det->device_allocs[0] + rz);
+    uint32_t v[6] = {0u, 0u, 0xffffffffu, 0u, (uint32_t)first_payload, (uint32_t)(first_payload >> 32)};
+    std::vector<uint8_t> zone(rz);
+    auto check = [&](const void *base, size_t bytes, bool host) -> int {
+        const uint32_t index = v[0]++;
+        for (int side = 0; rz && side < 2; ++side) {
+            const char *src = (const char *)base + (side ? rz + bytes : 0);
+            if (host) std::memcpy(zone.data(), src, rz);
+            else HIP_TRY(det, hipMemcpy(zone.data(), src, rz, hipMemcpyDeviceToHost));
+            for (size_t b = 0; b < rz; ++b)
+                if (zone[b] != 0xA5 && v[1]++ == 0) {
+                    v[2] = index;
+                    v[3] = (uint32_t)(int32_t)(side ? (long long)(bytes + b) : (long long)b - (long long)rz);
+                }
+        }
+        return AGX_OK;
+    };
+    for (size_t i = 0; i < det->device_allocs.size(); ++i)
+        if (int rc = check(det->device_allocs[i], det->alloc_bytes[i], false)) return rc;
+    for (const agx_detector::SideBuf &b : det->side)
+        if (b.base)
+            if (int rc = check(b.base, b.bytes, b.host)) return rc;
+    std::memcpy(host_out, v, sizeof v);
+    return AGX_OK;
+}
+}  // namespace
+
 int agx_debug_fetch(agx_detector *det, int frame, int what, void *host_out, size_t cap_bytes, size_t *n_items)
 {
     return agx_guard(det, [&]() -> int {
     if (!det || !host_out || !n_items) return fail(det, AGX_ERR_ARG, "null argument");
+    if (what == AGX_DBG_REDZONES) return fetch_redzones(det, host_out, cap_bytes, n_items);  // (no batch needed: agx_detect_batch leaves none)
+    if (what == AGX_DBG_TAIL_TABLE_ADDR) {  // tests of the guard check: {host address, payload bytes} of the device tail's frame table
+        *n_items = 2;
+        if (cap_bytes < 2 * sizeof(uint64_t)) return AGX_ERR_CAPACITY;
+        if (!det->h_tail_table) return fail(det, AGX_ERR_STATE, "no device tail has run on this handle");
+        const uint64_t v[2] = {(uint64_t)(uintptr_t)det->h_tail_table, (uint64_t)det->side[agx_detector::SB_TAIL_TABLE].bytes};
+        std::memcpy(host_out, v, sizeof v);
+        return AGX_OK;
+    }
     if (!det->enqueued) return fail(det, AGX_ERR_STATE, "no batch enqueued");
     const ChainArgs &a = det->args;
     if (frame < 0 || frame >= a.n_frames) return fail(det, AGX_ERR_ARG, "frame out of range");
@@ -1487,29 +1602,6 @@ int agx_debug_fetch(agx_detector *det, int frame, int what, void *host_out, size
         if (!det->h_luma || det->luma_bytes < lb) return fail(det, AGX_ERR_STATE, "no device luma: agx_detect on an L16 / RGB8 image first");
         if (cap_bytes < lb) return AGX_ERR_CAPACITY;
         std::memcpy(host_out, det->h_luma, lb);
-        return AGX_OK;
-    }
-    case 8: {  // AGX_DBG_REDZONES: {buffers, damaged guard bytes, first damaged buffer, its offset (from the payload
-               // start, as int32), device address of buffer 0's payload (lo, hi)}
-        *n_items = 6;
-        if (cap_bytes < 6 * sizeof(uint32_t)) return AGX_ERR_CAPACITY;
-        const size_t rz = det->redzone;
-        const uint64_t first_payload = det->device_allocs.empty() ? 0ull : (uint64_t)(uintptr_t)((char *)det->device_allocs[0] + rz);
-        uint32_t v[6] = {(uint32_t)det->device_allocs.size(), 0u, 0xffffffffu, 0u, (uint32_t)first_payload, (uint32_t)(first_payload >> 32)};
-        std::vector<uint8_t> zone(rz);
-        for (size_t i = 0; rz && i < det->device_allocs.size(); ++i)
-            for (int side = 0; side < 2; ++side) {
-                const char *src = (const char *)det->device_allocs[i] + (side ? rz + det->alloc_bytes[i] : 0);
-                HIP_TRY(det, hipMemcpy(zone.data(), src, rz, hipMemcpyDeviceToHost));
-                for (size_t b = 0; b < rz; ++b)
-                    if (zone[b] != 0xA5) {
-                        if (v[1]++ == 0) {
-                            v[2] = (uint32_t)i;
-                            v[3] = (uint32_t)(int32_t)(side ? (long long)(det->alloc_bytes[i] + b) : (long long)b - (long long)rz);
-                        }
-                    }
-            }
-        std::memcpy(host_out, v, sizeof v);
         return AGX_OK;
     }
     case 10: {  // wave timeline (debug_ablation & 4096): `frame` selects the kernel (1 = verify, 2 = flood, 3 = refine);

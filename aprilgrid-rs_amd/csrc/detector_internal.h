@@ -28,8 +28,10 @@ int agx_internal_chunk_luma8(agx_detector *det, const void *d_frames, int n_fram
 // counts / offsets / status; waits for the device
 int agx_internal_fetch_compact(agx_detector *det, const agx_saddle **records, uint32_t *counts, uint32_t *offsets, int *status);
 // option "device_tail": board search + decode of the enqueued batch on the device (tail_kernels.hip); the results in mapped
-// pinned host memory after agx_internal_fetch_tail: tags[f * tag_cap ..], table[4 f] = count, table[4 f + 1] = agx::TAIL_* status (+ 2: the frame's 100 MHz ticks, + 3: saddles | seeds << 16)
+// pinned host memory after agx_internal_fetch_tail: tags[f * *tag_cap ..] (the rows' stride, >= the cap that was enqueued), table[4 f] = count, table[4 f + 1] = agx::TAIL_* status (+ 2: the frame's 100 MHz ticks, + 3: saddles | seeds << 16)
 int agx_internal_device_tail(agx_detector *det);
+int agx_internal_tail_prepare(agx_detector *det);  // one-time set-up on the handle's device (code list, kernel attributes): all or nothing
+int agx_internal_tail_debug(const agx_detector *det);  // AGX_TAIL_DEBUG as read when the handle was created
 int agx_internal_enqueue_tail(agx_detector *det, const void *d_luma, size_t luma_row_stride, size_t luma_frame_stride, uint32_t tag_cap);
 int agx_internal_fetch_tail(agx_detector *det, const agx_tag **tags, const uint32_t **table, uint32_t *tag_cap);
 void agx_internal_tail_stats(agx_detector *det, int frames, int fallbacks, int uncertain);

@@ -34,10 +34,14 @@ struct TailArgs {
     int edge, border, hamming, n_codes;
     const uint64_t *codes;  // device copy of the family's code list
     int max_boards;
-    // results: tags[f][tag_cap], table[f] = {count, status, ticks (100 MHz) the frame took, saddles | seeds << 16}
+    // results: tags[f][tag_stride] (at most tag_cap of them written: more is TAIL_CAPACITY), table[f] = {count, status,
+    // ticks (100 MHz) the frame took, saddles | seeds << 16}
     agx_tag *tags;
     uint32_t *table;
-    uint32_t tag_cap;
+    uint32_t tag_cap, tag_stride;
+    // option "tail_debug_band" (tests of the hand-back path): a white-block angle within this many degrees of 60 / 120 is
+    // reported undecided whatever the exact evaluation would say (0 = off: only the kernel's own guard band)
+    float debug_band;
     int debug;  // AGX_TAIL_DEBUG >= 2 (and a build with -DAGX_TAIL_TIMERS): frame debug_frame's first wave prints where its time went (100 MHz ticks)
     int debug_frame;  // AGX_TAIL_DEBUG_FRAME (default 0)
 };

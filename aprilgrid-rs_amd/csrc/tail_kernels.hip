@@ -222,6 +222,12 @@ __device__ __forceinline__ int white_block(float s0_theta, float v02x, float v02
         sincosf(th, &sf, &cf);
         {  // degrees away from both thresholds: from the coarse angle (this device's sincosf adds 2e-5 degrees to its 0.04)
             const float ac = fabsf(angle_coarse(v02x, v02y, cf, sf));
+            {  // (tests only, TailArgs::debug_band: a wide band so that a known share of frames takes the hand-back path; the
+               // value lies in the frame's shared words -- sh[4] -- so that no register carries it through the search)
+                extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+                const float debug_band = *reinterpret_cast<const float *>(lds + OFF_SHARED + 4 * 4);
+                if (debug_band > 0.0f && (fabsf(ac - 60.0f) <= debug_band || fabsf(ac - 120.0f) <= debug_band)) return 2;
+            }
             if (ac < 60.0f - kCoarseBand || ac > 120.0f + kCoarseBand) return 0;
             if (ac > 60.0f + kCoarseBand && ac < 120.0f - kCoarseBand) return 1;
         }
@@ -966,7 +972,7 @@ __global__ void __launch_bounds__(64 * TW) k_board_tail(TailArgs a)
     uint32_t *tagids = reinterpret_cast<uint32_t *>(lds + OFF_TAGIDS);
     uint32_t *used = reinterpret_cast<uint32_t *>(lds + OFF_USED);
     uint32_t *hist = reinterpret_cast<uint32_t *>(lds + OFF_HIST);
-    uint32_t *sh = reinterpret_cast<uint32_t *>(lds + OFF_SHARED);  // [0] status, [1] n, [2] seeds, [3] saddles removed, [5 .. 7] where the chosen board is kept, [8 ..) the groups' words (two sets)
+    uint32_t *sh = reinterpret_cast<uint32_t *>(lds + OFF_SHARED);  // [0] status, [1] n, [2] seeds, [3] saddles removed, [4] debug band, [5 .. 7] where the chosen board is kept, [8 ..) the groups' words (two sets)
     uint8_t *wv = lds + OFF_WAVES + wave * WV_BYTES;  // this wave's own
 
     uint32_t status = 0;  // per lane; merged through sh[0]
@@ -991,7 +997,7 @@ __global__ void __launch_bounds__(64 * TW) k_board_tail(TailArgs a)
         }
         return;
     }
-    if (tid < 8 + 6 * TW) sh[tid] = 0;
+    if (tid < 8 + 6 * TW) sh[tid] = tid == 4 ? __float_as_uint(a.debug_band) : 0u;  // ([4]: white_block's debug band)
     int group_no = 0;  // (counts the groups of seeds over all rounds)
     u64 *codes = reinterpret_cast<u64 *>(lds + OFF_CODES);
     for (int i = tid; i < a.n_codes && i < TCODES; i += 64 * TW) codes[i] = a.codes[i];
@@ -1372,7 +1378,7 @@ __global__ void __launch_bounds__(64 * TW) k_board_tail(TailArgs a)
                 if (is_new) tagids[at] = (uint32_t)id;
                 if (id >= 0) {
                     if (last == lane) {
-                        agx_tag *o = a.tags + (size_t)f * a.tag_cap + at;
+                        agx_tag *o = a.tags + (size_t)f * a.tag_stride + at;
                         o->id = (uint32_t)id;
                         for (int i = 0; i < 8; ++i) o->xy[i] = dec_xy[8 * qi + i];
                     }

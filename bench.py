@@ -623,26 +623,16 @@ class CudaRuntime:
 
 
 def visible_gpus():
-    """GPUs this process would see, counted WITHOUT initialising HIP here (the parent of the ranks must never touch the
-    GPU): KFD topology nodes with SIMDs, cut down by *_VISIBLE_DEVICES.  None when sysfs does not say (no KFD)."""
-    import glob
-    n = 0
-    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
-    if not nodes:
+    """GPUs a rank would see, counted WITHOUT initialising HIP in this process (the parent of the ranks must never touch the
+    GPU): a short-lived child asks torch.  (The KFD topology in sysfs is no substitute: a container shows every GPU of the host
+    there, also those its device cgroup hides.)  None when the child cannot say."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True,
+                           timeout=600, cwd=ROOT)
+        return int(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else None
+    except (OSError, ValueError, IndexError, subprocess.TimeoutExpired):
         return None
-    for p in nodes:
-        try:
-            with open(p) as f:
-                props = dict(l.split()[:2] for l in f if len(l.split()) >= 2)
-        except OSError:
-            return None  # (a node this user may not read: let the ranks find out)
-        if int(props.get("simd_count", "0")) > 0:
-            n += 1
-    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
-        v = os.environ.get(var)
-        if v is not None:
-            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
-    return n
 
 
 def launch_ranks(args, argv):
@@ -656,7 +646,7 @@ def launch_ranks(args, argv):
     if not stub:
         seen = visible_gpus()
         if seen is not None and seen < args.gpus:
-            print("bench.py: --gpus %d but %d GPU%s visible on this node (KFD topology, *_VISIBLE_DEVICES applied)"
+            print("bench.py: --gpus %d but %d GPU%s visible to a rank on this node (torch.cuda.device_count() in a child process)"
                   % (args.gpus, seen, "" if seen == 1 else "s"), file=sys.stderr)
             return 2
     s = socket.socket()

@@ -146,6 +146,10 @@ int agx_detector_set_limits(agx_detector *det, uint32_t max_candidates, uint32_t
  *                          within 1e-4 degrees of the white-block thresholds, saddle.rs:26-38) or hold (more than 1024 saddles,
  *                          128 board cells ...) is handed to the host tail.  Read back: "last_device_tail_frames",
  *                          "last_device_tail_fallbacks", "last_device_tail_uncertain" of the last agx_detect_batch call
+ *   "tail_debug_band"      test hook of the hand-back path: n > 0 makes the device tail treat a white-block angle within n / 1000
+ *                          degrees of 60 / 120 as undecided (the kernel's own band is 1e-4 degrees, which the suite's frames never
+ *                          hit), so that a known share of frames takes the host tail; results unchanged
+ *                          (tests/test_gpu_device_tail.py).  0 (default) = off
  *   "debug_ablation"       measurement switches of the kernels (tools/): bits 1 .. 1024 remove parts of the blur kernel's
  *                          work -- timing experiments, results are INVALID; bits 128 / 2048 / 8192 / 16384 collect
  *                          statistics and phase times (AGX_DBG_VERIFY_STATS), 4096 the start and end of every wave of
@@ -357,10 +361,14 @@ enum { AGX_DBG_BLUR = 0, AGX_DBG_RESP = 1, AGX_DBG_MIN = 2, AGX_DBG_CENTERS = 3,
        AGX_DBG_WAVE_TIMES = 10, /* pairs of uint64 (start, end; 10 ns ticks of s_memrealtime) of every wave of one sparse
                                    kernel of the last batch; `frame` selects the kernel (1 verify, 2 flood + refine, 3 rare);
                                    needs debug_ablation & 4096 (tools/wave_timeline.py) */
-       AGX_DBG_REDZONES = 8 /* 6 x uint32: workspace buffers, damaged guard bytes, first damaged buffer, its byte
+       AGX_DBG_REDZONES = 8, /* 6 x uint32: guarded buffers, damaged guard bytes, first damaged buffer, its byte
                                offset from the payload start (int32), device address of buffer 0 (lo, hi: for the
-                               check of the check).  Guard bytes exist only in handles created with
-                               AGX_REDZONE_BYTES=<n> in the environment (memory-safety tests of the kernels) */ };
+                               check of the check).  Buffers = the chain's workspace, then the staging buffer, the luma
+                               planes and the device tail's code list, tag rows and frame table (mapped pinned host memory)
+                               as far as they exist.  Needs no enqueued batch.  Guard bytes exist only in handles created with
+                               AGX_REDZONE_BYTES=<n> in the environment (memory-safety tests of the kernels) */
+       AGX_DBG_TAIL_TABLE_ADDR = 11 /* 2 x uint64: host address and payload bytes of the device tail's frame table (the check
+                                       of the check for a buffer in mapped host memory).  Needs no enqueued batch */ };
 typedef struct agx_cluster_info {
     uint32_t first_index, size;
     float cx, cy;

@@ -2,7 +2,8 @@
 guard bytes (0xA5) in front of and behind every workspace buffer; after each workload -- the paths
 where an index could run away: list overflows, the generic clustering path, oversized components,
 rows that are not 4-byte aligned (dummy-row stores), lists beyond the LDS sort, tiny frames, every
-segment height -- the guards must be intact (agx_debug_fetch AGX_DBG_REDZONES) and the results still
+segment height, and agx_detect_batch's device tail (its code list, its tag rows and frame table in
+mapped pinned host memory, the staging and luma planes carry the same guards) -- the guards must be intact (agx_debug_fetch AGX_DBG_REDZONES) and the results still
 equal the oracle's."""
 import os
 
@@ -163,3 +164,110 @@ def test_lists_beyond_the_lds_sort(gdet, oracle):
     fr, _ = synth.render_batch(3, 1, 2048, 1536, device="cuda", pure_noise=True)
     res, status = _run(gdet, oracle, fr, fr.cpu().numpy(), "2048x1536 noise", n_check=1)
     assert len(res[0]) > 16384
+
+
+def _tail_buffers_intact(det, what, at_least):
+    r = det.debug_fetch(0, "redzones")
+    assert r["buffers"] >= at_least, (what, r)
+    assert r["damaged_bytes"] == 0, "%s: %s" % (what, r)
+    return r["buffers"]
+
+
+def test_the_device_tail_stays_inside_its_buffers(oracle):
+    """agx_detect_batch with the board search + decode on the device: the kernel writes tags and the frame table straight into
+    mapped pinned host memory and reads the family's code list, the staged frames and (L16 / RGB8) the luma planes -- all of
+    them allocated with the handle's guard bytes.  Workloads: the benchmark's frames, frames of > 512 saddles, 10 x 10 boards
+    (handed back), a tag capacity too small for the frame's tags, L16 / RGB8 chunks, a call of several 1024-frame chunks on two
+    host threads, the wide debug band (hand-backs that read the compact saddle list).  Guards intact, tags the host tail's."""
+    import aprilgrid_rs_amd as A
+    from tests.util import check_tags, oracle_detect_parallel
+    synth = synth_module()
+    d = _guarded_detector()
+    d.set_option("device_tail", 1)
+    host = A.TagDetector("t36h11", None, device=0)
+    host.set_option("device_tail", 0)
+
+    def both(frames, what, cap=128, threads=0, **kw):
+        rc_h, out_h, cnt_h, st_h = host.detect_batch_raw(frames, n_threads=threads, cap=cap, **kw)
+        rc_d, out_d, cnt_d, st_d = d.detect_batch_raw(frames, n_threads=threads, cap=cap, **kw)
+        assert rc_h == rc_d and np.array_equal(st_h, st_d) and np.array_equal(cnt_h, cnt_d), what
+        for f in range(len(frames)):
+            if st_h[f] == 0:
+                assert out_h[f, : cnt_h[f]].tobytes() == out_d[f, : cnt_d[f]].tobytes(), "%s frame %d" % (what, f)
+        assert d.get_option("last_device_tail_frames") == len(frames)
+        return cnt_d, st_d
+
+    # the benchmark's frames (host memory in: the staging buffer; a device copy as well)
+    fr, _ = synth.render_batch(0, 64, 1280, 800, device="cuda")
+    frames = fr.cpu().numpy()
+    cnt, _ = both(frames, "bench frames")
+    n0 = _tail_buffers_intact(d, "bench frames", 24)  # workspace + staging + code list + tag rows + frame table
+    both(frames, "bench frames from a device copy", device_frames=fr)
+    _tail_buffers_intact(d, "bench frames, device copy", n0)
+    refs = oracle_detect_parallel(oracle, frames[:8], threads=8)
+    got = d.detect_batch(frames[:8], n_threads=2)
+    for i in range(8):
+        check_tags(got[i], refs[i], "guarded handle, bench frame %d" % i)
+    # the caller's tag capacity below the frames' tags: the rows of the table keep their stride, nothing is written past cap
+    cap = int(cnt.max()) - 3
+    _, st = both(frames[:32], "capacity", cap=cap)
+    assert (st != 0).any()
+    _tail_buffers_intact(d, "tag capacity too small", n0)
+    # > 512 saddles per frame; 10 x 10 boards (more cells than the kernel's board holds: handed back)
+    a = synth.render_batch(500, 24, 640, 480, device="cuda")[0].cpu().numpy()
+    wide = np.ascontiguousarray(np.concatenate([a[0::3], a[1::3], a[2::3]], axis=2))
+    both(wide, "> 512 saddles")
+    _tail_buffers_intact(d, "> 512 saddles", n0)
+    big = np.stack([synth.render_frame(5 + i, 1280, 800, spec=synth.BoardSpec(rows=10, cols=10))[0].numpy() for i in range(3)])
+    both(big, "10 x 10 boards", cap=256)
+    assert d.get_option("last_device_tail_fallbacks") == 3
+    _tail_buffers_intact(d, "10 x 10 boards", n0)
+    # L16 / RGB8: the device's luma planes join the guarded buffers
+    for fmt in ("L16", "RGB8"):
+        f = synth.render_batch(300, 40, 320, 240, device="cuda", fmt=fmt)[0].cpu().numpy()
+        if fmt == "L16":
+            f = f.view(np.uint16)
+        both(f, fmt)
+        _tail_buffers_intact(d, fmt, n0 + 1)
+    # pure noise (every frame beyond the kernel's saddle list) and frames with nothing in them
+    noise = synth.render_batch(3, 3, 640, 480, device="cuda", pure_noise=True)[0].cpu().numpy()
+    both(np.concatenate([noise, np.full((2, 480, 640), 128, np.uint8)]), "noise and flat frames")
+    _tail_buffers_intact(d, "noise and flat frames", n0)
+    # several chunks (2 150 frames = three of up to 1 024) on two host threads, the staging slots in turn
+    small = synth.render_batch(1200, 96, 320, 240, device="cuda")[0].cpu().numpy()
+    many = np.concatenate([small] * 23)[:2150]
+    rc, out, cnt_m, st_m = d.detect_batch_raw(many, n_threads=2, cap=64)
+    rc_h, out_h, cnt_h, _ = host.detect_batch_raw(small, n_threads=4, cap=64)
+    assert rc == 0 == rc_h and d.get_option("last_device_tail_frames") == 2150
+    for f in range(2150):
+        assert cnt_m[f] == cnt_h[f % 96] and out[f, : cnt_m[f]].tobytes() == out_h[f % 96, : cnt_h[f % 96]].tobytes(), f
+    _tail_buffers_intact(d, "2 150 frames in three chunks", n0)
+    # the hand-back path on purpose (frames that read the chain's compact list on the host)
+    d.set_option("tail_debug_band", 50)
+    both(frames, "wide debug band")
+    assert d.get_option("last_device_tail_uncertain") > 0
+    _tail_buffers_intact(d, "wide debug band", n0)
+    d.set_option("tail_debug_band", 0)
+    d.close()
+    host.close()
+
+
+def test_a_write_into_a_tail_buffers_guard_is_seen():
+    """The check covers the side buffers: a byte written behind the device tail's frame table (mapped pinned host memory) is
+    reported with that buffer's number."""
+    import ctypes as C
+    synth = synth_module()
+    d = _guarded_detector()
+    d.set_option("device_tail", 1)
+    frames = synth.render_batch(300, 8, 320, 240, device="cuda")[0].cpu().numpy()
+    d.detect_batch(frames, n_threads=2)
+    r = d.debug_fetch(0, "redzones")
+    assert r["damaged_bytes"] == 0 and r["buffers"] >= 24
+    n = C.c_size_t(0)
+    addr = np.zeros(2, np.uint64)
+    # (debug item 11: host address and payload bytes of the device tail's frame table)
+    d._check(d._lib.agx_debug_fetch(d._h, 0, 11, addr.ctypes.data, addr.nbytes, C.byref(n)))
+    C.memset(int(addr[0]) + int(addr[1]) + 5, 0, 2)  # two bytes of the guard behind the table
+    r = d.debug_fetch(0, "redzones")
+    assert r["damaged_bytes"] == 2 and r["first_buffer"] == r["buffers"] - 1 and r["first_offset"] == int(addr[1]) + 5, r
+    d.close()

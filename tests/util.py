@@ -83,3 +83,18 @@ def oracle_saddles_parallel(O, frames_host, threads=8, params=None):
     O.lib()
     with ThreadPoolExecutor(threads) as ex:
         return list(ex.map(lambda f: O.refined_saddle_points(f, params=params), frames_host))
+
+
+def oracle_detect_parallel(O, frames_host, threads=8, family="T36H11", params=None):
+    """Oracle detect() maps of many frames (ctypes releases the GIL: frame-parallel)."""
+    from concurrent.futures import ThreadPoolExecutor
+    O.lib()
+    with ThreadPoolExecutor(threads) as ex:
+        return list(ex.map(lambda f: O.detect(f, family=family, params=params), frames_host))
+
+
+def check_tags(got, ref, what=""):
+    """One frame's {id: 4x2 corners}: the oracle's ids, the oracle's corners bit for bit."""
+    assert sorted(got) == sorted(ref), "%s: ids %s vs oracle %s" % (what, sorted(got), sorted(ref))
+    for t in ref:
+        assert bits_equal(got[t], ref[t]), "%s: corners of tag %d" % (what, t)
