@@ -82,6 +82,28 @@ def test_fixture_images_detect(det, oracle, name, expected):
         assert bits_equal(tags[tid], ref[tid]), "corners of tag %d" % tid
 
 
+@pytest.mark.parametrize("name", ALL_IMAGES)
+def test_the_images_own_geometry_through_the_hip_path(det, name):
+    """tests/grid_pins.py through the product: agx_detect, and agx_detect_batch with the board search + decode on the device
+    -- ids exactly 0 .. N-1, convex quads of one winding, every corner within 1 px of one regular planar grid seen through a
+    smooth camera.  No oracle involved: the images themselves are the reference here (tests/test_detector.rs:21-32 asserts len())."""
+    import aprilgrid_rs_amd as A
+    from tests import grid_pins
+    img = load_image(name)
+    expected = dict(REFERENCE_TAG_COUNTS).get(name)
+    r = grid_pins.check_image(name, det.detect(img), img.shape, expected)
+    assert r["camera_max_px"] < 0.75, r
+    d = A.TagDetector("t36h11", None, device=0)
+    d.set_option("device_tail", 1)
+    try:
+        tags = d.detect_batch(img[None], n_threads=2, cap=128)[0]
+        assert d.get_option("last_device_tail_frames") == 1
+        r2 = grid_pins.check_image(name, tags, img.shape, expected)
+        assert r2 == r  # (the same corners, hence the same residuals)
+    finally:
+        d.close()
+
+
 @pytest.mark.parametrize("family", ["T16H5", "T25H7", "T25H9", "T36H11B1"])
 def test_detect_other_tag_families(oracle, family):
     """TagDetector::new with the other families (src/detector.rs:369-405) on boards rendered with their

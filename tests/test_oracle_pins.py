@@ -3,7 +3,7 @@ path, plus implementation-independent ground truth.  CPU only."""
 import numpy as np
 import pytest
 
-from tests.util import REFERENCE_TAG_COUNTS, bits_equal, load_image, synth_module
+from tests.util import ALL_IMAGES, REFERENCE_TAG_COUNTS, bits_equal, load_image, synth_module
 from oracle import oracle as O
 
 
@@ -150,3 +150,46 @@ def test_luma_conversions():
     assert bits_equal(O.luma_f32(g16)[0], (g16[0].astype(np.float32) / np.float32(65535)))
     rgb = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 255]]], np.uint8)
     assert np.array_equal(O.luma_u8(rgb)[0], [54, 182, 18, 255])
+
+
+@pytest.mark.parametrize("name", ALL_IMAGES)
+def test_the_images_own_geometry(name):
+    """What the reference's images say whoever reads them (tests/grid_pins.py): the ids are exactly 0 .. N-1, every tag is a convex
+    quad wound like every other, and all corners of a board lie within 1 px of ONE regular planar grid (pitch 1.3 tag edges, ids
+    row by row) seen through a smooth 14-parameter camera.  The reference asserts len() only (tests/test_detector.rs:21-32)."""
+    from tests import grid_pins
+    img = load_image(name)
+    tags = O.detect(img)
+    r = grid_pins.check_image(name, tags, img.shape, dict(REFERENCE_TAG_COUNTS).get(name))
+    assert r["camera_max_px"] < 0.75 and r["camera_rms_px"] < 0.25, r  # (measured: max 0.12 .. 0.52, rms 0.05 .. 0.18)
+
+
+def test_the_geometry_pin_notices_a_wrong_detector():
+    """The check of the check: one corner moved by 2 px, two tags' ids exchanged, one tag's corners in rotated order, a missing
+    tag -- each is refused."""
+    from tests import grid_pins
+    img = load_image("EuRoC.png")
+    tags = O.detect(img)
+    grid_pins.check_image("EuRoC.png", tags, img.shape, 36)
+
+    def refused(bad):
+        try:
+            grid_pins.check_image("EuRoC.png", bad, img.shape, 36)
+        except AssertionError:
+            return True
+        return False
+
+    moved = {t: c.copy() for t, c in tags.items()}
+    moved[17][2] += np.float32(2.0)
+    assert refused(moved)
+    swapped = dict(tags)
+    swapped[8], swapped[9] = tags[9], tags[8]
+    assert refused(swapped)
+    rotated = dict(tags)
+    rotated[20] = np.roll(tags[20], 1, axis=0)
+    assert refused(rotated)
+    mirrored = dict(tags)
+    mirrored[3] = tags[3][::-1].copy()
+    assert refused(mirrored)
+    missing = {t: c for t, c in tags.items() if t != 35}
+    assert refused(missing)
