@@ -1,5 +1,6 @@
-"""Compare the output of tests/parity_dump.rs (one JSON object per line, printed by the real
-aprilgrid-rs crate) with the golden lists of tests/golden/saddles_<image>.json.  No GPU, no oracle.
+"""Compare the output of bindings/rust/tests/parity_dump.rs (one JSON object per line and
+implementation -- "impl": "crate" = the real aprilgrid-rs crate, "amd" = the same calls through bindings/rust; a line without
+"impl" is the crate's) with the golden lists of tests/golden/saddles_<image>.json.  No GPU, no oracle.
 
     python tools/compare_crate_dump.py crate_dump.jsonl [--strict]
 
@@ -40,7 +41,7 @@ def ulps(a, b):
 
 def compare(dump, gold, out, strict):
     bad = 0
-    name = gold["image"]
+    name = gold["image"] + (" [%s]" % dump["impl"] if "impl" in dump else "")
     ds, gs = dump["saddles"], gold["saddles"]
     if len(ds["x_bits"]) != len(gs["x_bits"]):
         out.append("FAIL %s: %d saddles in the crate's list, %d in the golden list" % (name, len(ds["x_bits"]), len(gs["x_bits"])))
