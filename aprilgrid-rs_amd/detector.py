@@ -294,12 +294,12 @@ class TagDetector:
     def sync(self):
         self._check(self._lib.agx_detector_sync(self._h))
 
-    def _follow_torch_stream(self, frames):
+    def _follow_torch_stream(self, frames=None):
         """Stream-order the chain behind whatever produced `frames`: launch on torch's current
         stream of that device (a detector otherwise uses its own non-blocking stream, which
-        does not wait for work queued on torch's streams)."""
+        does not wait for work queued on torch's streams).  frames None: the detector's own device."""
         import torch
-        s = torch.cuda.current_stream(frames.device).cuda_stream
+        s = torch.cuda.current_stream(frames.device if frames is not None else self.device).cuda_stream
         if getattr(self, "_stream_ptr", "own") != s:
             self.set_stream(s)
 
@@ -341,7 +341,13 @@ class TagDetector:
             out_saddles.shape[0], frame_table.data_ptr()))
         self._batch = None
 
-    def saddles_batch_enqueue_ptr(self, dptr, n, w, h, row_stride, frame_stride, fmt):
+    def saddles_batch_enqueue_ptr(self, dptr, n, w, h, row_stride, frame_stride, fmt, follow_torch_stream=True):
+        """agx_saddles_batch_enqueue on a raw device address (any row / frame stride: a view cut out of a larger allocation).
+        Like the tensor forms it is launched on torch's current stream of the detector's device, behind whatever torch has
+        queued there to produce the frames (and torch events on that stream see the kernels); follow_torch_stream=False keeps
+        the stream the detector is on (its own non-blocking one unless set_stream was called: the caller orders the work)."""
+        if follow_torch_stream:
+            self._follow_torch_stream()
         self._check(self._lib.agx_saddles_batch_enqueue(self._h, C.c_void_p(dptr), n, w, h, row_stride, frame_stride,
                                                         fmt))
         self._batch = (n, None)

@@ -104,6 +104,9 @@ def parse_args(argv=None):
                     help="N > 1: after the timed region, a second, separately reported timed pass with this many steps per collective "
                          "(fewer, larger messages: one rank through nccl pays +18 us per step with 1, +11 with 4, +9 with 8 -- "
                          "profiles/r5_gather_steps.txt); reported as `grouped_gather`, never `value`; 0 = skip")
+    ap.add_argument("--stream-frames", type=int, default=8192,
+                    help="N = 1: frames of the long stream of the detect_end_to_end leg (8192 = 8.4 GB of host memory and as much on the "
+                         "device; halved until it fits a quarter of the host memory this process may still take)")
     ap.add_argument("--pmc-traffic", type=float, default=None,
                     help="HBM bytes per K1 launch from a separate rocprofv3 --pmc run (profiles/)")
     return ap.parse_args(argv)
@@ -288,10 +291,15 @@ def recorded_traffic(key):
     return None, None
 
 
-def extra_leg(torch, A, dev, name, workload, n_frames, width, height, fmt, unique, noise, steps, warmup, verify_n, pitch=None):
+def extra_leg(torch, A, dev, name, workload, n_frames, width, height, fmt, unique, noise, steps, warmup, verify_n, pitch=None,
+              settle_ms=300.0):
     """One extra configuration on its own detector, strictly serial: wall-clock value, per-step
     median, K1 roofline from hipEvents in the timed region, oracle check of the first frames.
-    pitch (L8 only): bytes per row of the device allocation the frames are cut out of (padding after every row)."""
+    pitch (L8 only): bytes per row of the device allocation the frames are cut out of (padding after every row).
+    settle_ms: like the main workload, the leg keeps its chain running about that long, untimed, before its warm-up steps:
+    the legs follow seconds of host-side work (rendering, the oracle check of the previous leg) during which the GPU's clocks
+    fall back, and a timed region of 10 ms right after it read K1 15 - 19 % slower than the same kernel in steady state
+    (profiles/r6_k1_plan_sweep_*.txt against r5's extra_configs)."""
     frames, uniq = make_workload(0, n_frames, width, height, fmt, unique, noise, dev)
     det = A.TagDetector(A.TagFamily.T36H11, None, device=dev.index)
     px = n_frames * width * height
@@ -301,8 +309,17 @@ def extra_leg(torch, A, dev, name, workload, n_frames, width, height, fmt, uniqu
         assert fmt == "L8" and pitch >= width
         padded = torch.full((n_frames, height, pitch), 0xA5, dtype=torch.uint8, device=dev)  # (the padding holds garbage)
         padded[:, :, :width] = frames
+        torch.cuda.synchronize(dev)  # (the fill is done before anything reads the frames, whatever stream the chain is on)
+        # (the raw-address enqueue launches on torch's current stream like the tensor forms: the per-step events below see the kernels)
         enqueue = lambda: det.saddles_batch_enqueue_ptr(padded.data_ptr(), n_frames, width, height, pitch, pitch * height, _ffi.AGX_L8)
     try:
+        enqueue()  # (allocates the workspace)
+        torch.cuda.synchronize(dev)
+        t_settle = time.perf_counter()
+        while (time.perf_counter() - t_settle) * 1e3 < settle_ms:
+            for _ in range(8):
+                enqueue()
+            torch.cuda.synchronize(dev)
         for _ in range(max(warmup, 1) + 2):
             enqueue()
         torch.cuda.synchronize(dev)
@@ -427,7 +444,44 @@ def host_boundary_leg(torch, A, dev, n_frames, width, height, steps):
         torch.cuda.empty_cache()
 
 
-def detect_end_to_end_leg(torch, A, dev, n_frames, width, height, quick=False):
+def host_memory_available():
+    """Bytes of host memory this process may still take: MemAvailable, narrowed by the cgroup's limit (v2 memory.max -
+    memory.current, v1 memory.limit_in_bytes - memory.usage_in_bytes).  Beyond a cgroup limit there is no MemoryError to
+    catch -- the kernel kills the process -- so buffers of several GB are sized from this beforehand."""
+    avail = None
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                avail = int(line.split()[1]) * 1024
+    except OSError:
+        pass
+    for lim, cur in (("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory.current"),
+                     ("/sys/fs/cgroup/memory/memory.limit_in_bytes", "/sys/fs/cgroup/memory/memory.usage_in_bytes")):
+        try:
+            l = open(lim).read().strip()
+            if l != "max" and int(l) < (1 << 60):
+                left = int(l) - int(open(cur).read().strip())
+                avail = left if avail is None else min(avail, left)
+        except (OSError, ValueError):
+            pass
+    return avail
+
+
+def soft_leg(fn, *args, **kw):
+    """A reported-beside leg (never `value`): a failure that is not a parity failure -- out of memory, a HIP error, a refused
+    option -- becomes an "error" field of that leg instead of taking the whole bench line with it.  AssertionErrors (results that
+    differ from the oracle or from another path) stay fatal: a wrong result must not read as a missing measurement."""
+    try:
+        return fn(*args, **kw)
+    except AssertionError:
+        raise
+    except Exception as e:
+        import traceback
+        traceback.print_exc(file=sys.stderr)
+        return {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+
+
+def detect_end_to_end_leg(torch, A, dev, n_frames, width, height, quick=False, stream_frames=8192):
     """TagDetector::detect over the batch, end to end (SURVEY.md 8(d) "what is NOT in t_chain ... reported separately as
     end-to-end frames/s with the host-thread count stated"; reference shape benches/bench_detection.rs:24-36): configs[1]'s
     frames in ordinary (pageable) HOST memory -> agx_detect_batch -> tag ids + corners in host arrays.  Upload, chain, board
@@ -506,11 +560,17 @@ def detect_end_to_end_leg(torch, A, dev, n_frames, width, height, quick=False):
         big = None
         if not quick:
             # a longer stream of frames (the same 256 thirty-two times over: 8 GB of host memory): start-up and drain amortised, and
-            # long enough (several 100 ms scheduler periods) that a CPU quota binds -- the sustained rate
-            try:
-                big = np.concatenate([host] * max(1, 8192 // n_frames))
-            except MemoryError:  # (a host with a tight memory limit: a shorter stream)
-                big = np.concatenate([host] * max(1, 2048 // n_frames))
+            # long enough (several 100 ms scheduler periods) that a CPU quota binds -- the sustained rate.  Sized from the memory
+            # this process may still take (a cgroup limit kills, it does not raise): the stream may use a quarter of it
+            avail = host_memory_available()
+            n_stream = max(n_frames, stream_frames // n_frames * n_frames)
+            while avail is not None and n_stream > n_frames and 4 * n_stream * host[0].nbytes > avail:
+                n_stream //= 2
+            if n_stream >= 4 * n_frames:
+                try:
+                    big = np.concatenate([host] * (n_stream // n_frames))
+                except MemoryError:
+                    big = None
         # ---- the host tail, by thread count --------------------------------------------------------------------------------
         counts_t = [t for t in (1, 2, 4, 8, 16, 32, 64, 128, 256) if t < quota] + [quota]
         if quick:
@@ -1033,23 +1093,23 @@ def main(argv=None):
         result["extra_configs"] = {
             "configs[3]_4K": extra_leg(torch, A, dev, "4K", "configs[3]: 32 synthetic 3840x2160 L8 frames (8 distinct, tiled: "
                                        "rendering a 4K frame costs 8 frames of 1280x800)", 32, 3840, 2160, "L8", 8, False, st,
-                                       args.warmup, 2 * vf),
+                                       args.warmup, 2 * vf, settle_ms=args.settle_ms),
             "configs[4]_RGB8": extra_leg(torch, A, dev, "RGB8", "configs[4]: 256 synthetic 1280x800 RGB8 frames, HWC "
                                          "interleaved as kornia::Image<u8,3> (64 distinct, tiled)", 256, 1280, 800, "RGB8", 64,
-                                         False, st, args.warmup, 64 * vf),
+                                         False, st, args.warmup, 64 * vf, settle_ms=args.settle_ms),
             "L16": extra_leg(torch, A, dev, "L16", "256 synthetic 1280x800 L16 frames (64 distinct, tiled)", 256, 1280, 800,
-                             "L16", 64, False, st, args.warmup, 64 * vf),
+                             "L16", 64, False, st, args.warmup, 64 * vf, settle_ms=args.settle_ms),
             # frames that miss K1's aligned form: a width that is not a multiple of 4, rows that are not 4-byte aligned
             "unaligned_width": extra_leg(torch, A, dev, "1282 wide", "64 synthetic 1282x800 L8 frames, tightly packed (width % 4 = 2: rows start "
-                                         "at odd multiples of 2 bytes; K1's unaligned-dword form)", 64, 1282, 800, "L8", 64, False, st, args.warmup, 4 * vf),
+                                         "at odd multiples of 2 bytes; K1's unaligned-dword form)", 64, 1282, 800, "L8", 64, False, st, args.warmup, 4 * vf, settle_ms=args.settle_ms),
             "unaligned_pitch": extra_leg(torch, A, dev, "pitch 1283", "64 synthetic 1280x800 L8 frames cut out of an allocation with 1283 bytes "
-                                         "per row (odd pitch; K1's unaligned-dword form)", 64, 1280, 800, "L8", 64, False, st, args.warmup, 4 * vf, pitch=1283),
+                                         "per row (odd pitch; K1's unaligned-dword form)", 64, 1280, 800, "L8", 64, False, st, args.warmup, 4 * vf, pitch=1283, settle_ms=args.settle_ms),
             "pure_noise": extra_leg(torch, A, dev, "noise", "sensitivity row: 64 pure-noise 1280x800 L8 frames (16 distinct, "
                                     "tiled; ~7000 saddles per frame: worst case for the sparse stages)", 64, 1280, 800, "L8",
-                                    16, True, st, args.warmup, 4 * vf),
+                                    16, True, st, args.warmup, 4 * vf, settle_ms=args.settle_ms),
         }
-        result["host_boundary"] = host_boundary_leg(torch, A, dev, F, W, H, 20)
-        result["detect_end_to_end"] = detect_end_to_end_leg(torch, A, dev, F, W, H)
+        result["host_boundary"] = soft_leg(host_boundary_leg, torch, A, dev, F, W, H, 20)
+        result["detect_end_to_end"] = soft_leg(detect_end_to_end_leg, torch, A, dev, F, W, H, stream_frames=args.stream_frames)
         # BASELINE.json configs[0] and the reference's own bench shape (benches/bench_detection.rs:24-36): ONE frame
         # through detect -- latency, GPU path beside the oracle on this box's host -- and the 7-image table
         sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -1057,8 +1117,8 @@ def main(argv=None):
         cpu = bench_images.Cpu()
         det1 = A.TagDetector(A.TagFamily.T36H11, None, device=dev.index)
         try:
-            result["extra_configs"]["configs[0]_single_frame"] = bench_images.config0(det1, cpu, 9)
-            result["reference_bench_detection"] = bench_images.detection_table(det1, cpu, 5)
+            result["extra_configs"]["configs[0]_single_frame"] = soft_leg(bench_images.config0, det1, cpu, 9)
+            result["reference_bench_detection"] = soft_leg(bench_images.detection_table, det1, cpu, 5)
         finally:
             det1.close()
     if rank == 0:
