@@ -749,6 +749,11 @@ def main(argv=None):
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import bench_images
         return bench_images.main([])
+    # stdout carries rank 0's ONE JSON line and nothing else: whatever a library prints on file descriptor 1 from here on (RCCL's
+    # five-line version banner at the first collective, for one) goes to stderr; the line itself is written to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -1122,8 +1127,10 @@ def main(argv=None):
         finally:
             det1.close()
     if rank == 0:
-        print(json.dumps(result), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
+    os.close(json_fd)
+    if world > 1 or coll1:
         dist.barrier()
         dist.destroy_process_group()
     return result
