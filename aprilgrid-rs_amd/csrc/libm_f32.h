@@ -13,7 +13,7 @@
 #include <cstdint>
 #include <cstring>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)  // (the header is shared by the HIP kernels and the plain C++ host tail)
 #define AGX_HD __host__ __device__ inline
 #else
 #define AGX_HD inline
