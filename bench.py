@@ -1105,10 +1105,10 @@ def main(argv=None):
             "L16": extra_leg(torch, A, dev, "L16", "256 synthetic 1280x800 L16 frames (64 distinct, tiled)", 256, 1280, 800,
                              "L16", 64, False, st, args.warmup, 64 * vf, settle_ms=args.settle_ms),
             # frames that miss K1's aligned form: a width that is not a multiple of 4, rows that are not 4-byte aligned
-            "unaligned_width": extra_leg(torch, A, dev, "1282 wide", "64 synthetic 1282x800 L8 frames, tightly packed (width % 4 = 2: rows start "
-                                         "at odd multiples of 2 bytes; K1's unaligned-dword form)", 64, 1282, 800, "L8", 64, False, st, args.warmup, 4 * vf, settle_ms=args.settle_ms),
-            "unaligned_pitch": extra_leg(torch, A, dev, "pitch 1283", "64 synthetic 1280x800 L8 frames cut out of an allocation with 1283 bytes "
-                                         "per row (odd pitch; K1's unaligned-dword form)", 64, 1280, 800, "L8", 64, False, st, args.warmup, 4 * vf, pitch=1283, settle_ms=args.settle_ms),
+            "unaligned_width": extra_leg(torch, A, dev, "1282 wide", "256 synthetic 1282x800 L8 frames (64 distinct, tiled), tightly packed (width % 4 = 2: rows start "
+                                         "at odd multiples of 2 bytes; K1's unaligned-dword form; a batch that fills the chip like the headline's)", 256, 1282, 800, "L8", 64, False, st, args.warmup, 4 * vf, settle_ms=args.settle_ms),
+            "unaligned_pitch": extra_leg(torch, A, dev, "pitch 1283", "256 synthetic 1280x800 L8 frames (64 distinct, tiled) cut out of an allocation with 1283 bytes "
+                                         "per row (odd pitch; K1's unaligned-dword form)", 256, 1280, 800, "L8", 64, False, st, args.warmup, 4 * vf, pitch=1283, settle_ms=args.settle_ms),
             "pure_noise": extra_leg(torch, A, dev, "noise", "sensitivity row: 64 pure-noise 1280x800 L8 frames (16 distinct, "
                                     "tiled; ~7000 saddles per frame: worst case for the sparse stages)", 64, 1280, 800, "L8",
                                     16, True, st, args.warmup, 4 * vf, settle_ms=args.settle_ms),

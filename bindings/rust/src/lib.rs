@@ -85,7 +85,7 @@ impl Saddle {
 /// reference derives itself (src/detector.rs:409 `to_luma32f`, :507 `to_luma8`) for every other variant.
 enum Input<'a> {
     Native { px: *const c_void, stride: usize, fmt: c_int, _keep: std::marker::PhantomData<&'a ()> },
-    Planes { f32: image::ImageBuffer<image::Luma<f32>, Vec<f32>>, u8: image::GrayImage },
+    Planes { luma32f: image::ImageBuffer<image::Luma<f32>, Vec<f32>>, luma8: image::GrayImage },
 }
 
 /// A pooled handle; back in the pool when dropped -- also when the closure that used it panics (a handle owns about
@@ -164,7 +164,7 @@ impl TagDetector {
             ImageLuma16(b) => (native(b.as_raw().as_ptr() as *const c_void, 2 * b.width() as usize, ffi::AGX_L16), b.width(), b.height()),
             ImageRgb8(b) => (native(b.as_raw().as_ptr() as *const c_void, 3 * b.width() as usize, ffi::AGX_RGB8), b.width(), b.height()),
             // La8, Rgba8, Rgb16, Rgba16, La16, Rgb32F, Rgba32F: exactly the planes the reference computes
-            other => (Input::Planes { f32: other.to_luma32f(), u8: other.to_luma8() }, other.width(), other.height()),
+            other => (Input::Planes { luma32f: other.to_luma32f(), luma8: other.to_luma8() }, other.width(), other.height()),
         }
     }
 
@@ -173,7 +173,7 @@ impl TagDetector {
         let (inp, w, h) = Self::input(img);
         let (px, stride, fmt) = match &inp {
             Input::Native { px, stride, fmt, .. } => (*px, *stride, *fmt),
-            Input::Planes { f32, .. } => (f32.as_raw().as_ptr() as *const c_void, 4 * w as usize, ffi::AGX_LF32),
+            Input::Planes { luma32f, .. } => (luma32f.as_raw().as_ptr() as *const c_void, 4 * w as usize, ffi::AGX_LF32),
         };
         let mut out = vec![ffi::agx_saddle::default(); 4096];
         let mut n = 0u32;
@@ -207,8 +207,8 @@ impl TagDetector {
                 Input::Native { px, stride, fmt, .. } => {
                     ffi::agx_detect(d, *px, w as c_int, h as c_int, *stride, *fmt, out.as_mut_ptr(), out.len() as u32, &mut n)
                 }
-                Input::Planes { f32, u8 } => ffi::agx_detect_planes(
-                    d, f32.as_raw().as_ptr(), 4 * w as usize, u8.as_raw().as_ptr(), w as usize, w as c_int, h as c_int,
+                Input::Planes { luma32f, luma8 } => ffi::agx_detect_planes(
+                    d, luma32f.as_raw().as_ptr(), 4 * w as usize, luma8.as_raw().as_ptr(), w as usize, w as c_int, h as c_int,
                     out.as_mut_ptr(), out.len() as u32, &mut n,
                 ),
             }
