@@ -3,7 +3,7 @@ path, plus implementation-independent ground truth.  CPU only."""
 import numpy as np
 import pytest
 
-from tests.util import ALL_IMAGES, REFERENCE_TAG_COUNTS, bits_equal, load_image, synth_module
+from tests.util import ALL_IMAGES, REFERENCE_TAG_COUNTS, bits_equal, check_saddles_against_ground_truth, load_image, synth_module
 from oracle import oracle as O
 
 
@@ -136,6 +136,19 @@ def test_synthetic_ground_truth_ids_and_corners():
                 assert np.min(np.hypot(*(gt[tid] - p).T)) < 0.5
         total += len(tags)
     assert total >= 100
+
+
+def test_synthetic_ground_truth_saddles():
+    """The hot path's output against the renderer's own truth: every drawn tag corner inside the frame has a refined saddle of
+    the oracle within 0.3 px (the GPU suite asserts the same of the HIP chain on all 256 bench frames)."""
+    synth = synth_module()
+    dist = []
+    for i in (0, 5, 17):
+        frame, gt = synth.render_frame(i, 1280, 800)
+        s = O.refined_saddle_points(frame.numpy())
+        dist.append(check_saddles_against_ground_truth(np.stack([s["x"], s["y"]], 1), gt, 1280, 800, "frame %d" % i))
+    dist = np.concatenate(dist)
+    assert np.median(dist) < 0.05 and np.percentile(dist, 99) < 0.15, (np.median(dist), np.percentile(dist, 99))
 
 
 def test_flat_image_gives_nothing():

@@ -98,3 +98,16 @@ def check_tags(got, ref, what=""):
     assert sorted(got) == sorted(ref), "%s: ids %s vs oracle %s" % (what, sorted(got), sorted(ref))
     for t in ref:
         assert bits_equal(got[t], ref[t]), "%s: corners of tag %d" % (what, t)
+
+
+def check_saddles_against_ground_truth(saddles_xy, gt, width, height, what="", tol=0.3, margin=6.0):
+    """Implementation-independent check of the hot path: `gt` = {tag id: 4x2 projected corners} of a frame rendered from a
+    known homography (synth.py).  Every drawn tag corner inside the frame (a saddle of the printed pattern: the tag's black
+    border meets the small black square) must have a refined saddle within `tol` px.  Returns the distances."""
+    s = np.asarray(saddles_xy, np.float64)
+    g = np.unique(np.concatenate([gt[t] for t in gt]).round(6), axis=0)
+    g = g[(g[:, 0] > margin) & (g[:, 0] < width - margin) & (g[:, 1] > margin) & (g[:, 1] < height - margin)]
+    assert len(g) >= 100 and len(s) >= len(g), (what, len(g), len(s))
+    d = np.hypot(g[:, None, 0] - s[None, :, 0], g[:, None, 1] - s[None, :, 1]).min(axis=1)
+    assert d.max() < tol, "%s: the corner at %s has no saddle within %.2f px (nearest %.3f)" % (what, g[d.argmax()], tol, d.max())
+    return d
