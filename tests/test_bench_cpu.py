@@ -153,3 +153,35 @@ def test_bench_one_collective_per_step_or_per_three():
         gc = out["gather_check"]
         assert out["n_gpus"] == 3 and gc["ranks"] == 3 and gc["frames"] == 9 and gc["oracle_checked_remote_frames"] == 2
         assert ("%s steps per collective" % k) in out["config"]["parallelism"]
+
+
+def test_soft_legs_record_errors_but_never_hide_a_parity_failure():
+    """bench.soft_leg: a reported-beside leg that fails for a reason other than parity (out of memory, a HIP error, a refused
+    option) becomes an "error" field; an AssertionError -- results that differ from the oracle -- stays fatal."""
+    sys.path.insert(0, ROOT)
+    import bench
+    import pytest
+    assert bench.soft_leg(lambda a, b=1: a + b, 2, b=3) == 5
+
+    def oom():
+        raise MemoryError("no room for the stream")
+
+    def hip():
+        raise RuntimeError("HIP error: out of memory")
+
+    def parity():
+        assert False, "saddle lists differ from the oracle"
+
+    assert bench.soft_leg(oom)["error"].startswith("MemoryError")
+    assert "HIP error" in bench.soft_leg(hip)["error"]
+    with pytest.raises(AssertionError):
+        bench.soft_leg(parity)
+
+
+def test_the_stream_of_the_end_to_end_leg_is_sized_from_the_memory_the_process_may_take():
+    """bench.host_memory_available(): MemAvailable narrowed by the cgroup's limit (a cgroup limit kills, it does not raise)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    avail = bench.host_memory_available()
+    total = next(int(l.split()[1]) * 1024 for l in open("/proc/meminfo") if l.startswith("MemTotal:"))
+    assert avail is not None and 0 < avail <= total
