@@ -301,23 +301,28 @@ static int detect_batch_device_tail(agx_detector *det, const void *frames, const
     // the next, until no released part is left -- then they end.  No task ever waits for another one: a pool of a single
     // thread uploads the parts one by one (a task that waited for "its" turn while lower-numbered parts were still queued
     // behind it deadlocked pools of <= 6 threads on calls of >= 4 chunks).  A chunk's parts are released when its staging
-    // slot is free: the first S chunks at once, chunk ci + S when chunk ci's kernels are through.
+    // slot is free: the first S chunks at once, chunk ci + S when chunk ci's kernels are through.  (Measured on an 8 192-frame
+    // stream, profiles/r6_upload_scheduling_ab.txt: 157.5 ms per call like round 5's gated tasks; with the uploaders waiting for
+    // their stream instead of their own event 170 .. 194 ms.)
     const int P = std::max(1, std::min(6, pool->size()));
     int next_part = 0, released_parts = 0, live_uploaders = 0;  // (guarded by m)
     bool stop_uploads = false;                                   // an error ended the call: nothing more is taken (guarded by m)
     std::vector<int> parts_left;        // per chunk                                   (guarded by m)
     std::vector<char> chunk_failed;     //                                             (guarded by m)
     auto uploader = [&, device, P] {
+        // An uploader waits for ITS copy (an event behind it), not for the stream to run empty: two uploaders share a stream,
+        // and the other one -- and whoever takes the parts after it -- keeps enqueueing behind; waiting for the stream starved
+        // single parts for tens of milliseconds and let later chunks overtake the one the device was waiting for.
+        hipEvent_t mine = nullptr;
+        if (hipSetDevice(device) != hipSuccess || hipEventCreateWithFlags(&mine, hipEventDisableTiming) != hipSuccess) mine = nullptr;  // (then: the stream)
         for (;;) {
-            int idx;
+            int idx = -1;
             {
                 std::lock_guard<std::mutex> lk(m);
-                if (stop_uploads || next_part >= released_parts) {
-                    --live_uploaders;
-                    return;
-                }
-                idx = next_part++;
+                if (stop_uploads || next_part >= released_parts) --live_uploaders;  // nothing left to take: this uploader ends
+                else idx = next_part++;
             }
+            if (idx < 0) break;
             const int ci = idx / P, part = idx % P;
             const int c0 = ci * chunk, nf = std::min(chunk, n_frames - c0), slot = ci % S;
             const int f0 = (int)((long long)nf * part / P), f1 = (int)((long long)nf * (part + 1) / P);
@@ -326,7 +331,8 @@ static int detect_batch_device_tail(agx_detector *det, const void *frames, const
                              hipMemcpyAsync(d_stage + (size_t)slot * chunk_bytes + (size_t)f0 * frame_stride_bytes,
                                             (const uint8_t *)frames + (size_t)(c0 + f0) * frame_stride_bytes, (size_t)(f1 - f0) * frame_stride_bytes,
                                             hipMemcpyHostToDevice, up[part % S]) == hipSuccess &&
-                             hipStreamSynchronize(up[part % S]) == hipSuccess);
+                             (mine ? hipEventRecord(mine, up[part % S]) == hipSuccess && hipEventSynchronize(mine) == hipSuccess
+                                   : hipStreamSynchronize(up[part % S]) == hipSuccess));
             {
                 std::lock_guard<std::mutex> lk(m);
                 if (!ok) chunk_failed[(size_t)ci] = 1;
@@ -334,6 +340,7 @@ static int detect_batch_device_tail(agx_detector *det, const void *frames, const
             }
             cv.notify_all();
         }
+        if (mine) (void)hipEventDestroy(mine);
     };
     // `n_more` chunks' parts may go up: tops the uploaders up to P (ahead of every queued host tail)
     auto release_chunks = [&, P](int n_more) {
